@@ -1,0 +1,609 @@
+// Regrid kernels: precomputed index(+weight) gather over a stack of levels.
+//
+// Replaces, for all levels of a stack in ONE launch, the per-field statements
+//   R: filters/fields/regrid.py:380  data[..., self.nearest_grid_points]
+//   R: filters/fields/regrid.py:310  self.matrix @ data          (scipy csr_matvec)
+//   R: filters/fields/regrid.py:420  data[..., self.mask]
+// that the reference runs once per 2-D field in a Python loop (regrid.py:204-208).
+//
+// HBM-bound gather, no MFMA.  Design:
+//  * ATX_COLUMNS stacks: one target row is `C` 16-byte vectors; a workgroup owns a
+//    tile of consecutive targets, stages their neighbour indices / weights in LDS
+//    once (coalesced), then its 256 lanes sweep the flattened (target, vector)
+//    items — so consecutive lanes read consecutive 16 B of one source column and
+//    write consecutive 16 B of the output.  4 items per lane are in flight
+//    (up to 16 independent 16-byte loads).
+//  * tiles are dealt to XCDs in contiguous ranges (xcd_tile) so neighbouring
+//    targets that share source columns share an L2.
+//  * ATX_FIELDS stacks: lane = target, neighbour indices / weights live in
+//    registers and are reused for every level of the level chunk.
+#include "atx_common.hpp"
+
+namespace atx {
+
+constexpr int kUnroll = 4;  // items in flight per lane (columns kernels)
+
+// ---------------------------------------------------------------------------------
+// ATX_COLUMNS, fixed k (ELL).  K > 0: compile-time k; K == 0: runtime k.
+// ---------------------------------------------------------------------------------
+template <typename T, int VEC, int K, bool WEIGHTED, bool EPI>
+__global__ void __launch_bounds__(kBlock)
+regrid_cols_ell_kernel(const T* __restrict__ src, T* __restrict__ out,
+                       const int32_t* __restrict__ idx, const T* __restrict__ w,
+                       int64_t n_tgt, int k_rt, int n_lev, int C,
+                       int64_t src_pitch, int64_t out_pitch, int tile, unsigned n_tiles,
+                       const atx_level_op* __restrict__ prog, int n_stage,
+                       const uint8_t* __restrict__ tgt_mask) {
+    using V = Pack<T, VEC>;
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int k = K > 0 ? K : k_rt;
+    // LDS carve: weights (widest type first), indices, then the level program
+    T* w_s = reinterpret_cast<T*>(smem);
+    int32_t* idx_s = reinterpret_cast<int32_t*>(w_s + (WEIGHTED ? (size_t)tile * k : 0));
+    LevelOp<T>* prog_s = reinterpret_cast<LevelOp<T>*>(
+        smem + (((WEIGHTED ? (size_t)tile * k * sizeof(T) : 0) + (size_t)tile * k * sizeof(int32_t) + 15) & ~size_t(15)));
+
+    const unsigned tile_id = xcd_tile(blockIdx.x, n_tiles);
+    const int64_t t0 = (int64_t)tile_id * tile;
+    const int nt = (int)min((int64_t)tile, n_tgt - t0);
+    const int tid = threadIdx.x;
+
+    for (int i = tid; i < nt * k; i += kBlock) {
+        idx_s[i] = idx[t0 * k + i];
+        if (WEIGHTED) w_s[i] = w[t0 * k + i];
+    }
+    if (EPI) {
+        const int n_slots = C * VEC;
+        for (int i = tid; i < n_stage * n_slots; i += kBlock) {
+            const int s = i / n_slots, l = i - s * n_slots;
+            LevelOp<T> o;
+            if (l < n_lev) {
+                o = load_level_op<T>(prog, (int64_t)s * n_lev + l);
+            } else {
+                o.op = ATX_OP_COPY; o.use_mask = 0; o.p0 = 0; o.p1 = 0;
+            }
+            prog_s[i] = o;
+        }
+    }
+    __syncthreads();
+
+    const int items = nt * C;
+    const int dt = kBlock / C;
+    const int dc = kBlock - dt * C;
+    int t = tid / C;
+    int c = tid - t * C;
+
+    for (int q = tid; q < items; q += kBlock * kUnroll) {
+        int tt[kUnroll], cc[kUnroll];
+        bool ok[kUnroll];
+#pragma unroll
+        for (int u = 0; u < kUnroll; ++u) {
+            ok[u] = (q + u * kBlock) < items;
+            tt[u] = ok[u] ? t : 0;
+            cc[u] = ok[u] ? c : 0;
+            t += dt;
+            c += dc;
+            if (c >= C) { c -= C; ++t; }
+        }
+
+        V acc[kUnroll];
+        if (K > 0) {
+            // all K*kUnroll loads are independent: issue them before any arithmetic
+            V v[kUnroll][K > 0 ? K : 1];
+#pragma unroll
+            for (int u = 0; u < kUnroll; ++u) {
+#pragma unroll
+                for (int j = 0; j < (K > 0 ? K : 1); ++j) {
+                    const int64_t p = idx_s[tt[u] * K + j];
+                    v[u][j] = *reinterpret_cast<const V*>(src + p * src_pitch + (int64_t)cc[u] * VEC);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < kUnroll; ++u) {
+                if (WEIGHTED) {
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) acc[u].v[e] = T(0);
+#pragma unroll
+                    for (int j = 0; j < (K > 0 ? K : 1); ++j) {
+                        const T wj = w_s[tt[u] * K + j];
+#pragma unroll
+                        for (int e = 0; e < VEC; ++e) acc[u].v[e] = acc[u].v[e] + wj * v[u][j].v[e];
+                    }
+                } else {
+                    acc[u] = v[u][0];
+                }
+            }
+        } else {
+#pragma unroll
+            for (int u = 0; u < kUnroll; ++u) {
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) acc[u].v[e] = T(0);
+                const int base = tt[u] * k;
+                int j = 0;
+                for (; j + 2 <= k; j += 2) {
+                    const int64_t pa = idx_s[base + j], pb = idx_s[base + j + 1];
+                    const V va = *reinterpret_cast<const V*>(src + pa * src_pitch + (int64_t)cc[u] * VEC);
+                    const V vb = *reinterpret_cast<const V*>(src + pb * src_pitch + (int64_t)cc[u] * VEC);
+                    const T wa = WEIGHTED ? w_s[base + j] : T(1), wb = WEIGHTED ? w_s[base + j + 1] : T(1);
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) {
+                        acc[u].v[e] = acc[u].v[e] + wa * va.v[e];
+                        acc[u].v[e] = acc[u].v[e] + wb * vb.v[e];
+                    }
+                }
+                if (j < k) {
+                    const int64_t pa = idx_s[base + j];
+                    const V va = *reinterpret_cast<const V*>(src + pa * src_pitch + (int64_t)cc[u] * VEC);
+                    const T wa = WEIGHTED ? w_s[base + j] : T(1);
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) acc[u].v[e] = acc[u].v[e] + wa * va.v[e];
+                }
+            }
+        }
+
+#pragma unroll
+        for (int u = 0; u < kUnroll; ++u) {
+            if (!ok[u]) continue;
+            if (EPI) {
+                const bool masked = tgt_mask ? (tgt_mask[t0 + tt[u]] != 0) : false;
+                for (int s = 0; s < n_stage; ++s) {
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e)
+                        acc[u].v[e] = apply_level_op(prog_s[s * C * VEC + cc[u] * VEC + e], acc[u].v[e], masked);
+                }
+            }
+            *reinterpret_cast<V*>(out + (t0 + tt[u]) * out_pitch + (int64_t)cc[u] * VEC) = acc[u];
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------
+// ATX_COLUMNS, general CSR.  The tile's slice of (indices, data) is contiguous in
+// the CSR arrays: it is copied to LDS coalesced, then every lane walks its row
+// from LDS (scipy order: sum starts at 0, entries in storage order).
+// ---------------------------------------------------------------------------------
+template <typename T, int VEC, bool EPI>
+__global__ void __launch_bounds__(kBlock)
+regrid_cols_csr_kernel(const T* __restrict__ src, T* __restrict__ out,
+                       const int32_t* __restrict__ indptr, const int32_t* __restrict__ indices,
+                       const T* __restrict__ data, int64_t n_tgt, int n_lev, int C,
+                       int64_t src_pitch, int64_t out_pitch, int tile, unsigned n_tiles, int cap,
+                       const atx_level_op* __restrict__ prog, int n_stage,
+                       const uint8_t* __restrict__ tgt_mask) {
+    using V = Pack<T, VEC>;
+    extern __shared__ __align__(16) unsigned char smem[];
+    T* w_s = reinterpret_cast<T*>(smem);
+    int32_t* idx_s = reinterpret_cast<int32_t*>(w_s + cap);
+    int32_t* rp_s = idx_s + cap;
+    LevelOp<T>* prog_s = reinterpret_cast<LevelOp<T>*>(
+        smem + (((size_t)cap * (sizeof(T) + sizeof(int32_t)) + (size_t)(tile + 1) * sizeof(int32_t) + 15) & ~size_t(15)));
+
+    const unsigned tile_id = xcd_tile(blockIdx.x, n_tiles);
+    const int64_t t0 = (int64_t)tile_id * tile;
+    const int nt = (int)min((int64_t)tile, n_tgt - t0);
+    const int tid = threadIdx.x;
+
+    for (int i = tid; i <= nt; i += kBlock) rp_s[i] = indptr[t0 + i];
+    if (EPI) {
+        const int n_slots = C * VEC;
+        for (int i = tid; i < n_stage * n_slots; i += kBlock) {
+            const int s = i / n_slots, l = i - s * n_slots;
+            LevelOp<T> o;
+            if (l < n_lev) {
+                o = load_level_op<T>(prog, (int64_t)s * n_lev + l);
+            } else {
+                o.op = ATX_OP_COPY; o.use_mask = 0; o.p0 = 0; o.p1 = 0;
+            }
+            prog_s[i] = o;
+        }
+    }
+    __syncthreads();
+    const int64_t base = rp_s[0];
+    const int nnz_tile = rp_s[nt] - rp_s[0];
+    const bool staged = nnz_tile <= cap;  // block-uniform
+    if (staged) {
+        for (int i = tid; i < nnz_tile; i += kBlock) {
+            idx_s[i] = indices[base + i];
+            w_s[i] = data[base + i];
+        }
+    }
+    __syncthreads();
+
+    const int items = nt * C;
+    for (int q = tid; q < items; q += kBlock) {
+        const int t = q / C;
+        const int c = q - t * C;
+        const int j0 = rp_s[t] - rp_s[0], j1 = rp_s[t + 1] - rp_s[0];
+        V acc;
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) acc.v[e] = T(0);
+        int jj = j0;
+        for (; jj + 4 <= j1; jj += 4) {
+            int64_t p[4];
+            T wv[4];
+            V v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                p[u] = staged ? idx_s[jj + u] : indices[base + jj + u];
+                wv[u] = staged ? w_s[jj + u] : data[base + jj + u];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const V*>(src + p[u] * src_pitch + (int64_t)c * VEC);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) acc.v[e] = acc.v[e] + wv[u] * v[u].v[e];
+            }
+        }
+        for (; jj < j1; ++jj) {
+            const int64_t p = staged ? idx_s[jj] : indices[base + jj];
+            const T wv = staged ? w_s[jj] : data[base + jj];
+            const V v = *reinterpret_cast<const V*>(src + p * src_pitch + (int64_t)c * VEC);
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) acc.v[e] = acc.v[e] + wv * v.v[e];
+        }
+        if (EPI) {
+            const bool masked = tgt_mask ? (tgt_mask[t0 + t] != 0) : false;
+            for (int s = 0; s < n_stage; ++s) {
+#pragma unroll
+                for (int e = 0; e < VEC; ++e)
+                    acc.v[e] = apply_level_op(prog_s[s * C * VEC + c * VEC + e], acc.v[e], masked);
+            }
+        }
+        *reinterpret_cast<V*>(out + (t0 + t) * out_pitch + (int64_t)c * VEC) = acc;
+    }
+}
+
+// ---------------------------------------------------------------------------------
+// ATX_FIELDS, fixed k.  lane = target; grid.y = level chunk.
+// ---------------------------------------------------------------------------------
+template <typename T, int K, bool WEIGHTED, bool EPI>
+__global__ void __launch_bounds__(kBlock)
+regrid_fields_ell_kernel(const T* __restrict__ src, T* __restrict__ out,
+                         const int32_t* __restrict__ idx, const T* __restrict__ w,
+                         int64_t n_tgt, int k_rt, int n_lev, int64_t src_pitch, int64_t out_pitch,
+                         int lev_chunk, unsigned n_tiles,
+                         const atx_level_op* __restrict__ prog, int n_stage,
+                         const uint8_t* __restrict__ tgt_mask) {
+    const int k = K > 0 ? K : k_rt;
+    const unsigned tile_id = xcd_tile(blockIdx.x, n_tiles);
+    const int64_t t = (int64_t)tile_id * kBlock + threadIdx.x;
+    if (t >= n_tgt) return;
+    const int l0 = blockIdx.y * lev_chunk;
+    const int l1 = min(n_lev, l0 + lev_chunk);
+    const bool masked = (EPI && tgt_mask) ? (tgt_mask[t] != 0) : false;
+
+    if (K > 0) {
+        int64_t p[K > 0 ? K : 1];
+        T wj[K > 0 ? K : 1];
+#pragma unroll
+        for (int j = 0; j < (K > 0 ? K : 1); ++j) {
+            p[j] = idx[t * K + j];
+            wj[j] = WEIGHTED ? w[t * K + j] : T(1);
+        }
+#pragma unroll 4
+        for (int l = l0; l < l1; ++l) {
+            const T* s = src + (int64_t)l * src_pitch;
+            T acc;
+            if (WEIGHTED) {
+                acc = T(0);
+#pragma unroll
+                for (int j = 0; j < (K > 0 ? K : 1); ++j) acc = acc + wj[j] * s[p[j]];
+            } else {
+                acc = s[p[0]];
+            }
+            if (EPI) {
+                for (int st = 0; st < n_stage; ++st)
+                    acc = apply_level_op(load_level_op<T>(prog, (int64_t)st * n_lev + l), acc, masked);
+            }
+            out[(int64_t)l * out_pitch + t] = acc;
+        }
+    } else {
+        for (int l = l0; l < l1; ++l) {
+            const T* s = src + (int64_t)l * src_pitch;
+            T acc = T(0);
+            for (int j = 0; j < k; ++j) {
+                const T wv = WEIGHTED ? w[t * k + j] : T(1);
+                acc = acc + wv * s[idx[t * k + j]];
+            }
+            if (EPI) {
+                for (int st = 0; st < n_stage; ++st)
+                    acc = apply_level_op(load_level_op<T>(prog, (int64_t)st * n_lev + l), acc, masked);
+            }
+            out[(int64_t)l * out_pitch + t] = acc;
+        }
+    }
+}
+
+// ATX_FIELDS, general CSR: lane = row; the row's entries are re-read per level from
+// L1/L2 (they are the only reused bytes).
+template <typename T, bool EPI>
+__global__ void __launch_bounds__(kBlock)
+regrid_fields_csr_kernel(const T* __restrict__ src, T* __restrict__ out,
+                         const int32_t* __restrict__ indptr, const int32_t* __restrict__ indices,
+                         const T* __restrict__ data, int64_t n_tgt, int n_lev,
+                         int64_t src_pitch, int64_t out_pitch, int lev_chunk, unsigned n_tiles,
+                         const atx_level_op* __restrict__ prog, int n_stage,
+                         const uint8_t* __restrict__ tgt_mask) {
+    const unsigned tile_id = xcd_tile(blockIdx.x, n_tiles);
+    const int64_t t = (int64_t)tile_id * kBlock + threadIdx.x;
+    if (t >= n_tgt) return;
+    const int l0 = blockIdx.y * lev_chunk;
+    const int l1 = min(n_lev, l0 + lev_chunk);
+    const int64_t j0 = indptr[t], j1 = indptr[t + 1];
+    const bool masked = (EPI && tgt_mask) ? (tgt_mask[t] != 0) : false;
+    for (int l = l0; l < l1; ++l) {
+        const T* s = src + (int64_t)l * src_pitch;
+        T acc = T(0);
+        for (int64_t jj = j0; jj < j1; ++jj) acc = acc + data[jj] * s[indices[jj]];
+        if (EPI) {
+            for (int st = 0; st < n_stage; ++st)
+                acc = apply_level_op(load_level_op<T>(prog, (int64_t)st * n_lev + l), acc, masked);
+        }
+        out[(int64_t)l * out_pitch + t] = acc;
+    }
+}
+
+__global__ void __launch_bounds__(kBlock)
+check_indices_kernel(const int32_t* __restrict__ idx, int64_t n, int64_t n_src, unsigned long long* n_bad) {
+    unsigned long long bad = 0;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
+        const int64_t v = idx[i];
+        bad += (v < 0 || v >= n_src) ? 1u : 0u;
+    }
+    // wavefront (64-lane) shuffle reduction, then one atomic per wave
+#pragma unroll
+    for (int off = kWave / 2; off > 0; off >>= 1) bad += __shfl_down(bad, off, kWave);
+    if ((threadIdx.x & (kWave - 1)) == 0 && bad) atomicAdd(n_bad, bad);
+}
+
+// ---------------------------------------------------------------------------------
+// host-side launchers
+// ---------------------------------------------------------------------------------
+static int pick_tile(int64_t n_tgt, int C) {
+    // ~4 sweeps of 256 lanes x kUnroll items per workgroup, at least 8 targets
+    int tile = (kBlock * kUnroll * 2 + C - 1) / C;
+    if (tile < 8) tile = 8;
+    if (tile > 256) tile = 256;
+    if ((int64_t)tile > n_tgt) tile = (int)n_tgt;
+    return tile;
+}
+
+static int g_tile_override = 0;  // tuning hook (atx_set_tuning)
+
+template <typename T, int VEC, int K, bool WEIGHTED>
+static int launch_cols_ell(const T* src, T* out, const int32_t* idx, const T* w, int64_t n_tgt, int k,
+                           int n_lev, int64_t src_pitch, int64_t out_pitch, const atx_level_op* prog,
+                           int n_stage, const uint8_t* tgt_mask, hipStream_t stream) {
+    const int C = (n_lev + VEC - 1) / VEC;
+    int tile = g_tile_override > 0 ? g_tile_override : pick_tile(n_tgt, C);
+    if ((int64_t)tile > n_tgt) tile = (int)n_tgt;
+    const unsigned n_tiles = (unsigned)((n_tgt + tile - 1) / tile);
+    size_t lds = (size_t)tile * k * (sizeof(int32_t) + (WEIGHTED ? sizeof(T) : 0));
+    lds = (lds + 15) & ~size_t(15);
+    if (prog) lds += (size_t)n_stage * C * VEC * sizeof(LevelOp<T>);
+    ATX_REQUIRE(lds <= 64 * 1024, ATX_ENOTIMPL, "regrid_ell: tile needs %zu B of LDS (k=%d, n_lev=%d, stages=%d)", lds, k, n_lev, n_stage);
+    if (prog) {
+        hipLaunchKernelGGL((regrid_cols_ell_kernel<T, VEC, K, WEIGHTED, true>), dim3(n_tiles), dim3(kBlock), lds, stream,
+                           src, out, idx, w, n_tgt, k, n_lev, C, src_pitch, out_pitch, tile, n_tiles, prog, n_stage, tgt_mask);
+    } else {
+        hipLaunchKernelGGL((regrid_cols_ell_kernel<T, VEC, K, WEIGHTED, false>), dim3(n_tiles), dim3(kBlock), lds, stream,
+                           src, out, idx, w, n_tgt, k, n_lev, C, src_pitch, out_pitch, tile, n_tiles, prog, n_stage, tgt_mask);
+    }
+    ATX_LAUNCH_CHECK("regrid_cols_ell");
+    return ATX_OK;
+}
+
+template <typename T, int VEC>
+static int dispatch_cols_ell(const T* src, T* out, const int32_t* idx, const T* w, int64_t n_tgt, int k,
+                             int n_lev, int64_t sp, int64_t op, const atx_level_op* prog, int n_stage,
+                             const uint8_t* m, hipStream_t st) {
+    if (!w) return launch_cols_ell<T, VEC, 1, false>(src, out, idx, w, n_tgt, k, n_lev, sp, op, prog, n_stage, m, st);
+    switch (k) {
+        case 1: return launch_cols_ell<T, VEC, 1, true>(src, out, idx, w, n_tgt, k, n_lev, sp, op, prog, n_stage, m, st);
+        case 2: return launch_cols_ell<T, VEC, 2, true>(src, out, idx, w, n_tgt, k, n_lev, sp, op, prog, n_stage, m, st);
+        case 3: return launch_cols_ell<T, VEC, 3, true>(src, out, idx, w, n_tgt, k, n_lev, sp, op, prog, n_stage, m, st);
+        case 4: return launch_cols_ell<T, VEC, 4, true>(src, out, idx, w, n_tgt, k, n_lev, sp, op, prog, n_stage, m, st);
+        default: return launch_cols_ell<T, VEC, 0, true>(src, out, idx, w, n_tgt, k, n_lev, sp, op, prog, n_stage, m, st);
+    }
+}
+
+static int pick_lev_chunk(int n_lev) {
+    // enough level chunks for >= ~4 workgroups per CU even on small grids, chunks >= 8 levels
+    int chunks = (n_lev + 31) / 32;
+    return (n_lev + chunks - 1) / chunks;
+}
+
+template <typename T, int K, bool WEIGHTED>
+static int launch_fields_ell(const T* src, T* out, const int32_t* idx, const T* w, int64_t n_tgt, int k,
+                             int n_lev, int64_t sp, int64_t op, const atx_level_op* prog, int n_stage,
+                             const uint8_t* m, hipStream_t st) {
+    const unsigned n_tiles = (unsigned)((n_tgt + kBlock - 1) / kBlock);
+    const int lev_chunk = pick_lev_chunk(n_lev);
+    const unsigned n_chunks = (unsigned)((n_lev + lev_chunk - 1) / lev_chunk);
+    ATX_REQUIRE(n_chunks <= 65535, ATX_ENOTIMPL, "regrid_ell: too many level chunks (%u)", n_chunks);
+    if (prog) {
+        hipLaunchKernelGGL((regrid_fields_ell_kernel<T, K, WEIGHTED, true>), dim3(n_tiles, n_chunks), dim3(kBlock), 0, st,
+                           src, out, idx, w, n_tgt, k, n_lev, sp, op, lev_chunk, n_tiles, prog, n_stage, m);
+    } else {
+        hipLaunchKernelGGL((regrid_fields_ell_kernel<T, K, WEIGHTED, false>), dim3(n_tiles, n_chunks), dim3(kBlock), 0, st,
+                           src, out, idx, w, n_tgt, k, n_lev, sp, op, lev_chunk, n_tiles, prog, n_stage, m);
+    }
+    ATX_LAUNCH_CHECK("regrid_fields_ell");
+    return ATX_OK;
+}
+
+template <typename T>
+static int dispatch_fields_ell(const T* src, T* out, const int32_t* idx, const T* w, int64_t n_tgt, int k,
+                               int n_lev, int64_t sp, int64_t op, const atx_level_op* prog, int n_stage,
+                               const uint8_t* m, hipStream_t st) {
+    if (!w) return launch_fields_ell<T, 1, false>(src, out, idx, w, n_tgt, k, n_lev, sp, op, prog, n_stage, m, st);
+    switch (k) {
+        case 1: return launch_fields_ell<T, 1, true>(src, out, idx, w, n_tgt, k, n_lev, sp, op, prog, n_stage, m, st);
+        case 2: return launch_fields_ell<T, 2, true>(src, out, idx, w, n_tgt, k, n_lev, sp, op, prog, n_stage, m, st);
+        case 3: return launch_fields_ell<T, 3, true>(src, out, idx, w, n_tgt, k, n_lev, sp, op, prog, n_stage, m, st);
+        case 4: return launch_fields_ell<T, 4, true>(src, out, idx, w, n_tgt, k, n_lev, sp, op, prog, n_stage, m, st);
+        default: return launch_fields_ell<T, 0, true>(src, out, idx, w, n_tgt, k, n_lev, sp, op, prog, n_stage, m, st);
+    }
+}
+
+template <typename T>
+static bool cols_vector_ok(const void* src, const void* out, int64_t sp, int64_t op) {
+    constexpr int VEC = Vec16<T>::N;
+    return aligned16(src) && aligned16(out) && (sp % VEC == 0) && (op % VEC == 0);
+}
+
+template <typename T>
+static int regrid_ell_typed(const void* src_, void* out_, const int32_t* idx, const void* w_, int64_t n_tgt, int k,
+                            int n_lev, int64_t sp, int64_t op, int layout, const atx_level_op* prog, int n_stage,
+                            const uint8_t* m, hipStream_t st) {
+    const T* src = static_cast<const T*>(src_);
+    T* out = static_cast<T*>(out_);
+    const T* w = static_cast<const T*>(w_);
+    if (layout == ATX_COLUMNS) {
+        constexpr int VEC = Vec16<T>::N;
+        // the vector path needs every row start 16-byte aligned and room for the
+        // last (partial) vector inside the pitch
+        const int64_t covered = ((int64_t)(n_lev + VEC - 1) / VEC) * VEC;
+        if (cols_vector_ok<T>(src_, out_, sp, op) && covered <= sp && covered <= op)
+            return dispatch_cols_ell<T, VEC>(src, out, idx, w, n_tgt, k, n_lev, sp, op, prog, n_stage, m, st);
+        return dispatch_cols_ell<T, 1>(src, out, idx, w, n_tgt, k, n_lev, sp, op, prog, n_stage, m, st);
+    }
+    return dispatch_fields_ell<T>(src, out, idx, w, n_tgt, k, n_lev, sp, op, prog, n_stage, m, st);
+}
+
+template <typename T, int VEC>
+static int launch_cols_csr(const T* src, T* out, const int32_t* indptr, const int32_t* indices, const T* data,
+                           int64_t n_tgt, int64_t nnz, int n_lev, int64_t sp, int64_t op,
+                           const atx_level_op* prog, int n_stage, const uint8_t* m, hipStream_t st) {
+    const int C = (n_lev + VEC - 1) / VEC;
+    int tile = g_tile_override > 0 ? g_tile_override : pick_tile(n_tgt, C);
+    if ((int64_t)tile > n_tgt) tile = (int)n_tgt;
+    const unsigned n_tiles = (unsigned)((n_tgt + tile - 1) / tile);
+    // LDS room for ~2x the mean entries of a tile (tiles above it read CSR from L2)
+    const double mean = n_tgt > 0 ? (double)nnz / (double)n_tgt : 0.0;
+    int cap = (int)(mean * tile * 2.0) + 64;
+    if (cap > 4096) cap = 4096;
+    size_t lds = (size_t)cap * (sizeof(T) + sizeof(int32_t)) + (size_t)(tile + 1) * sizeof(int32_t);
+    lds = (lds + 15) & ~size_t(15);
+    if (prog) lds += (size_t)n_stage * C * VEC * sizeof(LevelOp<T>);
+    ATX_REQUIRE(lds <= 64 * 1024, ATX_ENOTIMPL, "regrid_csr: tile needs %zu B of LDS", lds);
+    if (prog) {
+        hipLaunchKernelGGL((regrid_cols_csr_kernel<T, VEC, true>), dim3(n_tiles), dim3(kBlock), lds, st, src, out, indptr,
+                           indices, data, n_tgt, n_lev, C, sp, op, tile, n_tiles, cap, prog, n_stage, m);
+    } else {
+        hipLaunchKernelGGL((regrid_cols_csr_kernel<T, VEC, false>), dim3(n_tiles), dim3(kBlock), lds, st, src, out, indptr,
+                           indices, data, n_tgt, n_lev, C, sp, op, tile, n_tiles, cap, prog, n_stage, m);
+    }
+    ATX_LAUNCH_CHECK("regrid_cols_csr");
+    return ATX_OK;
+}
+
+template <typename T>
+static int regrid_csr_typed(const void* src_, void* out_, const int32_t* indptr, const int32_t* indices,
+                            const void* data_, int64_t n_tgt, int64_t nnz, int n_lev, int64_t sp, int64_t op,
+                            int layout, const atx_level_op* prog, int n_stage, const uint8_t* m, hipStream_t st) {
+    const T* src = static_cast<const T*>(src_);
+    T* out = static_cast<T*>(out_);
+    const T* data = static_cast<const T*>(data_);
+    if (layout == ATX_COLUMNS) {
+        constexpr int VEC = Vec16<T>::N;
+        const int64_t covered = ((int64_t)(n_lev + VEC - 1) / VEC) * VEC;
+        if (cols_vector_ok<T>(src_, out_, sp, op) && covered <= sp && covered <= op)
+            return launch_cols_csr<T, VEC>(src, out, indptr, indices, data, n_tgt, nnz, n_lev, sp, op, prog, n_stage, m, st);
+        return launch_cols_csr<T, 1>(src, out, indptr, indices, data, n_tgt, nnz, n_lev, sp, op, prog, n_stage, m, st);
+    }
+    const unsigned n_tiles = (unsigned)((n_tgt + kBlock - 1) / kBlock);
+    const int lev_chunk = pick_lev_chunk(n_lev);
+    const unsigned n_chunks = (unsigned)((n_lev + lev_chunk - 1) / lev_chunk);
+    ATX_REQUIRE(n_chunks <= 65535, ATX_ENOTIMPL, "regrid_csr: too many level chunks (%u)", n_chunks);
+    if (prog) {
+        hipLaunchKernelGGL((regrid_fields_csr_kernel<T, true>), dim3(n_tiles, n_chunks), dim3(kBlock), 0, st, src, out,
+                           indptr, indices, data, n_tgt, n_lev, sp, op, lev_chunk, n_tiles, prog, n_stage, m);
+    } else {
+        hipLaunchKernelGGL((regrid_fields_csr_kernel<T, false>), dim3(n_tiles, n_chunks), dim3(kBlock), 0, st, src, out,
+                           indptr, indices, data, n_tgt, n_lev, sp, op, lev_chunk, n_tiles, prog, n_stage, m);
+    }
+    ATX_LAUNCH_CHECK("regrid_fields_csr");
+    return ATX_OK;
+}
+
+static int check_stack_args(const char* fn, const void* src, const void* out, int64_t n_src, int64_t n_tgt,
+                            int64_t n_lev, int64_t sp, int64_t op, int dtype, int layout) {
+    ATX_REQUIRE(src && out, ATX_EINVAL, "%s: null src/out pointer", fn);
+    ATX_REQUIRE(dtype == ATX_F32 || dtype == ATX_F64, ATX_EINVAL, "%s: bad dtype %d", fn, dtype);
+    ATX_REQUIRE(layout == ATX_COLUMNS || layout == ATX_FIELDS, ATX_EINVAL, "%s: bad layout %d", fn, layout);
+    ATX_REQUIRE(n_src > 0 && n_tgt >= 0 && n_lev > 0, ATX_EINVAL, "%s: bad sizes n_src=%lld n_tgt=%lld n_lev=%lld", fn,
+                (long long)n_src, (long long)n_tgt, (long long)n_lev);
+    ATX_REQUIRE(n_src <= INT32_MAX && n_tgt <= INT32_MAX && n_lev <= 65535, ATX_ENOTIMPL,
+                "%s: sizes exceed int32 indexing (n_src=%lld n_tgt=%lld n_lev=%lld)", fn, (long long)n_src,
+                (long long)n_tgt, (long long)n_lev);
+    if (layout == ATX_COLUMNS) {
+        ATX_REQUIRE(sp >= n_lev && op >= n_lev, ATX_ESHAPE, "%s: column pitch (%lld, %lld) < n_lev %lld", fn,
+                    (long long)sp, (long long)op, (long long)n_lev);
+    } else {
+        ATX_REQUIRE(sp >= n_src && op >= n_tgt, ATX_ESHAPE, "%s: field pitch (%lld, %lld) < points (%lld, %lld)", fn,
+                    (long long)sp, (long long)op, (long long)n_src, (long long)n_tgt);
+    }
+    return ATX_OK;
+}
+
+}  // namespace atx
+
+using namespace atx;
+
+extern "C" int atx_set_tuning(int tile) {
+    g_tile_override = tile;
+    return ATX_OK;
+}
+
+extern "C" int atx_regrid_ell(const void* src, void* out, const int32_t* idx, const void* w, int64_t n_src,
+                              int64_t n_tgt, int32_t k, int64_t n_lev, int64_t src_pitch, int64_t out_pitch,
+                              int dtype, int layout, const atx_level_op* prog, int32_t n_stage,
+                              const uint8_t* tgt_mask, void* stream) {
+    int st = check_stack_args("atx_regrid_ell", src, out, n_src, n_tgt, n_lev, src_pitch, out_pitch, dtype, layout);
+    if (st != ATX_OK) return st;
+    ATX_REQUIRE(idx, ATX_EINVAL, "atx_regrid_ell: null idx");
+    ATX_REQUIRE(k >= 1 && k <= 64, ATX_EINVAL, "atx_regrid_ell: k=%d outside [1, 64]", k);
+    ATX_REQUIRE(w || k == 1, ATX_EINVAL, "atx_regrid_ell: a pure gather (w == NULL) needs k == 1, got %d", k);
+    ATX_REQUIRE((prog == nullptr) == (n_stage == 0) && n_stage >= 0 && n_stage <= 8, ATX_EINVAL,
+                "atx_regrid_ell: prog/n_stage mismatch (n_stage=%d)", n_stage);
+    if (n_tgt == 0) return ATX_OK;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (dtype == ATX_F32)
+        return regrid_ell_typed<float>(src, out, idx, w, n_tgt, k, (int)n_lev, src_pitch, out_pitch, layout, prog, n_stage, tgt_mask, s);
+    return regrid_ell_typed<double>(src, out, idx, w, n_tgt, k, (int)n_lev, src_pitch, out_pitch, layout, prog, n_stage, tgt_mask, s);
+}
+
+extern "C" int atx_regrid_csr(const void* src, void* out, const int32_t* indptr, const int32_t* indices,
+                              const void* data, int64_t n_src, int64_t n_tgt, int64_t nnz, int64_t n_lev,
+                              int64_t src_pitch, int64_t out_pitch, int dtype, int layout, const atx_level_op* prog,
+                              int32_t n_stage, const uint8_t* tgt_mask, void* stream) {
+    int st = check_stack_args("atx_regrid_csr", src, out, n_src, n_tgt, n_lev, src_pitch, out_pitch, dtype, layout);
+    if (st != ATX_OK) return st;
+    ATX_REQUIRE(indptr, ATX_EINVAL, "atx_regrid_csr: null indptr");
+    ATX_REQUIRE(nnz >= 0 && nnz <= INT32_MAX, ATX_ENOTIMPL, "atx_regrid_csr: nnz=%lld outside int32", (long long)nnz);
+    ATX_REQUIRE(nnz == 0 || (indices && data), ATX_EINVAL, "atx_regrid_csr: null indices/data");
+    ATX_REQUIRE((prog == nullptr) == (n_stage == 0) && n_stage >= 0 && n_stage <= 8, ATX_EINVAL,
+                "atx_regrid_csr: prog/n_stage mismatch (n_stage=%d)", n_stage);
+    if (n_tgt == 0) return ATX_OK;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (dtype == ATX_F32)
+        return regrid_csr_typed<float>(src, out, indptr, indices, data, n_tgt, nnz, (int)n_lev, src_pitch, out_pitch, layout, prog, n_stage, tgt_mask, s);
+    return regrid_csr_typed<double>(src, out, indptr, indices, data, n_tgt, nnz, (int)n_lev, src_pitch, out_pitch, layout, prog, n_stage, tgt_mask, s);
+}
+
+extern "C" int atx_check_indices(const int32_t* idx, int64_t n, int64_t n_src, int64_t* n_bad, void* stream) {
+    ATX_REQUIRE(idx && n_bad, ATX_EINVAL, "atx_check_indices: null pointer");
+    ATX_REQUIRE(n >= 0 && n_src >= 0, ATX_EINVAL, "atx_check_indices: negative size");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    int st = hip_status(hipMemsetAsync(n_bad, 0, sizeof(int64_t), s), "atx_check_indices memset");
+    if (st != ATX_OK) return st;
+    if (n == 0) return ATX_OK;
+    int64_t blocks = (n + kBlock - 1) / kBlock;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(check_indices_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, s, idx, n, n_src,
+                       reinterpret_cast<unsigned long long*>(n_bad));
+    ATX_LAUNCH_CHECK("check_indices");
+    return ATX_OK;
+}

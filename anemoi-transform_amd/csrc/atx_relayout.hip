@@ -1,0 +1,109 @@
+// Layout conversion between field-major (ATX_FIELDS, the reference's unit:
+// `field.to_numpy()`, R: fields.py:178-202) and column stacks (ATX_COLUMNS, the
+// engine's native HBM layout).
+//
+// A workgroup moves TP points x LC levels through LDS.  On the FIELDS side a wave
+// touches 256 contiguous bytes of one level; on the COLUMNS side the TP columns of
+// the tile form one contiguous TP*pitch run, swept by consecutive lanes.  The LDS
+// tile is [point][level] with an odd row length (in 4-byte words for f32) so both
+// phases are bank-conflict free for f32 and at most 2-way for f64.
+#include "atx_common.hpp"
+
+namespace atx {
+
+template <typename T, bool TO_COLUMNS>
+__global__ void __launch_bounds__(kBlock)
+transpose_kernel(const T* __restrict__ src, T* __restrict__ dst, int64_t n_pts, int n_lev,
+                 int64_t src_pitch, int64_t dst_pitch, int TP, int LC, int LCpad) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    T* tile = reinterpret_cast<T*>(smem);
+    const int64_t p0 = (int64_t)blockIdx.x * TP;
+    const int l0 = blockIdx.y * LC;
+    const int np = (int)min((int64_t)TP, n_pts - p0);
+    const int nl = min(LC, n_lev - l0);
+    const int tid = threadIdx.x;
+
+    // fields side: element (p, l) at base[l*pitch + p]; columns side: base[p*pitch + l]
+    if (TO_COLUMNS) {
+        for (int i = tid; i < nl * TP; i += kBlock) {
+            const int l = i / TP, p = i - l * TP;
+            if (p < np) tile[p * LCpad + l] = src[(int64_t)(l0 + l) * src_pitch + p0 + p];
+        }
+        __syncthreads();
+        for (int i = tid; i < np * nl; i += kBlock) {
+            const int p = i / nl, l = i - p * nl;
+            dst[(p0 + p) * dst_pitch + l0 + l] = tile[p * LCpad + l];
+        }
+    } else {
+        for (int i = tid; i < np * nl; i += kBlock) {
+            const int p = i / nl, l = i - p * nl;
+            tile[p * LCpad + l] = src[(p0 + p) * src_pitch + l0 + l];
+        }
+        __syncthreads();
+        for (int i = tid; i < nl * TP; i += kBlock) {
+            const int l = i / TP, p = i - l * TP;
+            if (p < np) dst[(int64_t)(l0 + l) * dst_pitch + p0 + p] = tile[p * LCpad + l];
+        }
+    }
+}
+
+// same layout on both sides: pitched copy of rows of `row_len` elements
+template <typename T>
+__global__ void __launch_bounds__(kBlock)
+pitched_copy_kernel(const T* __restrict__ src, T* __restrict__ dst, int64_t n_rows, int64_t row_len,
+                    int64_t src_pitch, int64_t dst_pitch) {
+    const int64_t total = n_rows * row_len;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < total; i += (int64_t)gridDim.x * kBlock) {
+        const int64_t r = i / row_len, c = i - r * row_len;
+        dst[r * dst_pitch + c] = src[r * src_pitch + c];
+    }
+}
+
+template <typename T>
+static int relayout_typed(const void* src_, void* dst_, int64_t n_pts, int n_lev, int64_t sp, int64_t dp,
+                          int src_layout, int dst_layout, hipStream_t st) {
+    const T* src = static_cast<const T*>(src_);
+    T* dst = static_cast<T*>(dst_);
+    if (src_layout == dst_layout) {
+        const int64_t n_rows = src_layout == ATX_COLUMNS ? n_pts : n_lev;
+        const int64_t row_len = src_layout == ATX_COLUMNS ? n_lev : n_pts;
+        int64_t blocks = (n_rows * row_len + kBlock - 1) / kBlock;
+        if (blocks > 2048) blocks = 2048;
+        hipLaunchKernelGGL(pitched_copy_kernel<T>, dim3((unsigned)blocks), dim3(kBlock), 0, st, src, dst, n_rows, row_len, sp, dp);
+        ATX_LAUNCH_CHECK("pitched_copy");
+        return ATX_OK;
+    }
+    const int TP = 256 / (int)sizeof(T);  // 256 contiguous bytes per level on the fields side
+    int LC = n_lev < 160 ? n_lev : 128;
+    const int LCpad = LC | 1;
+    const size_t lds = (size_t)TP * LCpad * sizeof(T);
+    const unsigned gx = (unsigned)((n_pts + TP - 1) / TP);
+    const unsigned gy = (unsigned)((n_lev + LC - 1) / LC);
+    ATX_REQUIRE(gy <= 65535, ATX_ENOTIMPL, "atx_relayout: too many level chunks");
+    if (dst_layout == ATX_COLUMNS)
+        hipLaunchKernelGGL((transpose_kernel<T, true>), dim3(gx, gy), dim3(kBlock), lds, st, src, dst, n_pts, n_lev, sp, dp, TP, LC, LCpad);
+    else
+        hipLaunchKernelGGL((transpose_kernel<T, false>), dim3(gx, gy), dim3(kBlock), lds, st, src, dst, n_pts, n_lev, sp, dp, TP, LC, LCpad);
+    ATX_LAUNCH_CHECK("transpose");
+    return ATX_OK;
+}
+
+}  // namespace atx
+
+using namespace atx;
+
+extern "C" int atx_relayout(const void* src, void* dst, int64_t n_pts, int64_t n_lev, int64_t src_pitch,
+                            int64_t dst_pitch, int src_layout, int dst_layout, int dtype, void* stream) {
+    ATX_REQUIRE(src && dst, ATX_EINVAL, "atx_relayout: null pointer");
+    ATX_REQUIRE(src != dst, ATX_EINVAL, "atx_relayout: in-place relayout is not supported");
+    ATX_REQUIRE(dtype == ATX_F32 || dtype == ATX_F64, ATX_EINVAL, "atx_relayout: bad dtype %d", dtype);
+    ATX_REQUIRE((src_layout == ATX_COLUMNS || src_layout == ATX_FIELDS) && (dst_layout == ATX_COLUMNS || dst_layout == ATX_FIELDS),
+                ATX_EINVAL, "atx_relayout: bad layout (%d, %d)", src_layout, dst_layout);
+    ATX_REQUIRE(n_pts >= 0 && n_lev > 0 && n_lev <= INT32_MAX, ATX_EINVAL, "atx_relayout: bad sizes");
+    ATX_REQUIRE(src_pitch >= (src_layout == ATX_COLUMNS ? n_lev : n_pts), ATX_ESHAPE, "atx_relayout: src pitch %lld too small", (long long)src_pitch);
+    ATX_REQUIRE(dst_pitch >= (dst_layout == ATX_COLUMNS ? n_lev : n_pts), ATX_ESHAPE, "atx_relayout: dst pitch %lld too small", (long long)dst_pitch);
+    if (n_pts == 0) return ATX_OK;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (dtype == ATX_F32) return relayout_typed<float>(src, dst, n_pts, (int)n_lev, src_pitch, dst_pitch, src_layout, dst_layout, s);
+    return relayout_typed<double>(src, dst, n_pts, (int)n_lev, src_pitch, dst_pitch, src_layout, dst_layout, s);
+}

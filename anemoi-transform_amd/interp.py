@@ -1,0 +1,160 @@
+"""Index / weight precompute for the regrid filter (CPU, one-off per grid pair).
+
+The reference builds its gather indices with ``scipy.spatial.cKDTree`` on
+unit-sphere coordinates (R: spatial.py:132-167, 587-635) and reads interpolation
+matrices written by ``anemoi-transform make-regrid-file`` as ``.npz`` CSR
+triplets (R: commands/make-regrid-file.py:150-160, filters/fields/regrid.py:281-290).
+Both stay on the CPU here (one-off, seconds); their OUTPUTS
+feed the HIP gather kernels.  The external ``mir`` binary the reference shells
+out to for bilinear matrices is not available offline, so this module also
+generates k-NN inverse-distance and bilinear matrices in the same npz format.
+"""
+
+from __future__ import annotations
+
+from typing import Any
+
+import numpy as np
+
+from .grids import gaussian_latitudes, octahedral_row_lengths
+
+__all__ = [
+    "unit_sphere_xyz",
+    "nearest_grid_points",
+    "knn_inverse_distance",
+    "ell_to_csr",
+    "csr_uniform_k",
+    "bilinear_octahedral",
+    "save_matrix_npz",
+    "load_matrix_npz",
+]
+
+
+def unit_sphere_xyz(latitudes: np.ndarray, longitudes: np.ndarray) -> np.ndarray:
+    """``[N, 3]`` Cartesian coordinates on the unit sphere (R: spatial.py:132-167)."""
+    phi = np.deg2rad(np.asarray(latitudes, dtype=np.float64))
+    lda = np.deg2rad(np.asarray(longitudes, dtype=np.float64))
+    cos_phi = np.cos(phi)
+    return np.array((cos_phi * np.cos(lda), cos_phi * np.sin(lda), np.sin(phi))).transpose()
+
+
+def nearest_grid_points(
+    source_latitudes,
+    source_longitudes,
+    target_latitudes,
+    target_longitudes,
+    max_distance: float | None = None,
+    num_neighbours_to_return: int = 1,
+    return_distances: bool = False,
+):
+    """k nearest source points of every target point, by chord distance.
+
+    Same call surface and return order as the reference (R: spatial.py:587-635):
+    ``indices`` (int64, ``[Nt]`` or ``[Nt, k]``) or ``(indices, distances)``.
+    With ``max_distance`` cKDTree reports ``len(source)`` for "none found"
+    (R: spatial.py:630-632); the regrid filter rejects such indices before any
+    gather (``native.check_indices``).
+    """
+    from scipy.spatial import cKDTree
+
+    tree = cKDTree(unit_sphere_xyz(source_latitudes, source_longitudes))
+    kwargs = {} if max_distance is None else {"distance_upper_bound": max_distance}
+    distances, indices = tree.query(
+        unit_sphere_xyz(target_latitudes, target_longitudes), k=num_neighbours_to_return, **kwargs
+    )
+    if return_distances:
+        return indices, distances
+    return indices
+
+
+def knn_inverse_distance(in_grid: dict, out_grid: dict, k: int = 4, floor: float = 1e-12):
+    """k-NN inverse-distance weights ``w_j = (1/max(d_j, floor)) / sum``.
+
+    Returns ``(idx [Nt, k] int64, w [Nt, k] float64)``.
+    """
+    idx, dist = nearest_grid_points(
+        in_grid["latitudes"], in_grid["longitudes"], out_grid["latitudes"], out_grid["longitudes"],
+        num_neighbours_to_return=k, return_distances=True,
+    )
+    idx = idx.reshape(len(idx), -1)
+    dist = dist.reshape(len(dist), -1)
+    inv = 1.0 / np.maximum(dist, floor)
+    return idx, inv / inv.sum(axis=1, keepdims=True)
+
+
+def ell_to_csr(idx: np.ndarray, w: np.ndarray, n_src: int) -> dict[str, np.ndarray]:
+    """Fixed-k index/weight table as the CSR triplet of the MIR npz format."""
+    n_tgt, k = idx.shape
+    return dict(
+        matrix_data=np.ascontiguousarray(w, dtype=np.float64).reshape(-1),
+        matrix_indices=np.ascontiguousarray(idx, dtype=np.int32).reshape(-1),
+        matrix_indptr=(np.arange(n_tgt + 1, dtype=np.int64) * k).astype(np.int32),
+        matrix_shape=np.array([n_tgt, n_src]),
+    )
+
+
+def csr_uniform_k(indptr: np.ndarray) -> int | None:
+    """Row length if every CSR row holds the same number of entries, else ``None``."""
+    lengths = np.diff(indptr)
+    if lengths.size and (lengths == lengths[0]).all() and lengths[0] > 0:
+        return int(lengths[0])
+    return None
+
+
+def bilinear_octahedral(n: int, out_grid: dict) -> dict[str, np.ndarray]:
+    """Bilinear weights from the octahedral grid ``O<n>`` to arbitrary target points.
+
+    Two bracketing Gaussian rows x two bracketing longitudes per row (periodic),
+    linear in longitude on each row, then linear in latitude; above the first /
+    below the last row the nearest row is used alone.  Always 4 entries per target
+    (zero weights are kept) so the matrix is fixed-k.
+    """
+    lats = gaussian_latitudes(2 * n)  # north -> south
+    nlon = octahedral_row_lengths(n)
+    row_start = np.concatenate([[0], np.cumsum(nlon)[:-1]])
+    tlat = np.asarray(out_grid["latitudes"], dtype=np.float64)
+    tlon = np.mod(np.asarray(out_grid["longitudes"], dtype=np.float64), 360.0)
+
+    # first row whose latitude is <= target latitude (rows descend)
+    south = np.searchsorted(-lats, -tlat, side="left")
+    north = south - 1
+    south = np.clip(south, 0, len(lats) - 1)
+    north = np.clip(north, 0, len(lats) - 1)
+    span = lats[north] - lats[south]
+    w_north = np.where(span > 0, (tlat - lats[south]) / np.where(span > 0, span, 1.0), 1.0)
+    w_north = np.clip(w_north, 0.0, 1.0)
+
+    idx = np.empty((len(tlat), 4), dtype=np.int64)
+    w = np.empty((len(tlat), 4), dtype=np.float64)
+    for slot, (row, w_row) in enumerate(((north, w_north), (south, 1.0 - w_north))):
+        m = nlon[row]
+        x = tlon * (m / 360.0)
+        j0 = np.floor(x).astype(np.int64)
+        frac = x - j0
+        j0 = np.mod(j0, m)
+        j1 = np.mod(j0 + 1, m)
+        idx[:, 2 * slot] = row_start[row] + j0
+        idx[:, 2 * slot + 1] = row_start[row] + j1
+        w[:, 2 * slot] = w_row * (1.0 - frac)
+        w[:, 2 * slot + 1] = w_row * frac
+    return ell_to_csr(idx, w, int(nlon.sum()))
+
+
+def save_matrix_npz(path: str, matrix: dict[str, np.ndarray], in_grid: dict, out_grid: dict) -> None:
+    """Write the regrid-matrix npz the reference reads (R: make-regrid-file.py:150-160)."""
+    np.savez(
+        path,
+        matrix_data=matrix["matrix_data"],
+        matrix_indices=matrix["matrix_indices"],
+        matrix_indptr=matrix["matrix_indptr"],
+        matrix_shape=matrix["matrix_shape"],
+        in_latitudes=in_grid["latitudes"],
+        in_longitudes=in_grid["longitudes"],
+        out_latitudes=out_grid["latitudes"],
+        out_longitudes=out_grid["longitudes"],
+    )
+
+
+def load_matrix_npz(path: str) -> dict[str, Any]:
+    """R: regrid.py:281."""
+    return dict(np.load(path))

@@ -1,0 +1,248 @@
+"""ctypes binding of libatx — the only compute path of this package.
+
+There is no CPU fallback: if ``lib/libatx.so`` is missing, or a tensor handed to
+one of the wrappers does not live in HBM, the call raises.  Return codes of the
+C ABI (``include/atx.h``) are mapped to the exception types the reference raises
+on this path: ``ValueError`` for bad configuration, ``AssertionError`` for shape
+mismatches (R: filters/fields/regrid.py:377-378), ``NotImplementedError`` for
+unsupported combinations (R: regrid.py:332-335).
+"""
+
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import POINTER, c_char_p, c_double, c_int, c_int32, c_int64, c_size_t, c_void_p
+from typing import Any
+
+import numpy as np
+import torch
+
+LIB_NAME = "libatx.so"
+LIB_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib")
+
+# atx_dtype / atx_layout / atx_cmp / atx_op / atx_red (include/atx.h)
+F32, F64 = 0, 1
+COLUMNS, FIELDS = 0, 1
+CMP_GT, CMP_LT, CMP_EQ, CMP_NE, CMP_GE, CMP_LE, CMP_NOTNAN, CMP_ISNAN = range(8)
+(
+    OP_COPY,
+    OP_AFFINE,
+    OP_AFFINE_INV,
+    OP_MUL,
+    OP_DIV,
+    OP_CLIP,
+    OP_IMPUTE_NAN,
+    OP_EXP,
+    OP_LOG,
+    OP_SET_NAN,
+) = range(10)
+RED_MIN, RED_MAX, RED_NANCOUNT = range(3)
+
+OK, EINVAL, ESHAPE, ENOTIMPL, EHIP, EALIGN, EWORKSPACE = 0, -1, -2, -3, -4, -5, -6
+
+# numpy layout of `atx_level_op` (24 bytes)
+LEVEL_OP_DTYPE = np.dtype([("op", "<i4"), ("use_mask", "<i4"), ("p0", "<f8"), ("p1", "<f8")])
+
+# every symbol include/atx.h declares: name -> (restype, argtypes)
+SIGNATURES: dict[str, tuple[Any, list[Any]]] = {
+    "atx_version": (c_int, []),
+    "atx_last_error": (c_char_p, []),
+    "atx_strerror": (c_char_p, [c_int]),
+    "atx_device_count": (c_int, []),
+    "atx_set_tuning": (c_int, [c_int]),
+    "atx_regrid_ell": (
+        c_int,
+        [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int32, c_int64, c_int64, c_int64, c_int, c_int,
+         c_void_p, c_int32, c_void_p, c_void_p],
+    ),
+    "atx_regrid_csr": (
+        c_int,
+        [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int64, c_int64, c_int64, c_int,
+         c_int, c_void_p, c_int32, c_void_p, c_void_p],
+    ),
+    "atx_check_indices": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_void_p]),
+    "atx_pointwise_stack": (
+        c_int,
+        [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int64, c_int, c_int, c_void_p, c_int32, c_void_p, c_void_p],
+    ),
+    "atx_mask_build": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int, c_double, c_int, c_void_p]),
+    "atx_mask_count": (c_int, [c_void_p, c_int64, c_void_p, c_void_p]),
+    "atx_mask_to_index_workspace": (c_size_t, [c_int64]),
+    "atx_mask_to_index": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "atx_reduce": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_int, c_void_p]),
+    "atx_relayout": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int64, c_int, c_int, c_int, c_void_p]),
+}
+
+_lib: ctypes.CDLL | None = None
+
+
+class AtxError(RuntimeError):
+    """HIP runtime failure inside libatx."""
+
+
+def lib_path() -> str:
+    return os.path.join(LIB_DIR, LIB_NAME)
+
+
+def load() -> ctypes.CDLL:
+    """Load libatx.so (once) and declare every prototype.  Raises if it is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = lib_path()
+    if not os.path.exists(path):
+        raise RuntimeError(
+            f"{path} not found: the HIP extension is not built. Run `python -c \"import __graft_entry__ as g; "
+            "g.build()\"` (hipcc --offload-arch=gfx950) — this package has no CPU fallback."
+        )
+    handle = ctypes.CDLL(path)
+    for name, (restype, argtypes) in SIGNATURES.items():
+        fn = getattr(handle, name)  # AttributeError if the symbol is not exported
+        fn.restype = restype
+        fn.argtypes = argtypes
+    _lib = handle
+    return handle
+
+
+def _raise(code: int, fn: str) -> None:
+    handle = load()
+    msg = handle.atx_last_error().decode() or handle.atx_strerror(code).decode()
+    if code == EINVAL:
+        raise ValueError(msg)
+    if code == ESHAPE:
+        raise AssertionError(msg)
+    if code == ENOTIMPL:
+        raise NotImplementedError(msg)
+    raise AtxError(f"{fn}: {msg} (code {code})")
+
+
+def _call(fn: str, *args: Any) -> None:
+    code = getattr(load(), fn)(*args)
+    if code != OK:
+        _raise(code, fn)
+
+
+def _ptr(t: torch.Tensor | None) -> int | None:
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise RuntimeError(f"libatx works on HBM-resident tensors only, got a {t.device} tensor (no CPU fallback)")
+    return t.data_ptr()
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def dtype_code(dtype: torch.dtype) -> int:
+    if dtype == torch.float32:
+        return F32
+    if dtype == torch.float64:
+        return F64
+    raise ValueError(f"libatx supports float32 / float64 stacks, got {dtype}")
+
+
+def version() -> int:
+    return load().atx_version()
+
+
+def device_count() -> int:
+    return load().atx_device_count()
+
+
+def set_tuning(tile: int) -> None:
+    _call("atx_set_tuning", int(tile))
+
+
+# --------------------------------------------------------------------------------
+# tensor-level wrappers (these are what the filters call)
+# --------------------------------------------------------------------------------
+def regrid_ell(src, out, idx, w, *, n_src, n_tgt, k, n_lev, src_pitch, out_pitch, layout, prog=None, n_stage=0,
+               tgt_mask=None) -> None:
+    """out[t, l] = sum_j w[t, j] * src[idx[t, j], l]; ``w is None`` -> pure k = 1 gather."""
+    assert src.dtype == out.dtype, (src.dtype, out.dtype)
+    assert idx.dtype == torch.int32
+    if w is not None:
+        assert w.dtype == src.dtype, (w.dtype, src.dtype)
+    _call(
+        "atx_regrid_ell", _ptr(src), _ptr(out), _ptr(idx), _ptr(w), n_src, n_tgt, k, n_lev, src_pitch, out_pitch,
+        dtype_code(src.dtype), layout, _ptr(prog), n_stage, _ptr(tgt_mask), _stream(),
+    )
+
+
+def regrid_csr(src, out, indptr, indices, data, *, n_src, n_tgt, nnz, n_lev, src_pitch, out_pitch, layout, prog=None,
+               n_stage=0, tgt_mask=None) -> None:
+    """out[t, l] = sum over the CSR row t of data * src[indices, l] (scipy csr_matvec order)."""
+    assert src.dtype == out.dtype == data.dtype, (src.dtype, out.dtype, data.dtype)
+    assert indptr.dtype == torch.int32 and indices.dtype == torch.int32
+    _call(
+        "atx_regrid_csr", _ptr(src), _ptr(out), _ptr(indptr), _ptr(indices), _ptr(data), n_src, n_tgt, nnz, n_lev,
+        src_pitch, out_pitch, dtype_code(src.dtype), layout, _ptr(prog), n_stage, _ptr(tgt_mask), _stream(),
+    )
+
+
+def check_indices(idx, n_src: int) -> int:
+    """Number of entries of ``idx`` outside [0, n_src) (synchronises)."""
+    n_bad = torch.zeros(1, dtype=torch.int64, device=idx.device)
+    _call("atx_check_indices", _ptr(idx), idx.numel(), n_src, _ptr(n_bad), _stream())
+    return int(n_bad.item())
+
+
+def level_program(stages: list[list[tuple[int, int, float, float]]], device) -> torch.Tensor:
+    """Device copy of a per-level program: ``stages[s][l] = (op, use_mask, p0, p1)``."""
+    n_stage = len(stages)
+    n_lev = len(stages[0])
+    host = np.zeros(n_stage * n_lev, dtype=LEVEL_OP_DTYPE)
+    for s, stage in enumerate(stages):
+        assert len(stage) == n_lev
+        for l, (op, use_mask, p0, p1) in enumerate(stage):
+            host[s * n_lev + l] = (op, use_mask, p0, p1)
+    raw = torch.from_numpy(host.view(np.uint8).copy())
+    return raw.to(device)
+
+
+def pointwise_stack(x, y, *, n_pts, n_lev, x_pitch, y_pitch, layout, prog, n_stage, point_mask=None) -> None:
+    assert x.dtype == y.dtype
+    _call(
+        "atx_pointwise_stack", _ptr(x), _ptr(y), n_pts, n_lev, x_pitch, y_pitch, dtype_code(x.dtype), layout,
+        _ptr(prog), n_stage, _ptr(point_mask), _stream(),
+    )
+
+
+def mask_build(m, mask, *, n, stride=1, cmp, threshold=0.0) -> None:
+    assert mask.dtype == torch.uint8
+    _call("atx_mask_build", _ptr(m), stride, _ptr(mask), n, cmp, float(threshold), dtype_code(m.dtype), _stream())
+
+
+def mask_count(mask, n: int | None = None) -> int:
+    n = mask.numel() if n is None else n
+    count = torch.zeros(1, dtype=torch.int64, device=mask.device)
+    _call("atx_mask_count", _ptr(mask), n, _ptr(count), _stream())
+    return int(count.item())
+
+
+def mask_to_index(mask, n: int | None = None) -> torch.Tensor:
+    """Ascending int32 positions of the set mask bytes (stable compaction; synchronises)."""
+    n = mask.numel() if n is None else n
+    ws_bytes = load().atx_mask_to_index_workspace(n)
+    workspace = torch.empty(max(ws_bytes, 16), dtype=torch.uint8, device=mask.device)
+    index = torch.empty(max(n, 1), dtype=torch.int32, device=mask.device)
+    count = torch.zeros(1, dtype=torch.int64, device=mask.device)
+    _call("atx_mask_to_index", _ptr(mask), n, _ptr(index), _ptr(count), _ptr(workspace), workspace.numel(), _stream())
+    return index[: int(count.item())]
+
+
+def reduce(x, red: int, n: int | None = None) -> float:
+    n = x.numel() if n is None else n
+    result = torch.zeros(1, dtype=torch.float64, device=x.device)
+    _call("atx_reduce", _ptr(x), n, red, _ptr(result), dtype_code(x.dtype), _stream())
+    return float(result.item())
+
+
+def relayout(src, dst, *, n_pts, n_lev, src_pitch, dst_pitch, src_layout, dst_layout) -> None:
+    assert src.dtype == dst.dtype
+    _call(
+        "atx_relayout", _ptr(src), _ptr(dst), n_pts, n_lev, src_pitch, dst_pitch, src_layout, dst_layout,
+        dtype_code(src.dtype), _stream(),
+    )

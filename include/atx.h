@@ -1,0 +1,215 @@
+/*
+ * atx.h — C ABI of libatx, the MI355X (gfx950) field-transform kernels.
+ *
+ * This is the drop-in boundary for the filter hot path of ecmwf/anemoi-transform
+ * 0.4.2.  The reference is pure Python and has NO native interface on this
+ * path: its filters call numpy / scipy in-process.  Every entry point below
+ * therefore replaces a numpy/scipy *statement* of the reference, cited as
+ * `R:` (paths relative to /root/reference/src/anemoi/transform/).  The
+ * reference-side binding a maintainer would add (a ctypes stub) is shown in
+ * INTEGRATION.md.
+ *
+ * Conventions
+ *  - Plain C types only.  Every pointer named in a signature is a DEVICE
+ *    pointer (HBM) unless the comment says "host".  The caller owns every
+ *    buffer; the library allocates nothing and keeps no state besides a
+ *    thread-local error string.
+ *  - `stream` is a hipStream_t passed as void* (NULL = the null stream).
+ *    Calls enqueue work and return without synchronising.
+ *  - Return value: ATX_OK (0) or a negative ATX_E* code; atx_last_error()
+ *    gives the message for the calling thread.  Nothing throws across the ABI.
+ *  - A *stack* is a batch of `n_lev` fields on one grid of `n_pts` points.
+ *    Two HBM layouts (atx_layout):
+ *      ATX_COLUMNS  element (point p, level l) at  base[p * pitch + l]
+ *                   — all levels of one grid point are contiguous (a model
+ *                   column).  The engine's native layout: a neighbour read is
+ *                   one contiguous n_lev*B-byte run.
+ *      ATX_FIELDS   element (p, l) at base[l * pitch + p] — one field after
+ *                   the other, the reference's unit (`field.to_numpy()`).
+ *    `pitch` is in ELEMENTS (>= n_lev for ATX_COLUMNS, >= n_pts for ATX_FIELDS).
+ *  - dtype: ATX_F32 or ATX_F64; weights / scalars use the data dtype
+ *    (double parameters are rounded to float for ATX_F32, as numpy does for a
+ *    python-float operand).
+ *  - Floating point is evaluated WITHOUT contraction (no FMA): x*a+b is two
+ *    roundings, a CSR row is summed sequentially from 0 in index order, so the
+ *    f64 results are bit-identical to numpy / scipy.
+ */
+#ifndef ATX_H
+#define ATX_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ATX_VERSION 100 /* 0.1.0 */
+
+/* ---- status codes --------------------------------------------------------- */
+enum {
+    ATX_OK = 0,
+    ATX_EINVAL = -1,   /* bad argument (null pointer, negative size, bad enum) -> ValueError */
+    ATX_ESHAPE = -2,   /* inconsistent shapes / pitches -> AssertionError (R: filters/fields/regrid.py:377-378) */
+    ATX_ENOTIMPL = -3, /* unsupported combination -> NotImplementedError (R: regrid.py:332-335) */
+    ATX_EHIP = -4,     /* HIP runtime error at launch */
+    ATX_EALIGN = -5,   /* pointer / pitch alignment not met for the requested layout */
+    ATX_EWORKSPACE = -6 /* workspace too small */
+};
+
+typedef enum { ATX_F32 = 0, ATX_F64 = 1 } atx_dtype;
+typedef enum { ATX_COLUMNS = 0, ATX_FIELDS = 1 } atx_layout;
+
+/* comparison operators of apply_mask (R: filters/fields/apply_mask.py:23-36:
+ * the 12 spellings map onto these 6) plus the NaN test of remove_nans
+ * (R: filters/fields/remove_nans.py:101  `~np.isnan(data)`). */
+typedef enum {
+    ATX_CMP_GT = 0,
+    ATX_CMP_LT = 1,
+    ATX_CMP_EQ = 2,
+    ATX_CMP_NE = 3,
+    ATX_CMP_GE = 4,
+    ATX_CMP_LE = 5,
+    ATX_CMP_NOTNAN = 6, /* threshold ignored */
+    ATX_CMP_ISNAN = 7   /* threshold ignored */
+} atx_cmp;
+
+/* per-point operators (one per reference statement). p0/p1 are the scalars. */
+typedef enum {
+    ATX_OP_COPY = 0,       /* y = x (bit copy)                                               */
+    ATX_OP_AFFINE = 1,     /* y = x*p0 + p1        R: filters/fields/rescale.py:25           */
+    ATX_OP_AFFINE_INV = 2, /* y = (x - p1) / p0    R: rescale.py:28                          */
+    ATX_OP_MUL = 3,        /* y = x * p0           R: filters/fields/orog_to_z.py:59         */
+    ATX_OP_DIV = 4,        /* y = x / p0           R: orog_to_z.py:77 (a true division)      */
+    ATX_OP_CLIP = 5,       /* y = np.clip(x,p0,p1) R: filters/fields/clipper.py:69; a NaN
+                              bound means "no bound on that side"; NaN x stays NaN          */
+    ATX_OP_IMPUTE_NAN = 6, /* y = isnan(x)?p0:x    R: filters/fields/impute_nans.py:53-54    */
+    ATX_OP_EXP = 7,        /* y = exp(x)           R: filters/fields/lnsp_to_sp.py:47        */
+    ATX_OP_LOG = 8,        /* y = log(x)           R: lnsp_to_sp.py:65                       */
+    ATX_OP_SET_NAN = 9,    /* y = NaN (canonical quiet NaN)                                  */
+    ATX_OP_COUNT_ = 10
+} atx_op;
+
+/* One step of a per-level program: level l of a stack is transformed by
+ * prog[s * n_lev + l] for s = 0 .. n_stage-1 in turn.  ATX_OP_COPY leaves the
+ * level untouched (bit-exact pass-through of unselected fields,
+ * R: filter.py:193-194).  `use_mask` != 0 additionally writes NaN where the
+ * point mask is set, AFTER the arithmetic of that stage
+ * (R: apply_mask.py:185 `values[self.mask] = np.nan`). */
+typedef struct {
+    int32_t op;       /* atx_op */
+    int32_t use_mask; /* 0/1 */
+    double p0;
+    double p1;
+} atx_level_op;
+
+/* ---- library ------------------------------------------------------------- */
+int atx_version(void);
+const char* atx_last_error(void);          /* host string, valid until the next failing call of this thread */
+const char* atx_strerror(int code);        /* host string, static */
+/* Number of HIP devices visible, or a negative ATX_EHIP. */
+int atx_device_count(void);
+/* Tuning hook for benchmarks: targets per workgroup of the ATX_COLUMNS regrid
+ * kernels (0 = built-in choice).  Process-wide; results never depend on it. */
+int atx_set_tuning(int tile);
+
+/* ---- regrid: precomputed index(+weight) gather ---------------------------- */
+
+/*
+ * Fixed-k ("ELL") interpolation:  out[t, l] = sum_{j<k} w[t*k+j] * src[idx[t*k+j], l]
+ * accumulated from 0 in j order.
+ *   w == NULL : pure gather, k must be 1:  out[t, l] = src[idx[t], l]  (bit copy)
+ *     R: regrid.py:380  `data = data[..., self.nearest_grid_points]`
+ *     R: regrid.py:420  `data = data[..., self.mask]` (integer / compressed boolean mask)
+ *     R: filters/fields/remove_nans.py:113 `data[self._mask]` (via atx_mask_to_index)
+ *   w != NULL : R: regrid.py:310 `data = self.matrix @ data` for a CSR matrix whose
+ *     rows all hold k entries (k-NN weights, bilinear).
+ * idx: int32 [n_tgt*k], every value in [0, n_src) (check with atx_check_indices).
+ * w  : dtype  [n_tgt*k].
+ * prog (optional, device, n_stage*n_lev entries): per-level epilogue applied to
+ *   the interpolated value before it is stored (the fused regrid -> per-point
+ *   chain, R: workflows/pipeline.py:46-48 without materialising intermediates);
+ *   tgt_mask (optional, uint8 [n_tgt]) is the point mask used by `use_mask`.
+ * Requirements: ATX_COLUMNS with 16-byte aligned bases and pitches that are
+ *   multiples of 16 bytes take the vector path; anything else a scalar path.
+ */
+int atx_regrid_ell(const void* src, void* out, const int32_t* idx, const void* w,
+                   int64_t n_src, int64_t n_tgt, int32_t k, int64_t n_lev,
+                   int64_t src_pitch, int64_t out_pitch, int dtype, int layout,
+                   const atx_level_op* prog, int32_t n_stage, const uint8_t* tgt_mask,
+                   void* stream);
+
+/*
+ * General CSR interpolation: out[t, l] = sum_{jj in [indptr[t], indptr[t+1])} data[jj] * src[indices[jj], l]
+ * accumulated from 0 in jj order — scipy's csr_matvec.
+ *   R: regrid.py:281-285 (npz keys matrix_data f64 / matrix_indices int32 / matrix_indptr int32)
+ *   R: regrid.py:310
+ * indptr int32 [n_tgt+1] (device), indices int32 [nnz], data dtype [nnz].
+ */
+int atx_regrid_csr(const void* src, void* out, const int32_t* indptr, const int32_t* indices,
+                   const void* data, int64_t n_src, int64_t n_tgt, int64_t nnz, int64_t n_lev,
+                   int64_t src_pitch, int64_t out_pitch, int dtype, int layout,
+                   const atx_level_op* prog, int32_t n_stage, const uint8_t* tgt_mask,
+                   void* stream);
+
+/* Counts entries of idx[0..n) outside [0, n_src) into *n_bad (device int64,
+ * zeroed by the call).  cKDTree returns n_src for "no neighbour within
+ * distance_upper_bound" (R: spatial.py:630-632) — reject before gathering. */
+int atx_check_indices(const int32_t* idx, int64_t n, int64_t n_src, int64_t* n_bad, void* stream);
+
+/* ---- per-point transforms -------------------------------------------------- */
+
+/*
+ * y[p, l] = prog_{n_stage-1}( ... prog_0(x[p, l]) )  for every level l of a stack.
+ * x == y (in place) is allowed when the pitches agree.  point_mask: uint8
+ * [n_pts] or NULL (required if any stage has use_mask).
+ *   R: filter.py:188-196 (SingleFieldFilter map over fields), rescale.py:25,28,
+ *      orog_to_z.py:59,77, clipper.py:69, impute_nans.py:53-54, lnsp_to_sp.py:47,65,
+ *      apply_mask.py:183-185, glacier_mask.py:33
+ */
+int atx_pointwise_stack(const void* x, void* y, int64_t n_pts, int64_t n_lev,
+                        int64_t x_pitch, int64_t y_pitch, int dtype, int layout,
+                        const atx_level_op* prog, int32_t n_stage, const uint8_t* point_mask,
+                        void* stream);
+
+/* ---- masks ------------------------------------------------------------------ */
+
+/* mask[i] = (m[i*m_stride] CMP threshold) ? 1 : 0   for i < n.
+ *   R: apply_mask.py:160-163  `OPERATORS[op](mask_values, threshold)` / `mask_values == mask_value`
+ *   R: remove_nans.py:101     `~np.isnan(data)`  (ATX_CMP_NOTNAN)
+ * m_stride in elements (1 for a flat field, the pitch for a level of an ATX_COLUMNS stack). */
+int atx_mask_build(const void* m, int64_t m_stride, uint8_t* mask, int64_t n, int cmp, double threshold,
+                   int dtype, void* stream);
+
+/* *count (device int64) = number of non-zero mask bytes.  R: numpy boolean indexing output size. */
+int atx_mask_count(const uint8_t* mask, int64_t n, int64_t* count, void* stream);
+
+/* Stable compaction: index[0..count) = ascending positions i with mask[i] != 0;
+ * *count (device int64) receives the total.  The index list turns
+ * `data[bool_mask]` into atx_regrid_ell(k=1, w=NULL).
+ *   R: remove_nans.py:110-116, regrid.py:420 (boolean mask)
+ * workspace: device scratch of at least atx_mask_to_index_workspace(n) bytes. */
+size_t atx_mask_to_index_workspace(int64_t n);
+int atx_mask_to_index(const uint8_t* mask, int64_t n, int32_t* index, int64_t* count,
+                      void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---- reductions (range / validity checks) ---------------------------------- */
+typedef enum { ATX_RED_MIN = 0, ATX_RED_MAX = 1, ATX_RED_NANCOUNT = 2 } atx_red;
+/* result: device double[1]; min/max ignore nothing (NaN propagates like np.min);
+ * NANCOUNT returns the count as a double.
+ *   R: filters/fields/cos_sin_from_rad.py:73-76 `data.min()/max()`;
+ *      tests/field_filters/test_apply_mask.py:106 `np.sum(np.isnan(result))` */
+int atx_reduce(const void* x, int64_t n, int red, double* result, int dtype, void* stream);
+
+/* ---- layout --------------------------------------------------------------- */
+/* dst[p, l] = src[p, l] between layouts / pitches (LDS-tiled transpose when the
+ * layouts differ, strided copy when they agree).  No reference counterpart:
+ * `field.to_numpy()` (R: fields.py:178-202) is the field-major view of a stack. */
+int atx_relayout(const void* src, void* dst, int64_t n_pts, int64_t n_lev,
+                 int64_t src_pitch, int64_t dst_pitch, int src_layout, int dst_layout,
+                 int dtype, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ATX_H */

@@ -1,0 +1,369 @@
+"""CPU ORACLE — TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+
+A numpy / scipy restatement of the filter hot path of ecmwf/anemoi-transform
+0.4.2 (regrid gather / sparse interpolation, per-point transforms, mask
+filters).  Only ``tests/``, ``__graft_entry__.smoke()`` and the ``cpu_baseline``
+leg of ``bench.py`` may import this module, and only as the checker.  The
+product package never imports it: its compute path is libatx (HIP) and fails
+loudly without it.
+
+Every function cites the reference statement it restates (``R:`` = paths under
+``/root/reference/src/anemoi/transform/``).  numpy and scipy are the libraries
+that execute those statements in the reference, so the restatement runs the
+identical native routines (``take``, ufuncs, ``csr_matvec``, ``cKDTree``).
+
+Pinning: the reference package cannot be imported in
+the build container (``ModuleNotFoundError: earthkit`` / ``anemoi.utils`` —
+ordinary missing dependencies, no network to install them), so the oracle is
+pinned by the reference's own test vectors, transcribed as data into
+``tests/golden/reference_vectors.json`` and checked in
+``tests/test_oracle_golden.py``.  Regrid *numerics* are pinned by nothing in the
+reference (``tests/field_filters/test_regrid.py`` only iterates the pipeline);
+for K1-K3 the oracle is the reference's statement itself on synthetic inputs.
+
+Fields are plain dicts here: ``{"param": str, "values": ndarray, "latitudes":
+1-D ndarray (one per grid point), "longitudes": ..., **metadata}``.
+"""
+
+from __future__ import annotations
+
+from typing import Any
+
+import numpy as np
+
+# R: constants.py:13  g from earthkit.meteo; value pinned by
+# R: filters/tabular/geopotential_to_height.py:51
+G = 9.80665
+
+# R: filters/fields/apply_mask.py:23-36
+OPERATORS = {
+    ">": np.greater,
+    "<": np.less,
+    "==": np.equal,
+    "!=": np.not_equal,
+    ">=": np.greater_equal,
+    "<=": np.less_equal,
+    "gt": np.greater,
+    "lt": np.less,
+    "eq": np.equal,
+    "ne": np.not_equal,
+    "ge": np.greater_equal,
+    "le": np.less_equal,
+}
+
+
+# --------------------------------------------------------------------------------
+# array-level statements
+# --------------------------------------------------------------------------------
+def gather_nn(data: np.ndarray, nearest_grid_points: np.ndarray) -> np.ndarray:
+    """R: filters/fields/regrid.py:380 ``data = data[..., self.nearest_grid_points]``."""
+    return data[..., nearest_grid_points]
+
+
+def csr_apply(matrix_data, matrix_indices, matrix_indptr, matrix_shape, data: np.ndarray) -> np.ndarray:
+    """R: regrid.py:283-285,310 ``csr_array((data, indices, indptr), shape) @ data``."""
+    from scipy.sparse import csr_array
+
+    matrix = csr_array((matrix_data, matrix_indices, matrix_indptr), shape=tuple(int(s) for s in matrix_shape))
+    return matrix @ data
+
+
+def masked_subset(data: np.ndarray, mask: np.ndarray) -> np.ndarray:
+    """R: regrid.py:420 ``data = data[..., self.mask]`` (bool or integer mask)."""
+    return data[..., mask]
+
+
+def compute_mask(mask_values: np.ndarray, *, mask_value=None, threshold=None, threshold_operator=">") -> np.ndarray:
+    """R: apply_mask.py:160-163."""
+    if threshold is not None:
+        return OPERATORS[threshold_operator](mask_values, threshold)
+    return mask_values == mask_value
+
+
+def apply_mask_values(values: np.ndarray, mask: np.ndarray) -> np.ndarray:
+    """R: apply_mask.py:184-185 ``values[self.mask] = np.nan`` on the flattened copy."""
+    values = np.array(values, dtype=values.dtype, copy=True).reshape(-1)
+    values[mask] = np.nan
+    return values
+
+
+def not_nan_mask(data: np.ndarray) -> np.ndarray:
+    """R: filters/fields/remove_nans.py:101 ``~np.isnan(data)``."""
+    return ~np.isnan(data)
+
+
+def rescale_forward(x, scale, offset):
+    """R: filters/fields/rescale.py:25 ``x * self.scale + self.offset``."""
+    return x * scale + offset
+
+
+def rescale_backward(x, scale, offset):
+    """R: rescale.py:28 ``(x - self.offset) / self.scale``."""
+    return (x - offset) / scale
+
+
+def orog_to_z(x):
+    """R: filters/fields/orog_to_z.py:59 ``orography.to_numpy() * g``."""
+    return x * G
+
+
+def z_to_orog(x):
+    """R: orog_to_z.py:77 ``geopotential.to_numpy() / g``."""
+    return x / G
+
+
+def clip(x, minimum, maximum):
+    """R: filters/fields/clipper.py:69 ``np.clip(data, self.minimum, self.maximum)``."""
+    return np.clip(x, minimum, maximum)
+
+
+def impute_nans(x, value):
+    """R: filters/fields/impute_nans.py:53-54."""
+    values = np.array(x, copy=True).reshape(-1)
+    values[np.isnan(values)] = value
+    return values
+
+
+def lnsp_to_sp(x):
+    """R: filters/fields/lnsp_to_sp.py:47 ``np.exp(...)``."""
+    return np.exp(x)
+
+
+def sp_to_lnsp(x):
+    """R: lnsp_to_sp.py:65 ``np.log(...)``."""
+    return np.log(x)
+
+
+# --------------------------------------------------------------------------------
+# index / geometry precompute
+# --------------------------------------------------------------------------------
+def latlon_to_xyz(lat, lon, radius: float = 1.0):
+    """R: spatial.py:132-167 (unit sphere, h = 0)."""
+    phi = np.deg2rad(lat)
+    lda = np.deg2rad(lon)
+    cos_phi = np.cos(phi)
+    return cos_phi * np.cos(lda) * radius, cos_phi * np.sin(lda) * radius, np.sin(phi) * radius
+
+
+def nearest_grid_points(
+    source_latitudes,
+    source_longitudes,
+    target_latitudes,
+    target_longitudes,
+    max_distance=None,
+    num_neighbours_to_return: int = 1,
+    return_distances: bool = False,
+):
+    """R: spatial.py:587-635 — cKDTree on unit-sphere xyz, chord distance; returns
+    indices (int64) or ``(indices, distances)`` in THAT order (spatial.py:633-635)."""
+    from scipy.spatial import cKDTree
+
+    source_points = np.array(latlon_to_xyz(source_latitudes, source_longitudes)).transpose()
+    target_points = np.array(latlon_to_xyz(target_latitudes, target_longitudes)).transpose()
+    if max_distance is None:
+        distances, indices = cKDTree(source_points).query(target_points, k=num_neighbours_to_return)
+    else:
+        distances, indices = cKDTree(source_points).query(
+            target_points, k=num_neighbours_to_return, distance_upper_bound=max_distance
+        )
+    if return_distances:
+        return indices, distances
+    return indices
+
+
+# --------------------------------------------------------------------------------
+# filter-level restatements on dict fields
+# --------------------------------------------------------------------------------
+def _flat(field: dict) -> np.ndarray:
+    # R: fields.py:178-202 to_numpy(flatten=True) returns a flattened copy
+    return np.asarray(field["values"]).flatten()
+
+
+def _selected(field: dict, param) -> bool:
+    # R: fields.py:767-797 FieldSelection(param=...).match
+    if param is None:
+        return True
+    params = (param,) if isinstance(param, str) else tuple(param)
+    if len(params) == 0:
+        return True
+    return field.get("param") in params
+
+
+def filter_apply_mask(
+    fields: list[dict],
+    *,
+    mask_values: np.ndarray | None = None,
+    mask_param: str | None = None,
+    mask_value=None,
+    threshold=None,
+    threshold_operator: str = ">",
+    rename: str | None = None,
+    param=None,
+    return_mask: bool = False,
+) -> list[dict]:
+    """R: apply_mask.py:114-245 (``mask_values`` stands for the flattened first field of ``path``)."""
+    if (mask_values is None) == (mask_param is None):
+        raise ValueError("Exactly one of `path` or `mask_param` must be provided.")
+    if (mask_value is None) == (threshold is None):
+        raise ValueError("Exactly one of `mask_value` or `threshold` must be provided.")
+    if threshold is not None and threshold_operator not in OPERATORS:
+        raise ValueError(f"Invalid threshold operator: {threshold_operator}.")
+    kw = dict(mask_value=mask_value, threshold=threshold, threshold_operator=threshold_operator)
+
+    if mask_param is None:
+        mask = compute_mask(np.asarray(mask_values).flatten(), **kw)
+        remaining = list(fields)
+    else:
+        mask_field = None
+        remaining = []
+        for f in fields:  # R: apply_mask.py:194-218
+            if f.get("param") == mask_param:
+                if mask_field is None:
+                    mask_field = f
+                if not return_mask:
+                    continue
+            remaining.append(f)
+        if mask_field is None:
+            raise ValueError(f"Mask parameter '{mask_param}' not found in input data.")
+        mask = compute_mask(_flat(mask_field), **kw)
+
+    out = []
+    for f in remaining:
+        if _selected(f, param):
+            g = dict(f)
+            g["values"] = apply_mask_values(_flat(f), mask)
+            if rename is not None:
+                g["param"] = f"{f['param']}_{rename}"
+            out.append(g)
+        else:
+            out.append(f)
+    return out
+
+
+def filter_remove_nans(fields: list[dict], *, param: str | None = None) -> list[dict]:
+    """R: remove_nans.py:75-119 — mask from the first field (or first with ``param``)."""
+    if param is None:
+        first = fields[0]
+    else:
+        for first in fields:
+            if first.get("param") == param:
+                break
+        else:
+            raise ValueError(f"{param=} not found")
+    mask = not_nan_mask(_flat(first))
+    lat = np.asarray(first["latitudes"])[mask]
+    lon = np.asarray(first["longitudes"])[mask]
+    out = []
+    for f in fields:
+        g = dict(f)
+        g["values"] = _flat(f)[mask]
+        g["latitudes"], g["longitudes"] = lat, lon
+        out.append(g)
+    return out
+
+
+def _map_selected(fields, param, fn, **new_metadata):
+    # R: filter.py:188-196: unselected fields pass through by identity
+    out = []
+    for f in fields:
+        if _selected(f, param):
+            g = dict(f)
+            g["values"] = fn(np.asarray(f["values"]))
+            g.update({k: v for k, v in new_metadata.items()})
+            out.append(g)
+        else:
+            out.append(f)
+    return out
+
+
+def filter_rescale(fields, *, scale, offset, param, backward: bool = False):
+    """R: rescale.py:31-66."""
+    if backward:
+        return _map_selected(fields, param, lambda x: rescale_backward(x, scale, offset), param=param)
+    return _map_selected(fields, param, lambda x: rescale_forward(x, scale, offset), param=param)
+
+
+def filter_orog_to_z(fields, *, orography="orog", geopotential="z", backward: bool = False):
+    """R: orog_to_z.py:19-78."""
+    if backward:
+        return _map_selected(fields, geopotential, z_to_orog, param=orography)
+    return _map_selected(fields, orography, orog_to_z, param=geopotential)
+
+
+def filter_clip(fields, *, param, minimum=None, maximum=None):
+    """R: clipper.py:58-70."""
+    if minimum is None and maximum is None:
+        raise ValueError("At least one value for minimum or maximum must be specified.")
+    return _map_selected(fields, param, lambda x: clip(x, minimum, maximum), param=param)
+
+
+def filter_impute_nans(fields, *, param, value):
+    """R: impute_nans.py:47-55."""
+    return _map_selected(fields, param, lambda x: impute_nans(x, value))
+
+
+def filter_lnsp_to_sp(fields, *, log_of_surface_pressure="lnsp", surface_pressure="sp", backward: bool = False):
+    """R: lnsp_to_sp.py:19-66."""
+    if backward:
+        return _map_selected(fields, surface_pressure, sp_to_lnsp, param=log_of_surface_pressure)
+    return _map_selected(fields, log_of_surface_pressure, lnsp_to_sp, param=surface_pressure)
+
+
+def interpolator_name(*, method=None, matrix=None, mask=None) -> str:
+    """R: regrid.py:432-467 dispatch order: matrix > mask > method == 'nearest' > earthkit."""
+    if matrix is not None:
+        return "MIRMatrix"
+    if mask is not None:
+        return "MaskedRegrid"
+    if method == "nearest":
+        return "ScipyKDTreeNearestNeighbours"
+    return "EarthkitRegrid"
+
+
+def filter_regrid_nearest(fields, *, in_grid: dict | None, out_grid: dict) -> list[dict]:
+    """R: regrid.py:315-381 — k = 1 cKDTree gather; index computed once from the first field."""
+    idx = None
+    out = []
+    for f in fields:
+        if in_grid is None:
+            in_grid = dict(latitudes=np.asarray(f["latitudes"]), longitudes=np.asarray(f["longitudes"]))
+        if idx is None:
+            idx = nearest_grid_points(
+                in_grid["latitudes"], in_grid["longitudes"], out_grid["latitudes"], out_grid["longitudes"]
+            )
+        data = _flat(f)
+        assert data.shape == in_grid["latitudes"].shape, (data.shape, in_grid["latitudes"].shape)
+        assert data.shape == in_grid["longitudes"].shape, (data.shape, in_grid["longitudes"].shape)
+        g = dict(f)
+        g["values"] = gather_nn(data, idx)
+        g["latitudes"], g["longitudes"] = out_grid["latitudes"], out_grid["longitudes"]
+        out.append(g)
+    return out
+
+
+def filter_regrid_matrix(fields, *, matrix: dict[str, Any]) -> list[dict]:
+    """R: regrid.py:262-312 — ``matrix`` is the loaded npz dict (regrid.py:281)."""
+    out = []
+    for f in fields:
+        g = dict(f)
+        g["values"] = csr_apply(
+            matrix["matrix_data"], matrix["matrix_indices"], matrix["matrix_indptr"], matrix["matrix_shape"], _flat(f)
+        )
+        g["latitudes"], g["longitudes"] = matrix["out_latitudes"], matrix["out_longitudes"]
+        out.append(g)
+    return out
+
+
+def filter_regrid_mask(fields, *, mask: np.ndarray) -> list[dict]:
+    """R: regrid.py:384-429 — subset by an index / boolean mask; lat/lon from the first field."""
+    out_lat = out_lon = None
+    out = []
+    for f in fields:
+        g = dict(f)
+        g["values"] = masked_subset(_flat(f), mask)
+        if out_lat is None:
+            out_lat = np.asarray(f["latitudes"])[mask]
+            out_lon = np.asarray(f["longitudes"])[mask]
+        g["latitudes"], g["longitudes"] = out_lat, out_lon
+        out.append(g)
+    return out

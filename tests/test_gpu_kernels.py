@@ -1,0 +1,345 @@
+"""Parity of every libatx kernel against the CPU oracle, through the C ABI.
+
+Bit-exact for gathers, masks, compaction and f64 arithmetic (the library is built
+without FMA contraction, so f64 equals numpy / scipy bit for bit); f32
+interpolation within 1e-6 relative of the oracle fed the same f32 inputs
+(BASELINE.json north_star tolerance).
+"""
+
+from __future__ import annotations
+
+import numpy as np
+import pytest
+import torch
+
+from anemoi_transform_amd import native
+from anemoi_transform_amd.stack import COLUMNS, FIELDS, Stack
+from oracle import oracle
+
+pytestmark = pytest.mark.gpu
+
+DTYPES = [(torch.float64, np.float64), (torch.float32, np.float32)]
+LAYOUTS = [COLUMNS, FIELDS]
+RTOL_F32 = 1e-6  # north_star: "within 1e-6 relative for float interpolation"
+
+
+def make_fields(rng, n_lev, n_pts, np_dtype, nan_frac=0.0):
+    x = (280.0 + 30.0 * rng.standard_normal((n_lev, n_pts))).astype(np_dtype)
+    if nan_frac:
+        x[rng.random((n_lev, n_pts)) < nan_frac] = np.nan
+    return x
+
+
+def random_ell(rng, n_src, n_tgt, k, np_dtype):
+    idx = rng.integers(0, n_src, size=(n_tgt, k)).astype(np.int32)
+    w = rng.random((n_tgt, k))
+    w = (w / w.sum(axis=1, keepdims=True)).astype(np_dtype)
+    return idx, w
+
+
+def random_csr(rng, n_src, n_tgt, max_row, np_dtype, empty_rows=True):
+    lengths = rng.integers(0 if empty_rows else 1, max_row + 1, size=n_tgt)
+    indptr = np.concatenate([[0], np.cumsum(lengths)]).astype(np.int32)
+    nnz = int(indptr[-1])
+    indices = rng.integers(0, n_src, size=nnz).astype(np.int32)
+    data = rng.standard_normal(nnz).astype(np_dtype)
+    return indptr, indices, data
+
+
+def to_dev(a, dev):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+
+def assert_interp(got, want, np_dtype):
+    if np_dtype == np.float64:
+        assert np.array_equal(got, want, equal_nan=True)
+    else:
+        np.testing.assert_allclose(got, want, rtol=RTOL_F32, atol=1e-4)
+
+
+# ---------------------------------------------------------------------------------
+# regrid
+# ---------------------------------------------------------------------------------
+@pytest.mark.parametrize("tdtype,np_dtype", DTYPES)
+@pytest.mark.parametrize("layout", LAYOUTS)
+@pytest.mark.parametrize("n_lev", [1, 3, 137])
+def test_gather_nn_bit_exact(dev, tdtype, np_dtype, layout, n_lev):
+    """R: regrid.py:380 — a k=1 gather copies bits, NaN payloads included."""
+    rng = np.random.default_rng(1)
+    n_src, n_tgt = 5000, 3333
+    x = make_fields(rng, n_lev, n_src, np_dtype, nan_frac=0.05)
+    # a NaN with a payload must survive
+    x.view(np.uint32 if np_dtype == np.float32 else np.uint64)[0, 0] |= 0x7
+    idx = rng.integers(0, n_src, size=n_tgt).astype(np.int32)
+    src = Stack.from_fields(x, dev=dev, layout=layout)
+    out = src.new_like(n_pts=n_tgt)
+    native.regrid_ell(src.data, out.data, to_dev(idx, dev), None, n_src=n_src, n_tgt=n_tgt, k=1, n_lev=n_lev,
+                      src_pitch=src.pitch, out_pitch=out.pitch, layout=layout)
+    got = out.numpy()
+    want = oracle.gather_nn(x, idx)
+    itype = np.uint32 if np_dtype == np.float32 else np.uint64
+    assert np.array_equal(got.view(itype), want.view(itype))
+
+
+@pytest.mark.parametrize("tdtype,np_dtype", DTYPES)
+@pytest.mark.parametrize("layout", LAYOUTS)
+@pytest.mark.parametrize("k", [1, 2, 3, 4, 7])
+def test_regrid_ell_matches_csr_matvec(dev, tdtype, np_dtype, layout, k):
+    """R: regrid.py:310 — fixed-k rows against scipy's csr_matvec."""
+    rng = np.random.default_rng(2 + k)
+    n_src, n_tgt, n_lev = 4096, 2500, 19
+    x = make_fields(rng, n_lev, n_src, np_dtype)
+    idx, w = random_ell(rng, n_src, n_tgt, k, np_dtype)
+    src = Stack.from_fields(x, dev=dev, layout=layout)
+    out = src.new_like(n_pts=n_tgt)
+    native.regrid_ell(src.data, out.data, to_dev(idx, dev), to_dev(w, dev), n_src=n_src, n_tgt=n_tgt, k=k,
+                      n_lev=n_lev, src_pitch=src.pitch, out_pitch=out.pitch, layout=layout)
+    indptr = np.arange(n_tgt + 1) * k
+    want = np.stack([oracle.csr_apply(w.reshape(-1), idx.reshape(-1), indptr, (n_tgt, n_src), f) for f in x])
+    assert_interp(out.numpy(), want, np_dtype)
+
+
+@pytest.mark.parametrize("tdtype,np_dtype", DTYPES)
+@pytest.mark.parametrize("layout", LAYOUTS)
+def test_regrid_csr_ragged_rows(dev, tdtype, np_dtype, layout):
+    """General CSR: empty rows, long rows (beyond the LDS staging cap), duplicate columns."""
+    rng = np.random.default_rng(5)
+    n_src, n_tgt, n_lev = 3000, 1777, 11
+    x = make_fields(rng, n_lev, n_src, np_dtype)
+    indptr, indices, data = random_csr(rng, n_src, n_tgt, 9, np_dtype)
+    src = Stack.from_fields(x, dev=dev, layout=layout)
+    out = src.new_like(n_pts=n_tgt)
+    native.regrid_csr(src.data, out.data, to_dev(indptr, dev), to_dev(indices, dev), to_dev(data, dev), n_src=n_src,
+                      n_tgt=n_tgt, nnz=len(indices), n_lev=n_lev, src_pitch=src.pitch, out_pitch=out.pitch, layout=layout)
+    want = np.stack([oracle.csr_apply(data, indices, indptr, (n_tgt, n_src), f) for f in x])
+    got = out.numpy()
+    if np_dtype == np.float64:
+        assert np.array_equal(got, want)
+    else:
+        np.testing.assert_allclose(got, want, rtol=1e-5, atol=1e-2)  # sign-changing weights: atol scaled to |x|~300
+
+
+@pytest.mark.parametrize("layout", LAYOUTS)
+def test_regrid_csr_very_long_rows(dev, layout):
+    rng = np.random.default_rng(6)
+    n_src, n_tgt, n_lev = 2000, 64, 5
+    x = make_fields(rng, n_lev, n_src, np.float64)
+    lengths = rng.integers(200, 400, size=n_tgt)
+    indptr = np.concatenate([[0], np.cumsum(lengths)]).astype(np.int32)
+    indices = rng.integers(0, n_src, size=int(indptr[-1])).astype(np.int32)
+    data = rng.random(int(indptr[-1]))
+    src = Stack.from_fields(x, dev=dev, layout=layout)
+    out = src.new_like(n_pts=n_tgt)
+    native.regrid_csr(src.data, out.data, to_dev(indptr, dev), to_dev(indices, dev), to_dev(data, dev), n_src=n_src,
+                      n_tgt=n_tgt, nnz=len(indices), n_lev=n_lev, src_pitch=src.pitch, out_pitch=out.pitch, layout=layout)
+    want = np.stack([oracle.csr_apply(data, indices, indptr, (n_tgt, n_src), f) for f in x])
+    assert np.array_equal(out.numpy(), want)
+
+
+def test_regrid_unaligned_columns_take_scalar_path(dev):
+    """A columns stack whose pitch is not a 16-byte multiple still regrids correctly."""
+    rng = np.random.default_rng(7)
+    n_src, n_tgt, n_lev = 1000, 700, 5
+    x = make_fields(rng, n_lev, n_src, np.float32)
+    idx, w = random_ell(rng, n_src, n_tgt, 4, np.float32)
+    src_t = torch.zeros((n_src, 5), dtype=torch.float32, device=dev)
+    src_t.copy_(to_dev(x.T, dev))
+    out_t = torch.empty((n_tgt, 7), dtype=torch.float32, device=dev)
+    native.regrid_ell(src_t, out_t, to_dev(idx, dev), to_dev(w, dev), n_src=n_src, n_tgt=n_tgt, k=4, n_lev=n_lev,
+                      src_pitch=5, out_pitch=7, layout=COLUMNS)
+    indptr = np.arange(n_tgt + 1) * 4
+    want = np.stack([oracle.csr_apply(w.reshape(-1), idx.reshape(-1), indptr, (n_tgt, n_src), f) for f in x])
+    np.testing.assert_allclose(out_t[:, :n_lev].T.cpu().numpy(), want, rtol=RTOL_F32)
+
+
+def test_regrid_fused_epilogue(dev):
+    """regrid -> orog_to_z -> rescale fused in the gather epilogue equals the chained oracle."""
+    rng = np.random.default_rng(8)
+    n_src, n_tgt, n_lev = 2048, 1500, 6
+    x = make_fields(rng, n_lev, n_src, np.float64)
+    idx, w = random_ell(rng, n_src, n_tgt, 4, np.float64)
+    tmask = rng.random(n_tgt) < 0.2
+    stage0 = [(native.OP_MUL, 0, oracle.G, 0.0) if l == 1 else (native.OP_COPY, 0, 0, 0) for l in range(n_lev)]
+    stage1 = [(native.OP_AFFINE, 1 if l == 3 else 0, 1.0, -273.15) if l in (0, 3) else (native.OP_COPY, 0, 0, 0) for l in range(n_lev)]
+    for layout in LAYOUTS:
+        src = Stack.from_fields(x, dev=dev, layout=layout)
+        out = src.new_like(n_pts=n_tgt)
+        prog = native.level_program([stage0, stage1], dev)
+        native.regrid_ell(src.data, out.data, to_dev(idx, dev), to_dev(w, dev), n_src=n_src, n_tgt=n_tgt, k=4,
+                          n_lev=n_lev, src_pitch=src.pitch, out_pitch=out.pitch, layout=layout, prog=prog, n_stage=2,
+                          tgt_mask=to_dev(tmask.astype(np.uint8), dev))
+        indptr = np.arange(n_tgt + 1) * 4
+        want = np.stack([oracle.csr_apply(w.reshape(-1), idx.reshape(-1), indptr, (n_tgt, n_src), f) for f in x])
+        want[1] = oracle.orog_to_z(want[1])
+        want[0] = oracle.rescale_forward(want[0], 1.0, -273.15)
+        want[3] = oracle.rescale_forward(want[3], 1.0, -273.15)
+        want[3][tmask] = np.nan
+        assert np.array_equal(out.numpy(), want, equal_nan=True)
+
+
+def test_check_indices(dev):
+    idx = np.array([0, 5, 9, 10, -1, 3], dtype=np.int32)
+    assert native.check_indices(to_dev(idx, dev), 10) == 2
+    assert native.check_indices(to_dev(idx[:3], dev), 10) == 0
+
+
+def test_argument_errors_map_to_reference_exceptions(dev):
+    t = torch.zeros((4, 4), dtype=torch.float32, device=dev)
+    i = torch.zeros(4, dtype=torch.int32, device=dev)
+    with pytest.raises(AssertionError):  # pitch < n_lev: shape mismatch (R: regrid.py:377-378)
+        native.regrid_ell(t, t.clone(), i, None, n_src=4, n_tgt=4, k=1, n_lev=8, src_pitch=4, out_pitch=4, layout=COLUMNS)
+    with pytest.raises(ValueError):
+        native.regrid_ell(t, t.clone(), i, None, n_src=4, n_tgt=4, k=3, n_lev=4, src_pitch=4, out_pitch=4, layout=COLUMNS)
+    with pytest.raises(RuntimeError):  # CPU tensors are refused: no fallback
+        native.regrid_ell(t.cpu(), t.cpu(), i.cpu(), None, n_src=4, n_tgt=4, k=1, n_lev=4, src_pitch=4, out_pitch=4, layout=COLUMNS)
+
+
+# ---------------------------------------------------------------------------------
+# per-point programs
+# ---------------------------------------------------------------------------------
+def _run_prog(dev, x, layout, stages, mask=None, in_place=False):
+    n_lev, n_pts = x.shape
+    src = Stack.from_fields(x, dev=dev, layout=layout)
+    out = src if in_place else src.new_like()
+    prog = native.level_program(stages, dev)
+    native.pointwise_stack(src.data, out.data, n_pts=n_pts, n_lev=n_lev, x_pitch=src.pitch, y_pitch=out.pitch,
+                           layout=layout, prog=prog, n_stage=len(stages),
+                           point_mask=None if mask is None else to_dev(mask.astype(np.uint8), dev))
+    return out.numpy()
+
+
+@pytest.mark.parametrize("tdtype,np_dtype", DTYPES)
+@pytest.mark.parametrize("layout", LAYOUTS)
+@pytest.mark.parametrize("in_place", [False, True])
+def test_pointwise_ops_bit_exact(dev, tdtype, np_dtype, layout, in_place):
+    rng = np.random.default_rng(11)
+    n_lev, n_pts = 10, 4099
+    x = make_fields(rng, n_lev, n_pts, np_dtype, nan_frac=0.03)
+    x[4] = np.abs(x[4]) * 1e-2  # exp / log inputs
+    x[5] = np.abs(x[5]) + 1.0
+    x[0, :8] = [-0.0, 0.0, np.inf, -np.inf, np.nan, 1.0, -1.0, 273.15]
+    sc, off = np_dtype(1.8), np_dtype(-459.67)
+    stage = [
+        (native.OP_AFFINE, 0, 1.8, -459.67),
+        (native.OP_AFFINE_INV, 0, 1.8, -459.67),
+        (native.OP_MUL, 0, oracle.G, 0),
+        (native.OP_DIV, 0, oracle.G, 0),
+        (native.OP_EXP, 0, 0, 0),
+        (native.OP_LOG, 0, 0, 0),
+        (native.OP_CLIP, 0, 250.0, 300.0),
+        (native.OP_CLIP, 0, float("nan"), 280.0),
+        (native.OP_IMPUTE_NAN, 0, -1.0, 0),
+        (native.OP_COPY, 0, 0, 0),
+    ]
+    got = _run_prog(dev, x, layout, [stage], in_place=in_place)
+    g = np_dtype(oracle.G)
+    want = [
+        oracle.rescale_forward(x[0], sc, off),
+        oracle.rescale_backward(x[1], sc, off),
+        x[2] * g,
+        x[3] / g,
+        oracle.lnsp_to_sp(x[4]),
+        oracle.sp_to_lnsp(x[5]),
+        oracle.clip(x[6], np_dtype(250.0), np_dtype(300.0)),
+        oracle.clip(x[7], None, np_dtype(280.0)),
+        oracle.impute_nans(x[8], np_dtype(-1.0)),
+        x[9],
+    ]
+    for l in (0, 1, 2, 3, 6, 7, 8, 9):  # one-rounding arithmetic: bit-exact
+        assert want[l].dtype == np_dtype, (l, want[l].dtype)
+        assert np.array_equal(got[l], want[l], equal_nan=True), f"level {l}"
+        # signed zeros must match too (x*g keeps -0.0, x*1+0 does not)
+        finite = ~np.isnan(want[l])
+        assert np.array_equal(np.signbit(got[l][finite]), np.signbit(want[l][finite])), f"level {l} sign"
+    for l in (4, 5):  # libm vs ocml: a few ulp
+        np.testing.assert_allclose(got[l], want[l], rtol=1e-6 if np_dtype == np.float32 else 1e-14, equal_nan=True)
+
+
+@pytest.mark.parametrize("layout", LAYOUTS)
+def test_pointwise_mask_and_two_stages(dev, layout):
+    """R: apply_mask.py:185 after R: rescale.py:25 in one pass; unselected levels untouched."""
+    rng = np.random.default_rng(12)
+    n_lev, n_pts = 5, 1237
+    x = make_fields(rng, n_lev, n_pts, np.float64, nan_frac=0.01)
+    mask = rng.random(n_pts) < 0.3
+    s0 = [(native.OP_AFFINE, 0, 2.0, 1.0) if l in (1, 2) else (native.OP_COPY, 0, 0, 0) for l in range(n_lev)]
+    s1 = [(native.OP_COPY, 1, 0, 0) if l in (2, 4) else (native.OP_COPY, 0, 0, 0) for l in range(n_lev)]
+    got = _run_prog(dev, x, layout, [s0, s1], mask=mask)
+    want = x.copy()
+    want[1] = x[1] * 2.0 + 1.0
+    want[2] = oracle.apply_mask_values(x[2] * 2.0 + 1.0, mask)
+    want[4] = oracle.apply_mask_values(x[4], mask)
+    assert np.array_equal(got.view(np.uint64), want.view(np.uint64))
+
+
+# ---------------------------------------------------------------------------------
+# masks, compaction, reductions
+# ---------------------------------------------------------------------------------
+@pytest.mark.parametrize("tdtype,np_dtype", DTYPES)
+@pytest.mark.parametrize("op,cmp", [(">", native.CMP_GT), ("<", native.CMP_LT), ("==", native.CMP_EQ),
+                                    ("!=", native.CMP_NE), (">=", native.CMP_GE), ("<=", native.CMP_LE)])
+def test_mask_build_operators(dev, tdtype, np_dtype, op, cmp):
+    """R: apply_mask.py:23-36,160-163 incl. NaN semantics (== false, != true)."""
+    rng = np.random.default_rng(13)
+    n = 10007
+    m = rng.choice(np.array([0.0, 0.25, 0.5, 0.75, 1.0, np.nan]), size=n).astype(np_dtype)
+    mask = torch.empty(n + 3, dtype=torch.uint8, device=dev)
+    native.mask_build(to_dev(m, dev), mask, n=n, cmp=cmp, threshold=0.5)
+    want = oracle.compute_mask(m, threshold=0.5, threshold_operator=op)
+    assert np.array_equal(mask[:n].cpu().numpy().astype(bool), want)
+
+
+def test_mask_build_from_stack_level(dev):
+    """A mask field living inside a columns stack is read with stride = pitch."""
+    rng = np.random.default_rng(14)
+    x = make_fields(rng, 4, 999, np.float64, nan_frac=0.2)
+    st = Stack.from_fields(x, dev=dev)
+    mask = torch.empty(1000, dtype=torch.uint8, device=dev)
+    native.mask_build(st.level_view(2), mask, n=999, stride=st.pitch, cmp=native.CMP_NOTNAN)
+    assert np.array_equal(mask[:999].cpu().numpy().astype(bool), oracle.not_nan_mask(x[2]))
+    assert native.mask_count(mask, 999) == int(oracle.not_nan_mask(x[2]).sum())
+
+
+@pytest.mark.parametrize("n", [0, 1, 15, 4096, 4097, 1_000_003])
+@pytest.mark.parametrize("density", [0.0, 0.37, 1.0])
+def test_mask_to_index_is_stable_compaction(dev, n, density):
+    """R: remove_nans.py:113 / regrid.py:420 — boolean indexing == gather by ascending index list."""
+    rng = np.random.default_rng(15)
+    m = (rng.random(n) < density) if 0 < density < 1 else np.full(n, bool(density))
+    mask = to_dev(m.astype(np.uint8), dev) if n else torch.empty(0, dtype=torch.uint8, device=dev)
+    if n == 0:
+        mask = torch.empty(4, dtype=torch.uint8, device=dev)
+    index = native.mask_to_index(mask, n)
+    assert np.array_equal(index.cpu().numpy(), np.flatnonzero(m).astype(np.int32))
+
+
+@pytest.mark.parametrize("tdtype,np_dtype", DTYPES)
+def test_reduce(dev, tdtype, np_dtype):
+    rng = np.random.default_rng(16)
+    x = make_fields(rng, 1, 100003, np_dtype)[0]
+    xd = to_dev(x, dev)
+    assert native.reduce(xd, native.RED_MIN) == float(x.min())
+    assert native.reduce(xd, native.RED_MAX) == float(x.max())
+    assert native.reduce(xd, native.RED_NANCOUNT) == 0.0
+    x[[5, 77, 99999]] = np.nan
+    xd = to_dev(x, dev)
+    assert np.isnan(native.reduce(xd, native.RED_MIN)) and np.isnan(x.min())
+    assert np.isnan(native.reduce(xd, native.RED_MAX))
+    assert native.reduce(xd, native.RED_NANCOUNT) == float(np.sum(np.isnan(x)))
+
+
+# ---------------------------------------------------------------------------------
+# layout
+# ---------------------------------------------------------------------------------
+@pytest.mark.parametrize("tdtype,np_dtype", DTYPES)
+@pytest.mark.parametrize("n_lev,n_pts", [(1, 1), (3, 70), (137, 1000), (200, 333), (5, 40320)])
+def test_relayout_round_trip(dev, tdtype, np_dtype, n_lev, n_pts):
+    rng = np.random.default_rng(17)
+    x = make_fields(rng, n_lev, n_pts, np_dtype, nan_frac=0.01)
+    fm = Stack.from_fields(x, dev=dev, layout=FIELDS)
+    cols = fm.to_layout(COLUMNS)
+    itype = np.uint32 if np_dtype == np.float32 else np.uint64
+    assert np.array_equal(cols.data[:, :n_lev].T.cpu().numpy().view(itype), x.view(itype))
+    back = cols.to_layout(FIELDS)
+    assert np.array_equal(back.data.cpu().numpy().view(itype), x.view(itype))
+    assert np.array_equal(cols.level_numpy(n_lev - 1).view(itype), x[-1].view(itype))
