@@ -361,8 +361,9 @@ check_indices_kernel(const int32_t* __restrict__ idx, int64_t n, int64_t n_src, 
 // host-side launchers
 // ---------------------------------------------------------------------------------
 static int pick_tile(int64_t n_tgt, int C) {
-    // ~4 sweeps of 256 lanes x kUnroll items per workgroup, at least 8 targets
-    int tile = (kBlock * kUnroll * 2 + C - 1) / C;
+    // about 3/4 of one sweep of 256 lanes x kUnroll items per workgroup (measured best on
+    // O1280 -> 0.25 deg x137: tiles of 16-24 targets, profiles/r01_tile_sweep.log), >= 8 targets
+    int tile = (kBlock * kUnroll * 3 / 4 + C - 1) / C;
     if (tile < 8) tile = 8;
     if (tile > 256) tile = 256;
     if ((int64_t)tile > n_tgt) tile = (int)n_tgt;

@@ -1,0 +1,93 @@
+#!/usr/bin/env python3
+"""Workload for the rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE, one counter set per run).
+
+Runs, on one GPU, with the bench's O1280 -> 0.25 degree k=4 x137 inputs:
+  1. a CALIBRATION launch with a known byte count in the same access width as the
+     regrid kernel (16 B per lane): `atx_pointwise_stack` copying the whole source
+     stack out of place  -> reads n_src*pitch*B bytes, writes the same;
+  2. `--launches` regrid launches (`regrid_cols_ell_kernel`).
+The counters of (1) give the correction factor MI355X_MICROARCH.md §HBM asks for
+(FETCH_SIZE reads ~1/2 of a wide coalesced stream on gfx950); tools/pmc_summarize.py
+applies it to (2) and writes profiles/traffic.json.
+
+    rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d gpurun_out/pmc_fetch -- python3 tools/pmc_probe.py
+    rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d gpurun_out/pmc_write -- python3 tools/pmc_probe.py
+"""
+
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import __graft_entry__ as graft  # noqa: E402
+import bench  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--launches", type=int, default=3)
+    ap.add_argument("--dtype", default="f32")
+    ap.add_argument("--k", type=int, default=4)
+    ap.add_argument("--levels", type=int, default=137)
+    ap.add_argument("--meta", default=os.path.join(ROOT, "gpurun_out", "pmc_meta.json"))
+    args = ap.parse_args()
+
+    graft.load_package()
+    from anemoi_transform_amd import native
+    from anemoi_transform_amd.grids import lookup
+    from anemoi_transform_amd.interp import knn_inverse_distance
+    from anemoi_transform_amd.stack import COLUMNS, Stack
+
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    tdtype = torch.float32 if args.dtype == "f32" else torch.float64
+    npdt = np.float32 if args.dtype == "f32" else np.float64
+    itemsize = 4 if args.dtype == "f32" else 8
+
+    src_grid, tgt_grid = lookup("o1280"), lookup("0.25")
+    n_src, n_tgt = len(src_grid["latitudes"]), len(tgt_grid["latitudes"])
+    idx64, w64 = knn_inverse_distance(src_grid, tgt_grid, k=args.k)
+    idx = torch.from_numpy(idx64.astype(np.int32)).to(dev)
+    w = torch.from_numpy(w64.astype(npdt)).to(dev) if args.k > 1 else None
+    src = bench.synth_stack(src_grid, args.levels, tdtype, dev, 0, COLUMNS)
+    out = Stack.empty(n_tgt, args.levels, tdtype, dev, COLUMNS)
+    torch.cuda.synchronize()
+
+    # 1. calibration: full-stack copy, 16 B per lane, known bytes
+    copy = src.new_like()
+    prog = native.level_program([[(native.OP_COPY, 0, 0.0, 0.0)] * args.levels], dev)
+    native.pointwise_stack(src.data, copy.data, n_pts=n_src, n_lev=args.levels, x_pitch=src.pitch, y_pitch=copy.pitch,
+                           layout=COLUMNS, prog=prog, n_stage=1)
+    torch.cuda.synchronize()
+    covered = (args.levels + (16 // itemsize) - 1) // (16 // itemsize) * (16 // itemsize)
+    calib_bytes = n_src * covered * itemsize
+
+    # 2. the regrid launches
+    for _ in range(args.launches):
+        native.regrid_ell(src.data, out.data, idx, w, n_src=n_src, n_tgt=n_tgt, k=args.k, n_lev=args.levels,
+                          src_pitch=src.pitch, out_pitch=out.pitch, layout=COLUMNS)
+    torch.cuda.synchronize()
+
+    meta = {
+        "config": f"o1280->0.25 k={args.k} L={args.levels} {args.dtype} columns gpus=1",
+        "calibration_kernel": "pointwise_cols_kernel",
+        "calibration_read_bytes": calib_bytes,
+        "calibration_write_bytes": calib_bytes,
+        "regrid_kernel": "regrid_cols_ell_kernel",
+        "regrid_launches": args.launches,
+        "algorithmic_bytes_per_launch": bench.algorithmic_bytes(args.levels, itemsize, int(np.unique(idx64).size), n_tgt, args.k),
+    }
+    os.makedirs(os.path.dirname(args.meta), exist_ok=True)
+    json.dump(meta, open(args.meta, "w"), indent=1)
+    print(json.dumps(meta))
+
+
+if __name__ == "__main__":
+    main()
