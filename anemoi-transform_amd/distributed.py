@@ -1,0 +1,104 @@
+"""Multi-GPU regrid: target points sharded over ranks, source stack sent once.
+
+One process per GPU (``torch.distributed``; backend ``nccl`` = RCCL over xGMI on
+MI355X, ``gloo`` in the CPU tests).  The reference has no counterpart: it is a
+single-process loop.  The partitioning follows SURVEY.md §8e:
+
+* row ``t`` of the interpolation operator reads only source points and writes only
+  target ``t``, so ``[0, n_tgt)`` is cut into ``world`` contiguous slices
+  (``GatherPlan.shard``) and the slices never talk to each other;
+* every rank needs the source stack: it is broadcast ONCE (``broadcast_stack``,
+  one RCCL broadcast of the contiguous stack tensor) — or, better, each rank only
+  loads the band of source columns its slice references (``source_band``): in the
+  column layout that band is one contiguous slab;
+* outputs stay sharded (``FieldList`` per rank); ``gather_target_shards``
+  assembles the full field on every rank for callers that need it.
+"""
+
+from __future__ import annotations
+
+import os
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from .gather import GatherPlan, shard_bounds
+from .stack import COLUMNS, Stack
+
+
+def init_process_group(backend: str | None = None) -> tuple[int, int]:
+    """Join the job described by RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT; returns (rank, world)."""
+    if not dist.is_initialized():
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC only on this platform
+        kwargs = {}
+        if backend == "nccl":
+            local = int(os.environ.get("LOCAL_RANK", "0"))
+            torch.cuda.set_device(local)
+            kwargs["device_id"] = torch.device("cuda", local)
+        dist.init_process_group(backend, **kwargs)
+    return dist.get_rank(), dist.get_world_size()
+
+
+def broadcast_stack(stack: Stack | None, src: int, *, n_pts: int, n_lev: int, dtype: torch.dtype, device: torch.device,
+                    layout: int = COLUMNS) -> Stack:
+    """The source stack of rank ``src`` on every rank (one broadcast of the whole pitched tensor)."""
+    if dist.get_rank() == src:
+        assert stack is not None and (stack.n_pts, stack.n_lev, stack.layout) == (n_pts, n_lev, layout)
+        buf = stack
+    else:
+        buf = Stack.empty(n_pts, n_lev, dtype, device, layout)
+    dist.broadcast(buf.data, src=src)
+    return buf
+
+
+def exchange_stacks(mine: Stack) -> list[Stack]:
+    """Every rank contributes one stack of identical shape; every rank ends up with all of them
+    (``world`` broadcasts — the "source broadcast once" step of a target-sharded job)."""
+    rank, world = dist.get_rank(), dist.get_world_size()
+    out = []
+    for r in range(world):
+        out.append(broadcast_stack(mine if r == rank else None, r, n_pts=mine.n_pts, n_lev=mine.n_lev, dtype=mine.dtype,
+                                   device=mine.device, layout=mine.layout))
+    return out
+
+
+def source_band(plan: GatherPlan) -> tuple[int, int]:
+    """``[lo, hi)`` range of source points a (sharded) plan references.  For a latitude-ordered
+    target slice this is a narrow band of the source grid — with column stacks one contiguous
+    slab of HBM, so a rank can be fed its band instead of the whole stack."""
+    idx = plan.index if plan.kind == "ell" else plan.indices
+    if idx.size == 0:
+        return 0, 0
+    return int(idx.min()), int(idx.max()) + 1
+
+
+def rebase_plan(plan: GatherPlan, lo: int, hi: int) -> GatherPlan:
+    """The same plan expressed against the source slab ``[lo, hi)``."""
+    if plan.kind == "ell":
+        return GatherPlan(hi - lo, plan.n_tgt, index=plan.index.astype(np.int64) - lo, weights=plan.weights)
+    return GatherPlan(hi - lo, plan.n_tgt, csr=(plan.data, plan.indices.astype(np.int64) - lo, plan.indptr))
+
+
+def sharded_regrid(plan: GatherPlan, src: Stack, rank: int | None = None, world: int | None = None) -> Stack:
+    """This rank's slice of ``plan`` applied to the (replicated) source stack."""
+    rank = dist.get_rank() if rank is None else rank
+    world = dist.get_world_size() if world is None else world
+    return plan.shard(rank, world).apply(src)
+
+
+def gather_target_shards(local: Stack, n_tgt: int) -> Stack:
+    """All target slices on every rank (column layout: each slice is a contiguous row range)."""
+    assert local.layout == COLUMNS, "target shards are row ranges of a column stack"
+    rank, world = dist.get_rank(), dist.get_world_size()
+    full = Stack.empty(n_tgt, local.n_lev, local.dtype, local.device, COLUMNS)
+    for r in range(world):
+        lo, hi = shard_bounds(n_tgt, r, world)
+        if r == rank:
+            assert local.n_pts == hi - lo
+            full.data[lo:hi].copy_(local.data)
+        if hi > lo:
+            dist.broadcast(full.data[lo:hi], src=r)
+    return full

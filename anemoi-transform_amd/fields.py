@@ -1,0 +1,533 @@
+"""earthkit-shaped Field / FieldList for the filter path, backed by HBM stacks.
+
+The reference filters see earthkit-data fields through a small surface
+(SURVEY.md §8b): ``to_numpy(flatten=, dtype=, index=)``, ``values``, ``shape``,
+``grid_points()``, ``to_latlon()``, ``metadata(...)``, ``clone()``; and
+FieldLists through iteration, ``len``, indexing, ``metadata(key)``, ``sel``.
+earthkit-data is not installed here, so this module supplies look-alikes:
+
+* ``ArrayField``   — a host field built from the ``list-of-dicts`` form the
+  reference's tests use (R: tests/conftest.py:40-67): 2-D ``values`` laid out
+  latitude-major over distinct ``latitudes`` / ``longitudes``.
+* ``DerivedField`` — the three zero-copy wrappers of the reference in one class:
+  new data (R: fields.py:157-205 ``NewDataField``), new metadata with the
+  override-before-template lookup (R: fields.py:468-568), new lat/lon
+  (R: fields.py:318-381).  Its data is either a host array or — the engine's case —
+  ``(Stack, level)``: one level of a stack resident in HBM.  ``to_numpy`` is the
+  compatibility path and implies a device-to-host copy.
+* ``FieldList``    — ``SimpleFieldList`` look-alike (R: fields.py:35-48).
+* ``FieldSelection`` — R: fields.py:767-797.
+
+``group_into_stacks`` is how filters see a FieldList: runs of same-grid fields as
+whole stacks, so each filter is one kernel launch per stack instead of one numpy
+call per field.
+"""
+
+from __future__ import annotations
+
+import logging
+from typing import Any, Iterable, Iterator
+
+import numpy as np
+import torch
+
+from . import stack as _stack
+from .stack import COLUMNS, Stack
+
+LOG = logging.getLogger(__name__)
+
+MISSING = object()
+
+# R: tests/conftest.py:27 — the keys a "mars" namespace view exposes
+MARS_KEYS = ("param", "levelist", "levtype", "type", "step", "date", "time", "number", "expver", "class", "stream", "domain")
+
+_GEO_KEYS = ("latitudes", "longitudes")
+
+
+class Geography:
+    """``metadata().geography`` of a field (R: fields.py:208-315)."""
+
+    def __init__(self, owner: "Field") -> None:
+        self._owner = owner
+
+    def latitudes(self, dtype=None) -> np.ndarray:
+        lat = self._owner.grid_points()[0]
+        return lat if dtype is None else lat.astype(dtype)
+
+    def longitudes(self, dtype=None) -> np.ndarray:
+        lon = self._owner.grid_points()[1]
+        return lon if dtype is None else lon.astype(dtype)
+
+    def shape(self) -> tuple[int, ...]:
+        return tuple(self._owner.shape)
+
+    def resolution(self) -> str:
+        return "unknown"
+
+    def mars_area(self) -> list[float]:
+        lat, lon = self._owner.grid_points()
+        return [np.amax(lat), np.amin(lon), np.amin(lat), np.amax(lon)]
+
+    def mars_grid(self) -> None:
+        return None
+
+    def projection(self) -> None:
+        return None
+
+
+class _MetadataView:
+    """What ``field.metadata()`` (no arguments) returns: ``get`` / ``keys`` / ``[]`` / ``geography``."""
+
+    def __init__(self, field: "Field") -> None:
+        self._field = field
+        self.geography = Geography(field)
+
+    def get(self, key: str, default: Any = None) -> Any:
+        try:
+            return self._field.metadata(key)
+        except KeyError:
+            return default
+
+    def keys(self):
+        return self._field._metadata_keys()
+
+    def __getitem__(self, key: str) -> Any:
+        return self._field.metadata(key)
+
+    def __contains__(self, key: str) -> bool:
+        return self.get(key, MISSING) is not MISSING
+
+    def items(self):
+        return [(k, self.get(k)) for k in self.keys()]
+
+
+class Field:
+    """Common surface of host and device fields."""
+
+    # ---- to be provided by subclasses -----------------------------------------------
+    shape: tuple[int, ...]
+
+    def _flat(self) -> np.ndarray:  # a fresh, flattened host copy
+        raise NotImplementedError
+
+    def grid_points(self) -> tuple[np.ndarray, np.ndarray]:
+        raise NotImplementedError
+
+    def _lookup(self, key: str) -> Any:  # MISSING if absent
+        raise NotImplementedError
+
+    def _metadata_keys(self) -> list[str]:
+        raise NotImplementedError
+
+    def stack_ref(self) -> tuple[Stack, int] | None:
+        """``(stack, level)`` if the data lives in HBM, else ``None``."""
+        return None
+
+    # ---- reference surface -----------------------------------------------------------
+    def to_numpy(self, flatten: bool = False, dtype: Any = None, index: Any = None) -> np.ndarray:
+        # R: fields.py:178-202 — astype, flatten, index, in that order; always a copy here
+        data = self._flat()
+        if dtype is not None:
+            data = data.astype(dtype)
+        if not flatten:
+            data = data.reshape(self.shape)
+        if index is not None:
+            data = data[index]
+        return data
+
+    @property
+    def values(self) -> np.ndarray:
+        return self.to_numpy(flatten=True)
+
+    def to_latlon(self, flatten: bool = True) -> dict[str, np.ndarray]:
+        lat, lon = self.grid_points()
+        if not flatten:
+            lat, lon = lat.reshape(self.shape), lon.reshape(self.shape)
+        return dict(lat=lat, lon=lon)
+
+    def metadata(self, *keys: str, namespace: str | None = None, default: Any = MISSING, **_: Any) -> Any:
+        if namespace:
+            assert len(keys) == 0, (keys, namespace)
+            return self._namespace(namespace)
+        if len(keys) == 0:
+            return _MetadataView(self)
+
+        def one(key: str) -> Any:
+            value = self._lookup(key)
+            if value is MISSING:
+                if default is not MISSING:
+                    return default
+                raise KeyError(key)
+            return value
+
+        result = [one(k) for k in keys]
+        return result[0] if len(result) == 1 else tuple(result)
+
+    def _namespace(self, namespace: str) -> dict[str, Any]:
+        if namespace != "mars":
+            return {}
+        out = {}
+        for key in MARS_KEYS:
+            value = self._lookup(key)
+            if value is not MISSING:
+                out[key] = value
+        return out
+
+    def clone(self, **metadata: Any) -> "DerivedField":
+        # R: fields.py:131-144 / 600-641: new metadata, same data
+        return DerivedField(self, metadata=metadata)
+
+    def __iter__(self):
+        raise NotImplementedError(f"{self}: iterating is not supported")  # R: fields.py:146-154
+
+
+class ArrayField(Field):
+    """A host field: array + metadata dict + per-point coordinates."""
+
+    def __init__(self, values: Any, metadata: dict[str, Any], latitudes: np.ndarray, longitudes: np.ndarray) -> None:
+        self._values = np.asarray(values)
+        self._md = dict(metadata)
+        self._latitudes = np.asarray(latitudes, dtype=np.float64)
+        self._longitudes = np.asarray(longitudes, dtype=np.float64)
+        self.shape = tuple(self._values.shape)
+        assert self._latitudes.shape == self._longitudes.shape == (self._values.size,), (
+            self._latitudes.shape, self._longitudes.shape, self._values.shape,
+        )
+
+    @classmethod
+    def from_dict(cls, spec: dict[str, Any]) -> "ArrayField":
+        """The ``list-of-dicts`` entry form of the reference tests (R: tests/conftest.py:63).
+
+        ``values`` is ``[nlat, nlon]`` over DISTINCT ``latitudes`` / ``longitudes``
+        (flattened latitude-major, R: tests/field_filters/test_remove_nans.py:17-45),
+        or 1-D with one latitude / longitude per point.
+        """
+        spec = dict(spec)
+        values = np.asarray(spec.pop("values"))
+        if values.dtype.kind != "f":
+            values = values.astype(np.float64)
+        lat = np.asarray(spec["latitudes"], dtype=np.float64)
+        lon = np.asarray(spec["longitudes"], dtype=np.float64)
+        if values.ndim == 2 and lat.ndim == 1 and lon.ndim == 1 and values.shape == (len(lat), len(lon)):
+            lat2, lon2 = np.meshgrid(lat, lon, indexing="ij")
+            lat, lon = lat2.reshape(-1), lon2.reshape(-1)
+        else:
+            lat, lon = lat.reshape(-1), lon.reshape(-1)
+        return cls(values, spec, lat, lon)
+
+    def _flat(self) -> np.ndarray:
+        return self._values.flatten()
+
+    def grid_points(self) -> tuple[np.ndarray, np.ndarray]:
+        return self._latitudes, self._longitudes
+
+    def _lookup(self, key: str) -> Any:
+        return self._md.get(key, MISSING)
+
+    def _metadata_keys(self) -> list[str]:
+        return list(self._md.keys())
+
+    def __repr__(self) -> str:
+        return f"ArrayField({self._md.get('param')}, shape={self.shape})"
+
+
+class DerivedField(Field):
+    """A field that re-labels a template: new data and / or metadata and / or grid."""
+
+    def __init__(
+        self,
+        template: Field,
+        *,
+        data: np.ndarray | None = None,
+        stack_level: tuple[Stack, int] | None = None,
+        latitudes: np.ndarray | None = None,
+        longitudes: np.ndarray | None = None,
+        metadata: dict[str, Any] | None = None,
+    ) -> None:
+        # metadata overrides travel as a dict: keys such as "level" or "data" are legal metadata names
+        assert data is None or stack_level is None
+        stack, level = stack_level if stack_level is not None else (None, None)
+        self._template = template
+        self._data = data
+        self._stack = stack
+        self._level = level
+        self._latitudes = latitudes
+        self._longitudes = longitudes
+        self._overrides = dict(metadata or {})
+        if data is not None:
+            self.shape = tuple(np.shape(data))  # R: fields.py:168-171
+        elif stack is not None:
+            tshape = tuple(getattr(template, "shape", ()))
+            keep = latitudes is None and int(np.prod(tshape or (0,))) == stack.n_pts
+            self.shape = tshape if keep else (stack.n_pts,)
+        elif latitudes is not None:
+            self.shape = (len(latitudes),)
+        else:
+            self.shape = tuple(template.shape)
+
+    # ---- data ------------------------------------------------------------------------
+    def stack_ref(self) -> tuple[Stack, int] | None:
+        if self._stack is not None:
+            return self._stack, self._level
+        if self._data is None:
+            return self._template.stack_ref()
+        return None
+
+    def _flat(self) -> np.ndarray:
+        if self._stack is not None:
+            return host_level(self._stack, self._level)
+        if self._data is not None:
+            return np.asarray(self._data).flatten()
+        return self._template.to_numpy(flatten=True)
+
+    # ---- grid ------------------------------------------------------------------------
+    def grid_points(self) -> tuple[np.ndarray, np.ndarray]:
+        if self._latitudes is not None:
+            return self._latitudes, self._longitudes
+        return self._template.grid_points()
+
+    # ---- metadata: overrides are consulted before the template (R: fields.py:532-546) ----
+    def _lookup(self, key: str) -> Any:
+        if key in self._overrides:
+            value = self._overrides[key]
+            if callable(value):
+                return value(self, key, self._template.metadata())
+            return value
+        if self._latitudes is not None and key in _GEO_KEYS:
+            return self._latitudes if key == "latitudes" else self._longitudes
+        return self._template._lookup(key) if isinstance(self._template, Field) else _foreign_lookup(self._template, key)
+
+    def _metadata_keys(self) -> list[str]:
+        # the template's keys only (R: fields.py:508-509; hence the xfails at tests/test_fields.py:45-46)
+        if isinstance(self._template, Field):
+            return self._template._metadata_keys()
+        return list(self._template.metadata().keys())
+
+    def _namespace(self, namespace: str) -> dict[str, Any]:
+        # copy of the template's namespace; overrides only for keys already present (R: fields.py:523-530)
+        base = dict(self._template.metadata(namespace=namespace))
+        for key in list(base.keys()):
+            if key in self._overrides:
+                base[key] = self._overrides[key]
+        return base
+
+    def __repr__(self) -> str:
+        where = f"hbm level {self._level}" if self._stack is not None else ("host array" if self._data is not None else "template data")
+        return f"DerivedField({self._template!r}, {where}, metadata={self._overrides})"
+
+
+def _foreign_lookup(field: Any, key: str) -> Any:
+    """Metadata of a real earthkit field used as a template."""
+    try:
+        return field.metadata(key)
+    except KeyError:
+        return MISSING
+
+
+# ---- host copies of device levels ------------------------------------------------------
+_HOST_CACHE_ATTR = "_host_fields"
+
+
+def host_level(stack: Stack, level: int) -> np.ndarray:
+    """One level of a stack as a fresh host array.
+
+    The first access brings the whole stack over in ONE device-to-host copy
+    (field-major, through the relayout kernel); later accesses are slices of it.
+    Stacks are immutable once published to a FieldList, so the copy cannot go stale.
+    """
+    cached = _host_cache.get(id(stack))
+    if cached is None or cached[0] is not stack:
+        cached = (stack, stack.numpy())
+        _host_cache.clear()  # keep at most one stack on the host
+        _host_cache[id(stack)] = cached
+    return cached[1][level].copy()
+
+
+_host_cache: dict[int, tuple[Stack, np.ndarray]] = {}
+
+
+# ---- reference factory functions --------------------------------------------------------
+def new_field_from_numpy(array: np.ndarray, *, template: Field, **metadata: Any) -> DerivedField:
+    """R: fields.py:645-662."""
+    return DerivedField(template, data=array, metadata=metadata)
+
+
+def new_field_from_latitudes_longitudes(template: Field, latitudes: np.ndarray, longitudes: np.ndarray) -> DerivedField:
+    """R: fields.py:719-738."""
+    return DerivedField(template, latitudes=np.asarray(latitudes), longitudes=np.asarray(longitudes))
+
+
+def new_field_with_metadata(template: Field, **metadata: Any) -> DerivedField:
+    """R: fields.py:683-698."""
+    return DerivedField(template, metadata=metadata)
+
+
+def new_field_from_stack(stack: Stack, level: int, *, template: Field, latitudes=None, longitudes=None,
+                         metadata: dict[str, Any] | None = None) -> DerivedField:
+    """Engine-side factory: the field is level ``level`` of an HBM stack."""
+    return DerivedField(template, stack_level=(stack, level), latitudes=latitudes, longitudes=longitudes, metadata=metadata)
+
+
+class FieldList:
+    """Ordered collection of fields (``SimpleFieldList`` look-alike, R: fields.py:35-48)."""
+
+    def __init__(self, fields: Iterable[Any] | None = None) -> None:
+        self._fields = list(fields or [])
+
+    def __iter__(self) -> Iterator[Any]:
+        return iter(self._fields)
+
+    def __len__(self) -> int:
+        return len(self._fields)
+
+    def __getitem__(self, i):
+        if isinstance(i, slice):
+            return FieldList(self._fields[i])
+        return self._fields[i]
+
+    def append(self, field: Any) -> None:
+        self._fields.append(field)
+
+    def metadata(self, *keys: str, **kwargs: Any) -> list[Any]:
+        return [f.metadata(*keys, **kwargs) for f in self._fields]
+
+    def sel(self, **selection: Any) -> "FieldList":
+        def ok(f):
+            for key, want in selection.items():
+                want = want if isinstance(want, (list, tuple)) else (want,)
+                try:
+                    if f.metadata(key) not in want:
+                        return False
+                except KeyError:
+                    return False
+            return True
+
+        return FieldList([f for f in self._fields if ok(f)])
+
+    def to_numpy(self, **kwargs: Any) -> np.ndarray:
+        return np.stack([f.to_numpy(**kwargs) for f in self._fields])
+
+    @property
+    def ls(self) -> str:
+        return "\n".join(repr(f) for f in self._fields)
+
+    def __repr__(self) -> str:
+        return f"FieldList({len(self._fields)} fields)"
+
+
+def new_fieldlist_from_list(fields: list[Any]) -> FieldList:
+    return FieldList(fields)
+
+
+def new_empty_fieldlist() -> FieldList:
+    return FieldList([])
+
+
+def fieldlist_from_dicts(specs: list[dict[str, Any]]) -> FieldList:
+    """``ekd.from_source("list-of-dicts", specs)`` look-alike."""
+    return FieldList([ArrayField.from_dict(s) for s in specs])
+
+
+class FieldSelection:
+    """Which fields a filter transforms (R: fields.py:767-797)."""
+
+    ALLOWED_KEYS = {"param", "levelist"}
+
+    def __init__(self, **kwargs: Any) -> None:
+        self._spec = kwargs
+        if not set(self._spec).issubset(self.ALLOWED_KEYS):
+            raise ValueError(f"Invalid keys in spec: {tuple(self._spec)} - only {self.ALLOWED_KEYS} are allowed.")
+        for key, value in list(self._spec.items()):
+            if isinstance(value, (str, int, float, bool)):
+                self._spec[key] = (value,)
+            elif value is None or (isinstance(value, (list, tuple)) and len(value) == 0):
+                del self._spec[key]
+            elif not isinstance(value, (list, tuple)):
+                raise ValueError(f"Invalid value for key {key}: {value}")
+        self._all = len(self._spec) == 0
+
+    def match(self, field: Any) -> bool:
+        if self._all:
+            return True
+        try:
+            return all(field.metadata(key) in values for key, values in self._spec.items())
+        except KeyError:
+            return False
+
+
+# =================================================================================
+# FieldList -> stacks
+# =================================================================================
+class StackGroup:
+    """Fields of a FieldList that share a grid, as one HBM stack.
+
+    ``positions[i]`` is the index in the FieldList of the field stored at level ``i``.
+    """
+
+    __slots__ = ("stack", "positions", "fields")
+
+    def __init__(self, stack: Stack, positions: list[int], fields: list[Any]) -> None:
+        self.stack = stack
+        self.positions = positions
+        self.fields = fields
+
+
+_upload_dtype: torch.dtype | None = None
+
+
+def set_upload_dtype(dtype: torch.dtype | None) -> None:
+    """Force the dtype host fields are uploaded in (``None``: keep float32 inputs, else float64 —
+    the reference's ``to_numpy`` default)."""
+    global _upload_dtype
+    _upload_dtype = dtype
+
+
+def _host_dtype(arrays: list[np.ndarray]) -> torch.dtype:
+    if _upload_dtype is not None:
+        return _upload_dtype
+    return torch.float32 if all(a.dtype == np.float32 for a in arrays) else torch.float64
+
+
+def select_levels(stack: Stack, levels: list[int]) -> Stack:
+    """A new stack holding the given levels of ``stack`` (device-side copy)."""
+    if levels == list(range(stack.n_lev)):
+        return stack
+    out = Stack.empty(stack.n_pts, len(levels), stack.dtype, stack.device, stack.layout, zero=True)
+    index = torch.tensor(levels, dtype=torch.long, device=stack.device)
+    if stack.layout == COLUMNS:
+        out.data[:, : len(levels)] = stack.data.index_select(1, index)
+    else:
+        out.data[: len(levels), : stack.n_pts] = stack.data.index_select(0, index)[:, : stack.n_pts]
+    return out
+
+
+def group_into_stacks(fields: Iterable[Any], positions: list[int] | None = None) -> list[StackGroup]:
+    """Partition fields into stacks: device fields by the stack they live in, host fields by grid size.
+
+    Host groups are uploaded once (one H2D copy + one relayout launch); device groups
+    that cover a whole stack in order are used in place, others are compacted on the
+    device.  ``positions`` restricts the grouping to a subset of the list.
+    """
+    fields = list(fields)
+    wanted = range(len(fields)) if positions is None else positions
+    buckets: dict[Any, list[int]] = {}
+    for i in wanted:
+        ref = fields[i].stack_ref() if isinstance(fields[i], Field) else None
+        if ref is not None:
+            key = ("hbm", id(ref[0]))
+        else:
+            key = ("host", int(np.prod(fields[i].shape)))
+        buckets.setdefault(key, []).append(i)
+
+    groups = []
+    for key, members in buckets.items():
+        group_fields = [fields[i] for i in members]
+        if key[0] == "hbm":
+            stack = group_fields[0].stack_ref()[0]
+            levels = [f.stack_ref()[1] for f in group_fields]
+            groups.append(StackGroup(select_levels(stack, levels), members, group_fields))
+        else:
+            arrays = [f.to_numpy(flatten=True) for f in group_fields]
+            dtype = _host_dtype(arrays)
+            groups.append(StackGroup(Stack.from_fields(arrays, dtype=dtype, dev=_stack.device()), members, group_fields))
+    return groups

@@ -1,0 +1,236 @@
+"""The ``regrid`` filter: grid-to-grid interpolation as one gather launch per stack.
+
+Mirror of R: filters/fields/regrid.py — same constructor, same choice between the four
+interpolators (``matrix`` > ``mask`` > ``method == "nearest"`` > earthkit-regrid,
+R: regrid.py:432-467), same validation and error types.  Where the reference loops over
+fields calling ``interpolator(field)`` (R: regrid.py:204-208), this filter groups the
+FieldList into HBM stacks and runs the interpolator's ``GatherPlan`` once per stack;
+``interpolator(field)`` still works for a single field.
+"""
+
+from __future__ import annotations
+
+import logging
+from typing import Any
+
+import numpy as np
+
+from ..core import Filter, filter_registry
+from ..fields import Field, FieldList, group_into_stacks, new_field_from_stack
+from ..gather import GatherPlan
+
+LOG = logging.getLogger(__name__)
+
+
+def as_gridspec(grid: Any) -> dict[str, Any] | None:
+    """R: regrid.py:29-48."""
+    if grid is None:
+        return None
+    if isinstance(grid, (str, list, tuple)):
+        return {"grid": grid}
+    return grid
+
+
+def as_griddata(grid: Any) -> dict[str, Any] | None:
+    """R: regrid.py:51-84 — a Field gives its own grid points; names go through ``grids.lookup``."""
+    if grid is None:
+        return None
+    if isinstance(grid, Field) or (hasattr(grid, "grid_points") and not isinstance(grid, dict)):
+        lat, lon = grid.grid_points()
+        return dict(latitudes=lat, longitudes=lon)
+    if isinstance(grid, dict) and "latitudes" in grid and "longitudes" in grid:
+        return grid
+    if isinstance(grid, (str, list, tuple)):
+        from ..grids import lookup
+
+        return lookup(grid)
+    raise ValueError(f"Invalid grid: {grid}")
+
+
+class _Interpolator:
+    """Common part: run a GatherPlan over stacks and re-label the result with the output grid."""
+
+    def plan_for(self, first_field: Any) -> GatherPlan:
+        raise NotImplementedError
+
+    def out_latlon(self, first_field: Any) -> tuple[np.ndarray, np.ndarray]:
+        raise NotImplementedError
+
+    def regrid_fieldlist(self, data: Any, *, shard: tuple[int, int] | None = None) -> FieldList:
+        fields = list(data)
+        out: list[Any] = [None] * len(fields)
+        for group in group_into_stacks(fields):
+            plan = self.plan_for(group.fields[0])
+            lat, lon = self.out_latlon(group.fields[0])
+            if shard is not None:
+                from ..gather import shard_bounds
+
+                lo, hi = shard_bounds(plan.n_tgt, *shard)
+                plan, lat, lon = self._sharded(plan, shard), lat[lo:hi], lon[lo:hi]
+            regridded = plan.apply(group.stack)
+            for level, (pos, f) in enumerate(zip(group.positions, group.fields)):
+                out[pos] = new_field_from_stack(regridded, level, template=f, latitudes=lat, longitudes=lon)
+        return FieldList(out)
+
+    def _sharded(self, plan: GatherPlan, shard: tuple[int, int]) -> GatherPlan:
+        cache = self.__dict__.setdefault("_shard_cache", {})
+        key = (id(plan), shard)
+        if key not in cache:
+            cache[key] = plan.shard(*shard)
+        return cache[key]
+
+    def __call__(self, field: Any) -> Any:
+        return self.regrid_fieldlist([field])[0]
+
+
+class EarthkitRegrid(_Interpolator):
+    """Default interpolator of the reference: delegates to ``earthkit.regrid.interpolate``, which
+    fetches a pre-generated MIR matrix from a remote inventory (R: regrid.py:211-259).  That
+    third-party path is unavailable offline: constructing it raises unless
+    earthkit-regrid is importable; use ``matrix=`` (see ``interp``) or ``method="nearest"``."""
+
+    def __init__(self, *, in_grid: Any, out_grid: Any, method: str = "linear", check: bool = False) -> None:
+        self.in_grid = as_gridspec(in_grid)
+        self.out_grid = as_gridspec(out_grid)
+        self.method = method
+        if check:
+            LOG.warning("Check is not supported by EarthkitRegrid")
+        try:
+            import earthkit.regrid  # type: ignore # noqa: F401
+        except ImportError as e:
+            raise NotImplementedError(
+                f"regrid(method={method!r}) needs earthkit-regrid and its remote matrix inventory, which are not "
+                "available here; pass a pre-computed `matrix` (anemoi_transform_amd.interp writes the same npz "
+                "format) or use method='nearest'"
+            ) from e
+        raise NotImplementedError("earthkit-regrid matrices are not wired to the HBM path yet; pass `matrix=`")
+
+
+class MIRMatrix(_Interpolator):
+    """A matrix written by ``anemoi-transform make-regrid-file`` (R: regrid.py:262-312), or the same dict in memory."""
+
+    def __init__(self, *, matrix: Any, check: bool) -> None:
+        self.check = check
+        if self.check:
+            LOG.warning("Check is not supported by MIRMatrix")
+        loaded = dict(np.load(matrix)) if isinstance(matrix, str) else dict(matrix)
+        self.plan = GatherPlan.from_matrix(loaded)
+        self.in_grid = dict(latitudes=loaded.get("in_latitudes"), longitudes=loaded.get("in_longitudes"))
+        self.out_grid = dict(latitudes=loaded["out_latitudes"], longitudes=loaded["out_longitudes"])
+
+    def plan_for(self, first_field: Any) -> GatherPlan:
+        return self.plan
+
+    def out_latlon(self, first_field: Any):
+        return self.out_grid["latitudes"], self.out_grid["longitudes"]
+
+
+class ScipyKDTreeNearestNeighbours(_Interpolator):
+    """k = 1 nearest neighbour on the unit sphere (R: regrid.py:315-381, spatial.py:587-635)."""
+
+    nearest_grid_points = None
+
+    def __init__(self, *, in_grid: Any = None, out_grid: Any = None, method: str, check: bool = False) -> None:
+        if method != "nearest":
+            raise NotImplementedError(f"ScipyKDTreeNearestNeighbours does not support {method}, only 'nearest'")
+        self.in_grid = as_griddata(in_grid)
+        self.out_grid = as_griddata(out_grid)
+        if self.out_grid is None:
+            raise ValueError("out_grid is required, but not provided")
+        if check:
+            LOG.warning("Check is not supported by ScipyKDTreeNearestNeighbours")
+        self._plan: GatherPlan | None = None
+
+    def plan_for(self, first_field: Any) -> GatherPlan:
+        if self.in_grid is None:  # defaults to the first field's own grid (R: regrid.py:359-361)
+            self.in_grid = as_griddata(first_field)
+            assert self.in_grid is not None, first_field
+        if self._plan is None:
+            from ..interp import nearest_grid_points
+
+            self.nearest_grid_points = nearest_grid_points(
+                self.in_grid["latitudes"], self.in_grid["longitudes"],
+                self.out_grid["latitudes"], self.out_grid["longitudes"],
+            )
+            self._plan = GatherPlan(len(self.in_grid["latitudes"]), len(self.nearest_grid_points), index=self.nearest_grid_points)
+        # R: regrid.py:377-378
+        n = int(np.prod(first_field.shape))
+        assert (n,) == np.shape(self.in_grid["latitudes"]), ((n,), np.shape(self.in_grid["latitudes"]))
+        assert (n,) == np.shape(self.in_grid["longitudes"]), ((n,), np.shape(self.in_grid["longitudes"]))
+        return self._plan
+
+    def out_latlon(self, first_field: Any):
+        return self.out_grid["latitudes"], self.out_grid["longitudes"]
+
+
+class MaskedRegrid(_Interpolator):
+    """Subset by an index list or a boolean mask (R: regrid.py:384-429), e.g. the output of
+    ``global_on_lam_mask`` (R: spatial.py:506-536)."""
+
+    out_latitudes = None
+    out_longitudes = None
+
+    def __init__(self, *, mask: Any, check: bool) -> None:
+        if check:
+            LOG.warning("Check is not supported by MaskedRegrid")
+        self.mask = np.load(mask)["mask"] if isinstance(mask, str) else np.asarray(mask)
+        self._plans: dict[int, GatherPlan] = {}
+
+    def plan_for(self, first_field: Any) -> GatherPlan:
+        n_src = int(np.prod(first_field.shape))
+        if n_src not in self._plans:
+            if self.mask.dtype == bool and self.mask.size != n_src:
+                raise IndexError(f"boolean index did not match indexed array: mask has {self.mask.size} points, field has {n_src}")
+            self._plans[n_src] = GatherPlan.from_mask(self.mask, n_src)
+        return self._plans[n_src]
+
+    def out_latlon(self, first_field: Any):
+        if self.out_latitudes is None or self.out_longitudes is None:  # cached from the first field (R: regrid.py:422-425)
+            lat, lon = first_field.grid_points()
+            self.out_latitudes = lat[self.mask]
+            self.out_longitudes = lon[self.mask]
+        return self.out_latitudes, self.out_longitudes
+
+
+def _interpolator(*, method: str | None = None, matrix: Any = None, mask: Any = None) -> str:
+    """R: regrid.py:432-467."""
+    if matrix is not None:
+        return "MIRMatrix"
+    if mask is not None:
+        return "MaskedRegrid"
+    if method == "nearest":
+        return "ScipyKDTreeNearestNeighbours"
+    return "EarthkitRegrid"
+
+
+def make_interpolator(in_grid=None, out_grid=None, method=None, matrix=None, mask=None, check=None) -> Any:
+    """R: regrid.py:470-516 — ``None`` arguments are dropped before the interpolator is built."""
+    name = _interpolator(method=method, matrix=matrix, mask=mask)
+    kwargs = dict(in_grid=in_grid, out_grid=out_grid, method=method, matrix=matrix, mask=mask, check=check)
+    kwargs = {k: v for k, v in kwargs.items() if v is not None}
+    return globals()[name](**kwargs)
+
+
+@filter_registry.register("regrid")
+class RegridFilter(Filter):
+    """Regrid every field of a FieldList to another grid.
+
+    ``shard=(rank, world)`` (extension) makes this process compute only its
+    contiguous slice of the target points: rows of the operator are independent, so
+    the per-rank outputs need no exchange.
+    """
+
+    def __init__(self, *, in_grid=None, out_grid=None, method=None, matrix=None, mask=None, check=False, shard=None) -> None:
+        self.in_grid = in_grid
+        self.out_grid = out_grid
+        self.method = method
+        self.shard = tuple(shard) if shard is not None else None
+        self.interpolator = make_interpolator(
+            in_grid=in_grid, out_grid=out_grid, method=method, matrix=matrix, mask=mask, check=check
+        )
+
+    def forward(self, data: Any) -> FieldList:
+        return self._interpolate(data)
+
+    def _interpolate(self, data: Any) -> FieldList:
+        return self.interpolator.regrid_fieldlist(data, shard=self.shard)

@@ -1,0 +1,159 @@
+"""Gather plans: host-validated index(+weight) tables and their device copies.
+
+One object for the three shapes of the reference's regrid operator
+(R: filters/fields/regrid.py):
+  * k = 1 index list      — ``data[..., nearest_grid_points]`` (:380), ``data[..., mask]`` (:420),
+                            ``data[self._mask]`` of remove_nans (remove_nans.py:113)
+  * fixed-k weights (ELL) — a CSR matrix whose rows all hold k entries (:310)
+  * general CSR           — any other MIR matrix (:310)
+
+Indices are validated on the host before anything is uploaded (the kernels trust
+them): every index must lie in ``[0, n_src)``; cKDTree's "no neighbour" marker
+``n_src`` (R: spatial.py:630-632) is rejected here.  Device copies are cached per
+(device, dtype).  ``shard(rank, world)`` cuts a contiguous slice of target points
+for the multi-GPU path: rows are independent, so no exchange is
+needed after the gather.
+"""
+
+from __future__ import annotations
+
+from typing import Any
+
+import numpy as np
+import torch
+
+from . import native
+from .stack import Stack
+
+
+class GatherPlan:
+    def __init__(
+        self,
+        n_src: int,
+        n_tgt: int,
+        *,
+        index: np.ndarray | None = None,  # [n_tgt] or [n_tgt, k]
+        weights: np.ndarray | None = None,  # [n_tgt, k] or None (pure gather)
+        csr: tuple[np.ndarray, np.ndarray, np.ndarray] | None = None,  # (data, indices, indptr)
+    ) -> None:
+        self.n_src = int(n_src)
+        self.n_tgt = int(n_tgt)
+        self._device: dict[tuple[str, torch.dtype], tuple[torch.Tensor, ...]] = {}
+        if csr is not None:
+            data, indices, indptr = csr
+            self.kind = "csr"
+            self.data = np.ascontiguousarray(data, dtype=np.float64)
+            self.indices = self._check(np.ascontiguousarray(indices))
+            self.indptr = np.ascontiguousarray(indptr, dtype=np.int64)
+            if len(self.indptr) != self.n_tgt + 1 or self.indptr[0] != 0 or self.indptr[-1] != len(self.indices):
+                raise ValueError("malformed CSR matrix: indptr does not match the shape / number of entries")
+            if np.any(np.diff(self.indptr) < 0):
+                raise ValueError("malformed CSR matrix: indptr is not non-decreasing")
+            if len(self.indices) >= 2**31:
+                raise NotImplementedError("matrices with 2^31 or more entries are not supported")
+            self.k = None
+        else:
+            index = np.asarray(index)
+            if index.ndim == 1:
+                index = index.reshape(-1, 1)
+            if index.shape[0] != self.n_tgt:
+                raise ValueError(f"index table has {index.shape[0]} rows for {self.n_tgt} target points")
+            self.kind = "ell"
+            self.k = int(index.shape[1])
+            self.index = self._check(np.ascontiguousarray(index))
+            self.weights = None if weights is None else np.ascontiguousarray(weights, dtype=np.float64).reshape(index.shape)
+            if self.weights is None and self.k != 1:
+                raise ValueError("a gather without weights needs exactly one index per target point")
+
+    # ---- construction helpers ----------------------------------------------------------
+    def _check(self, idx: np.ndarray) -> np.ndarray:
+        if idx.dtype.kind not in "iu":
+            raise ValueError(f"indices must be integers, got {idx.dtype}")
+        if idx.size and (idx.min() < 0 or idx.max() >= self.n_src):
+            raise ValueError(
+                f"gather index outside [0, {self.n_src}): min {idx.min()}, max {idx.max()} "
+                "(cKDTree reports len(source) when no neighbour lies within max_distance)"
+            )
+        if self.n_src >= 2**31:
+            raise NotImplementedError("grids with 2^31 or more points are not supported")
+        return idx.astype(np.int32)
+
+    @classmethod
+    def from_matrix(cls, matrix: dict[str, Any]) -> "GatherPlan":
+        """From the npz dict of a regrid matrix (R: regrid.py:281-285)."""
+        from .interp import csr_uniform_k
+
+        n_tgt, n_src = (int(s) for s in matrix["matrix_shape"])
+        data, indices, indptr = matrix["matrix_data"], matrix["matrix_indices"], matrix["matrix_indptr"]
+        k = csr_uniform_k(np.asarray(indptr))
+        if k is not None and k <= 64 and len(indptr) == n_tgt + 1:
+            return cls(n_src, n_tgt, index=np.asarray(indices).reshape(n_tgt, k), weights=np.asarray(data).reshape(n_tgt, k))
+        return cls(n_src, n_tgt, csr=(data, indices, indptr))
+
+    @classmethod
+    def from_mask(cls, mask: np.ndarray, n_src: int | None = None) -> "GatherPlan":
+        """From a boolean mask or an integer index list (R: regrid.py:402,420; spatial.py:533-536)."""
+        mask = np.asarray(mask)
+        if mask.dtype == bool:
+            n_src = mask.size if n_src is None else n_src
+            index = np.flatnonzero(mask.reshape(-1))
+        else:
+            if n_src is None:
+                raise ValueError("an integer mask needs the number of source points")
+            index = mask.reshape(-1)
+            index = np.where(index < 0, index + n_src, index)  # numpy indexing accepts negatives
+        return cls(n_src, len(index), index=index)
+
+    def shard(self, rank: int, world: int) -> "GatherPlan":
+        """The contiguous ``rank``-th of ``world`` slices of the target points."""
+        lo, hi = shard_bounds(self.n_tgt, rank, world)
+        if self.kind == "ell":
+            return GatherPlan(self.n_src, hi - lo, index=self.index[lo:hi],
+                              weights=None if self.weights is None else self.weights[lo:hi])
+        p0, p1 = int(self.indptr[lo]), int(self.indptr[hi])
+        return GatherPlan(self.n_src, hi - lo, csr=(self.data[p0:p1], self.indices[p0:p1], self.indptr[lo:hi + 1] - p0))
+
+    # ---- device side -------------------------------------------------------------------
+    def _tensors(self, device: torch.device, dtype: torch.dtype) -> tuple[torch.Tensor, ...]:
+        key = (str(device), dtype)
+        if key not in self._device:
+            np_dtype = np.float32 if dtype == torch.float32 else np.float64
+            if self.kind == "ell":
+                idx = torch.from_numpy(self.index.reshape(-1)).to(device)
+                w = None if self.weights is None else torch.from_numpy(self.weights.astype(np_dtype).reshape(-1)).to(device)
+                self._device[key] = (idx, w)
+            else:
+                self._device[key] = (
+                    torch.from_numpy(self.indptr.astype(np.int32)).to(device),
+                    torch.from_numpy(self.indices).to(device),
+                    torch.from_numpy(self.data.astype(np_dtype)).to(device),
+                )
+        return self._device[key]
+
+    def apply(self, src: Stack, *, prog: torch.Tensor | None = None, n_stage: int = 0,
+              tgt_mask: torch.Tensor | None = None) -> Stack:
+        """Run the gather over every level of ``src``; returns a new stack on the target points."""
+        # R: regrid.py:377-378 — the field must live on the plan's source grid
+        assert src.n_pts == self.n_src, (src.n_pts, self.n_src)
+        out = src.new_like(n_pts=self.n_tgt, zero=False)
+        if self.n_tgt == 0:
+            return out
+        if self.kind == "ell":
+            idx, w = self._tensors(src.device, src.dtype)
+            native.regrid_ell(
+                src.data, out.data, idx, w, n_src=self.n_src, n_tgt=self.n_tgt, k=self.k, n_lev=src.n_lev,
+                src_pitch=src.pitch, out_pitch=out.pitch, layout=src.layout, prog=prog, n_stage=n_stage, tgt_mask=tgt_mask,
+            )
+        else:
+            indptr, indices, data = self._tensors(src.device, src.dtype)
+            native.regrid_csr(
+                src.data, out.data, indptr, indices, data, n_src=self.n_src, n_tgt=self.n_tgt, nnz=len(self.indices),
+                n_lev=src.n_lev, src_pitch=src.pitch, out_pitch=out.pitch, layout=src.layout, prog=prog, n_stage=n_stage,
+                tgt_mask=tgt_mask,
+            )
+        return out
+
+
+def shard_bounds(n: int, rank: int, world: int) -> tuple[int, int]:
+    """Balanced contiguous partition of ``range(n)`` into ``world`` slices."""
+    return (n * rank) // world, (n * (rank + 1)) // world

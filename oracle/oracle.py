@@ -262,11 +262,11 @@ def filter_remove_nans(fields: list[dict], *, param: str | None = None) -> list[
     return out
 
 
-def _map_selected(fields, param, fn, **new_metadata):
+def _map_selected(fields, selected_param, fn, **new_metadata):
     # R: filter.py:188-196: unselected fields pass through by identity
     out = []
     for f in fields:
-        if _selected(f, param):
+        if _selected(f, selected_param):
             g = dict(f)
             g["values"] = fn(np.asarray(f["values"]))
             g.update({k: v for k, v in new_metadata.items()})

@@ -1,0 +1,159 @@
+"""Test double for ``anemoi_transform_amd.native`` — TEST INFRASTRUCTURE.
+
+The product has exactly one compute path (libatx on HBM tensors).  To exercise the
+HOST logic (registry, field plumbing, selection, metadata, grouping into stacks,
+sharding) on the GPU-less build box, the CPU tests monkeypatch the tensor-level
+wrappers of ``native`` with these functions, which evaluate the same contracts on
+CPU tensors with the oracle's numpy / scipy statements.  Nothing in the package
+imports this module.
+"""
+
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from anemoi_transform_amd import native
+from oracle import oracle
+
+COLUMNS, FIELDS = native.COLUMNS, native.FIELDS
+
+
+def _levels(t: torch.Tensor, n_pts: int, n_lev: int, layout: int) -> np.ndarray:
+    """Writable [n_lev, n_pts] numpy view of a stack tensor."""
+    a = t.numpy()
+    return a[:n_pts, :n_lev].T if layout == COLUMNS else a[:n_lev, :n_pts]
+
+
+def _parse_prog(prog: torch.Tensor, n_stage: int, n_lev: int) -> np.ndarray:
+    return prog.numpy().view(native.LEVEL_OP_DTYPE).reshape(n_stage, n_lev)
+
+
+def _apply_op(entry, x: np.ndarray, mask: np.ndarray | None) -> np.ndarray:
+    op, use_mask = int(entry["op"]), int(entry["use_mask"])
+    p0, p1 = x.dtype.type(entry["p0"]), x.dtype.type(entry["p1"])
+    if op == native.OP_COPY:
+        y = x.copy()
+    elif op == native.OP_AFFINE:
+        y = oracle.rescale_forward(x, p0, p1)
+    elif op == native.OP_AFFINE_INV:
+        y = oracle.rescale_backward(x, p0, p1)
+    elif op == native.OP_MUL:
+        y = x * p0
+    elif op == native.OP_DIV:
+        y = x / p0
+    elif op == native.OP_CLIP:
+        y = oracle.clip(x, None if np.isnan(p0) else p0, None if np.isnan(p1) else p1)
+    elif op == native.OP_IMPUTE_NAN:
+        y = oracle.impute_nans(x, p0)
+    elif op == native.OP_EXP:
+        y = oracle.lnsp_to_sp(x)
+    elif op == native.OP_LOG:
+        y = oracle.sp_to_lnsp(x)
+    elif op == native.OP_SET_NAN:
+        y = np.full_like(x, np.nan)
+    else:
+        raise ValueError(op)
+    if use_mask:
+        assert mask is not None
+        y = oracle.apply_mask_values(y, mask)
+    return y
+
+
+def _epilogue(levels: np.ndarray, prog, n_stage, mask, n_lev):
+    if prog is None:
+        return
+    table = _parse_prog(prog, n_stage, n_lev)
+    m = None if mask is None else mask.numpy()[: levels.shape[1]].astype(bool)
+    for s in range(n_stage):
+        for l in range(n_lev):
+            levels[l] = _apply_op(table[s, l], levels[l].copy(), m)
+
+
+def regrid_ell(src, out, idx, w, *, n_src, n_tgt, k, n_lev, src_pitch, out_pitch, layout, prog=None, n_stage=0, tgt_mask=None):
+    x = _levels(src, n_src, n_lev, layout)
+    y = _levels(out, n_tgt, n_lev, layout)
+    index = idx.numpy().reshape(n_tgt, k)
+    if w is None:
+        assert k == 1
+        for l in range(n_lev):
+            y[l] = oracle.gather_nn(x[l], index[:, 0])
+    else:
+        weights = w.numpy().reshape(-1)
+        indptr = np.arange(n_tgt + 1) * k
+        for l in range(n_lev):
+            y[l] = oracle.csr_apply(weights, index.reshape(-1), indptr, (n_tgt, n_src), np.ascontiguousarray(x[l]))
+    _epilogue(y, prog, n_stage, tgt_mask, n_lev)
+
+
+def regrid_csr(src, out, indptr, indices, data, *, n_src, n_tgt, nnz, n_lev, src_pitch, out_pitch, layout, prog=None,
+               n_stage=0, tgt_mask=None):
+    x = _levels(src, n_src, n_lev, layout)
+    y = _levels(out, n_tgt, n_lev, layout)
+    for l in range(n_lev):
+        y[l] = oracle.csr_apply(data.numpy(), indices.numpy(), indptr.numpy(), (n_tgt, n_src), np.ascontiguousarray(x[l]))
+    _epilogue(y, prog, n_stage, tgt_mask, n_lev)
+
+
+def check_indices(idx, n_src):
+    a = idx.numpy()
+    return int(((a < 0) | (a >= n_src)).sum())
+
+
+def pointwise_stack(x, y, *, n_pts, n_lev, x_pitch, y_pitch, layout, prog, n_stage, point_mask=None):
+    xs = _levels(x, n_pts, n_lev, layout)
+    ys = _levels(y, n_pts, n_lev, layout)
+    ys[...] = xs
+    _epilogue(ys, prog, n_stage, point_mask, n_lev)
+
+
+_CMP = {
+    native.CMP_GT: ">", native.CMP_LT: "<", native.CMP_EQ: "==", native.CMP_NE: "!=", native.CMP_GE: ">=", native.CMP_LE: "<=",
+}
+
+
+def mask_build(m, mask, *, n, stride=1, cmp, threshold=0.0):
+    values = m.numpy().reshape(-1)[: n]  # `m` is already the strided view of one level
+    if cmp == native.CMP_NOTNAN:
+        res = oracle.not_nan_mask(values)
+    elif cmp == native.CMP_ISNAN:
+        res = ~oracle.not_nan_mask(values)
+    else:
+        res = oracle.compute_mask(values, threshold=values.dtype.type(threshold), threshold_operator=_CMP[cmp])
+    mask.numpy()[:n] = res.astype(np.uint8)
+
+
+def mask_count(mask, n=None):
+    n = mask.numel() if n is None else n
+    return int((mask.numpy()[:n] != 0).sum())
+
+
+def mask_to_index(mask, n=None):
+    n = mask.numel() if n is None else n
+    return torch.from_numpy(np.flatnonzero(mask.numpy()[:n]).astype(np.int32))
+
+
+def reduce(x, red, n=None):
+    a = x.numpy().reshape(-1)[: (x.numel() if n is None else n)]
+    if red == native.RED_MIN:
+        return float(a.min())
+    if red == native.RED_MAX:
+        return float(a.max())
+    return float(np.isnan(a).sum())
+
+
+def relayout(src, dst, *, n_pts, n_lev, src_pitch, dst_pitch, src_layout, dst_layout):
+    _levels(dst, n_pts, n_lev, dst_layout)[...] = _levels(src, n_pts, n_lev, src_layout)
+
+
+PATCHED = ["regrid_ell", "regrid_csr", "check_indices", "pointwise_stack", "mask_build", "mask_count", "mask_to_index",
+           "reduce", "relayout"]
+
+
+def install(monkeypatch) -> None:
+    """Route the package's native wrappers and its device choice to this double."""
+    from anemoi_transform_amd import stack
+
+    for name in PATCHED:
+        monkeypatch.setattr(native, name, globals()[name])
+    monkeypatch.setattr(stack, "device", lambda: torch.device("cpu"))

@@ -1,0 +1,100 @@
+"""The N > 1 path with world_size 2 on the CPU (gloo): target-point sharding, one source
+broadcast, optional gather of the shards.  Kernels are the oracle-backed double
+(tests/native_double.py); what is under test is the sharding / communication logic that
+bench.py and the driver's multi-GPU run rely on.
+"""
+
+from __future__ import annotations
+
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port() -> int:
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+class _Patch:
+    """Minimal monkeypatch stand-in for spawned workers."""
+
+    def setattr(self, obj, name, value):
+        setattr(obj, name, value)
+
+
+def _worker(rank: int, world: int, port: int, kind: str, tmpdir: str) -> None:
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import __graft_entry__ as graft
+
+    graft.load_package()
+    import torch.distributed as dist
+
+    import native_double
+    from anemoi_transform_amd import distributed as atxd
+    from anemoi_transform_amd import interp
+    from anemoi_transform_amd.gather import GatherPlan
+    from anemoi_transform_amd.grids import lookup
+    from anemoi_transform_amd.stack import Stack
+    from oracle import oracle
+
+    native_double.install(_Patch())
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    assert atxd.init_process_group("gloo") == (rank, world)
+
+    src_grid, tgt_grid = lookup("o16"), lookup([10.0, 10.0])
+    n_src, n_tgt, n_lev = len(src_grid["latitudes"]), len(tgt_grid["latitudes"]), 3
+    idx, w = interp.knn_inverse_distance(src_grid, tgt_grid, k=4)
+    if kind == "ell":
+        plan = GatherPlan(n_src, n_tgt, index=idx, weights=w)
+        indptr = np.arange(n_tgt + 1) * 4
+        data, indices = w.reshape(-1), idx.reshape(-1)
+    else:
+        keep = (np.arange(idx.size) % 7 != 0).reshape(idx.shape)
+        indptr = np.concatenate([[0], np.cumsum(keep.sum(axis=1))])
+        data, indices = w[keep], idx[keep]
+        plan = GatherPlan(n_src, n_tgt, csr=(data, indices, indptr))
+
+    rng = np.random.default_rng(100 + rank)  # every rank owns a different source stack
+    mine_host = 280.0 + rng.standard_normal((n_lev, n_src))
+    mine = Stack.from_fields(mine_host, dev=torch.device("cpu"))
+
+    # 1. sources exchanged once, then every rank interpolates its target slice of every stack
+    stacks = atxd.exchange_stacks(mine)
+    assert len(stacks) == world
+    for r, st in enumerate(stacks):
+        expect = 280.0 + np.random.default_rng(100 + r).standard_normal((n_lev, n_src))
+        assert np.array_equal(st.numpy(), expect)
+        local = atxd.sharded_regrid(plan, st)
+        full = atxd.gather_target_shards(local, n_tgt)
+        want = np.stack([oracle.csr_apply(data, indices, indptr, (n_tgt, n_src), f) for f in expect])
+        assert np.array_equal(full.numpy(), want), f"rank {rank} stack {r}"
+
+    # 2. feeding a rank only the band of source columns its slice references gives the same rows
+    shard = plan.shard(rank, world)
+    lo, hi = atxd.source_band(shard)
+    band = Stack.from_fields(mine_host[:, lo:hi], dev=torch.device("cpu"))
+    got = atxd.rebase_plan(shard, lo, hi).apply(band).numpy()
+    assert np.array_equal(got, shard.apply(mine).numpy())
+    assert hi - lo < n_src  # a latitude band, not the whole grid
+
+    dist.barrier()
+    with open(os.path.join(tmpdir, f"ok{rank}"), "w") as f:
+        f.write("ok")
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("kind", ["ell", "csr"])
+def test_target_sharded_regrid_world2(tmp_path, kind):
+    world = 2
+    mp.spawn(_worker, args=(world, _free_port(), kind, str(tmp_path)), nprocs=world, join=True)
+    assert all((tmp_path / f"ok{r}").exists() for r in range(world))

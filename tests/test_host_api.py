@@ -1,0 +1,430 @@
+"""Host-side contract tests (no GPU): grids, registry, Transform / Filter bases, fields, C ABI exports.
+
+Modelled on the offline parts of R: tests/test_filter.py, test_dispatchingfilter.py,
+test_fields.py, test_create.py, test_grids.py.
+"""
+
+from __future__ import annotations
+
+import ctypes
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+
+from anemoi_transform_amd import grids, interp, native
+from anemoi_transform_amd.core import (
+    DispatchingFilter,
+    Pipeline,
+    Registry,
+    ReversedTransform,
+    SingleFieldFilter,
+    Transform,
+)
+from anemoi_transform_amd.fields import (
+    ArrayField,
+    FieldList,
+    FieldSelection,
+    fieldlist_from_dicts,
+    new_field_from_latitudes_longitudes,
+    new_field_from_numpy,
+)
+from anemoi_transform_amd.gather import GatherPlan, shard_bounds
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLDEN = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "reference_vectors.json")))
+
+
+# ---- grids -------------------------------------------------------------------------------
+def test_lookup_o96_known_answers():
+    """R: tests/test_grids.py:50-58."""
+    g = GOLDEN["grid_o96"]
+    x = grids.lookup("o96")
+    assert x["latitudes"].shape == (g["n_points"],) == x["longitudes"].shape
+    assert x["latitudes"].mean() == pytest.approx(g["mean_latitude"], abs=1e-9)
+    assert x["longitudes"].mean() == pytest.approx(g["mean_longitude"])
+    assert x["latitudes"][g["index"]] == pytest.approx(g["latitude_at_index"])
+    assert x["longitudes"][g["index"]] == pytest.approx(g["longitude_at_index"])
+
+
+@pytest.mark.parametrize("name,n", [("o32", 5248), ("O96", 40320), ("o1280", 6599680), ("f48", 96 * 192)])
+def test_gaussian_grid_sizes(name, n):
+    g = grids.lookup(name)
+    assert len(g["latitudes"]) == n == len(g["longitudes"])
+    assert np.all(np.diff(g["latitudes"]) <= 0)  # north to south
+    assert g["longitudes"].min() == 0.0 and g["longitudes"].max() < 360.0
+
+
+def test_latlon_grids_and_npz(tmp_path):
+    g = grids.lookup([0.25, 0.25])
+    assert len(g["latitudes"]) == 721 * 1440
+    assert g["latitudes"][0] == 90.0 and g["latitudes"][-1] == -90.0 and g["longitudes"][1] == 0.25
+    assert len(grids.lookup("1.0")["latitudes"]) == 181 * 360
+    assert len(grids.lookup("5/2.5")["latitudes"]) == 37 * 144
+    path = str(tmp_path / "grid.npz")
+    np.savez(path, latitudes=g["latitudes"][:10], longitudes=g["longitudes"][:10])
+    assert np.array_equal(grids.lookup(path)["longitudes"], g["longitudes"][:10])
+    with pytest.raises(ValueError):
+        grids.lookup("n320")  # classic reduced grids need the downloaded table (out of scope)
+
+
+def test_gaussian_latitudes_are_legendre_roots():
+    lats = grids.gaussian_latitudes(64)
+    x = np.sin(np.deg2rad(lats))
+    p = np.polynomial.legendre.Legendre.basis(64)(x)
+    assert np.max(np.abs(p)) < 1e-12
+
+
+# ---- precompute -------------------------------------------------------------------------
+def test_bilinear_weights_rows_sum_to_one_and_bracket():
+    tgt = grids.lookup([10.0, 10.0])
+    m = interp.bilinear_octahedral(16, tgt)
+    w = m["matrix_data"].reshape(-1, 4)
+    assert np.allclose(w.sum(axis=1), 1.0) and w.min() >= 0.0
+    assert interp.csr_uniform_k(m["matrix_indptr"]) == 4
+    src = grids.lookup("o16")
+    idx = m["matrix_indices"].reshape(-1, 4)
+    # the four corners lie on at most two latitude rows around the target latitude
+    for t in (0, 100, len(tgt["latitudes"]) - 1):
+        rows = np.unique(src["latitudes"][idx[t]])
+        assert len(rows) <= 2
+        if len(rows) == 2:
+            assert rows.min() <= tgt["latitudes"][t] <= rows.max()
+
+
+def test_knn_weights_and_matrix_file(tmp_path):
+    src, tgt = grids.lookup("o16"), grids.lookup([20.0, 20.0])
+    idx, w = interp.knn_inverse_distance(src, tgt, k=4)
+    assert idx.shape == w.shape == (len(tgt["latitudes"]), 4)
+    assert np.allclose(w.sum(axis=1), 1.0)
+    m = interp.ell_to_csr(idx, w, len(src["latitudes"]))
+    path = str(tmp_path / "m.npz")
+    interp.save_matrix_npz(path, m, src, tgt)
+    loaded = interp.load_matrix_npz(path)
+    # the npz keys the reference reads (R: filters/fields/regrid.py:281-290)
+    assert set(loaded) == {"matrix_data", "matrix_indices", "matrix_indptr", "matrix_shape", "in_latitudes", "in_longitudes",
+                           "out_latitudes", "out_longitudes"}
+    assert loaded["matrix_indices"].dtype == np.int32 and loaded["matrix_indptr"].dtype == np.int32
+    assert tuple(loaded["matrix_shape"]) == (len(tgt["latitudes"]), len(src["latitudes"]))
+
+
+def test_gather_plan_validation_and_sharding():
+    with pytest.raises(ValueError, match="outside"):
+        GatherPlan(10, 3, index=np.array([0, 10, 2]))  # cKDTree's "no neighbour" marker is rejected
+    with pytest.raises(ValueError):
+        GatherPlan(10, 3, index=np.array([[0, 1], [2, 3], [4, 5]]))  # k = 2 without weights
+    plan = GatherPlan(10, 7, index=np.arange(14).reshape(7, 2) % 10, weights=np.ones((7, 2)) / 2)
+    parts = [plan.shard(r, 3) for r in range(3)]
+    assert sum(p.n_tgt for p in parts) == 7
+    assert np.array_equal(np.concatenate([p.index for p in parts]), plan.index)
+    csr = GatherPlan(10, 3, csr=(np.ones(5), np.array([1, 2, 3, 4, 5]), np.array([0, 2, 2, 5])))
+    s = csr.shard(1, 2)
+    assert s.n_tgt == 2 and np.array_equal(s.indptr, [0, 0, 3]) and np.array_equal(s.indices, [3, 4, 5])
+    assert [shard_bounds(10, r, 4) for r in range(4)] == [(0, 2), (2, 5), (5, 7), (7, 10)]
+    m = GatherPlan.from_mask(np.array([True, False, True, True]))
+    assert m.k == 1 and np.array_equal(m.index[:, 0], [0, 2, 3])
+
+
+# ---- registry ------------------------------------------------------------------------------
+def test_registry_surface():
+    reg = Registry("pkg")
+
+    @reg.register("alpha")
+    class Alpha:
+        def __init__(self, x=1):
+            self.x = x
+
+    reg.register("beta", lambda **kw: ("beta", kw), aliases=["b", "be-ta"])
+    assert reg.registered == ["alpha", "beta"]
+    assert reg.aliases() == {"beta": ["b", "be_ta"]}
+    assert set(reg.factories) == {"alpha", "beta"}
+    assert reg.create("alpha", x=3).x == 3
+    assert reg.create("b", y=1) == ("beta", {"y": 1})
+    assert reg.from_config("alpha").x == 1
+    assert reg.from_config({"alpha": {"x": 5}}).x == 5
+    assert reg.from_config({"be-ta": None}) == ("beta", {})
+    assert reg.lookup("nope", return_none=True) is None
+    with pytest.raises(ValueError):
+        reg.create("nope")
+    with pytest.raises(AssertionError):  # R: filters/__init__.py:30-33 relies on this
+        reg.register("alpha", Alpha)
+    with pytest.raises(AssertionError):
+        reg.register("gamma", Alpha, aliases=["b"])
+    with pytest.raises(ValueError):
+        reg.from_config({"a": 1, "b": 2})
+
+
+# ---- Transform / SingleFieldFilter / DispatchingFilter contracts ----------------------------------
+def test_singlefieldfilter_contract():
+    """R: tests/test_filter.py:22-105 (the offline part)."""
+    with pytest.raises(TypeError, match="abstract method"):
+        SingleFieldFilter()
+
+    class BadRequired(SingleFieldFilter):
+        required_inputs = "string_not_allowed"
+
+        def forward_transform(self, field):
+            pass
+
+    with pytest.raises(TypeError, match="Required inputs must be a list or tuple"):
+        BadRequired()
+
+    class Foo(SingleFieldFilter):
+        required_inputs = ("foo",)
+
+        def forward_transform(self, field):
+            pass
+
+    with pytest.raises(ValueError, match=r"Unknown input\(s\)"):
+        Foo(foo="bar", baz="qux")
+    with pytest.raises(TypeError, match="Missing required input"):
+        Foo()
+
+    class Opt(SingleFieldFilter):
+        optional_inputs = {"temperature": "2t"}
+
+        def forward_transform(self, field):
+            pass
+
+    assert Opt().temperature == "2t"
+    assert Opt(temperature="temperature").temperature == "temperature"
+    with pytest.raises(AttributeError):
+        Opt().missing
+
+    class Prep(SingleFieldFilter):
+        required_inputs = ("positive_number",)
+
+        def prepare_filter(self):
+            if self.positive_number < 0:
+                raise ValueError("positive_number must be positive")
+
+        def forward_transform(self, field):
+            pass
+
+    with pytest.raises(ValueError, match="positive_number must be positive"):
+        Prep(positive_number=-1)
+
+
+SPECS = [
+    {"param": "t", "levelist": 500, "values": np.arange(6.0).reshape(3, 2), "latitudes": [10.0, 0.0, -10.0], "longitudes": [20.0, 40.0]},
+    {"param": "q", "levelist": 850, "values": np.arange(6.0).reshape(3, 2) * 2, "latitudes": [10.0, 0.0, -10.0], "longitudes": [20.0, 40.0]},
+]
+
+
+def test_user_defined_singlefieldfilter_runs_on_host_arrays():
+    """A filter written against the reference API (numpy in forward_transform) works unchanged
+    (R: tests/test_filter.py:108-170)."""
+
+    class PlusOne(SingleFieldFilter):
+        optional_inputs = {"param": "t"}
+
+        def forward_select(self):
+            return {"param": self.param}
+
+        def forward_transform(self, field):
+            return self.new_field_from_numpy(field.to_numpy() + 1, template=field)
+
+        def backward_transform(self, field):
+            return self.new_field_from_numpy(field.to_numpy() - 1, template=field)
+
+    fl = fieldlist_from_dicts(SPECS)
+    out = PlusOne()(fl)
+    assert np.array_equal(out[0].to_numpy(), SPECS[0]["values"] + 1)
+    assert out[1] is fl[1]
+    back = PlusOne().reverse()(out)
+    assert np.array_equal(back[0].to_numpy(), SPECS[0]["values"])
+    rev = PlusOne.reversed(param="q")
+    assert isinstance(rev, ReversedTransform)
+    assert np.array_equal(rev(fl)[1].to_numpy(), SPECS[1]["values"] - 1)
+
+    class ForwardOnly(SingleFieldFilter):
+        def forward_transform(self, field):
+            return field
+
+    with pytest.raises(NotImplementedError, match="Field backward transform not implemented"):
+        ForwardOnly.reversed()(fl)
+
+
+def test_pipeline_and_reverse():
+    class Add(Transform):
+        def __init__(self, k):
+            self.k = k
+
+        def forward(self, data):
+            return data + self.k
+
+        def backward(self, data):
+            return data - self.k
+
+    class Mul(Transform):
+        def forward(self, data):
+            return data * 2
+
+    p = Add(1) | Add(10)
+    assert isinstance(p, Pipeline) and p(0) == 11 and p.backward(11) == 0
+    q = p | Mul()  # nested two-element pipelines (R: transform.py:116-131)
+    assert isinstance(q.filters[0], Pipeline) and q(0) == 22
+    with pytest.raises(NotImplementedError, match="is not reversible"):
+        q.backward(1)
+    assert repr(Add(1).reverse()).startswith("Reversed(")
+    assert Add(1).patch_data_request({"a": 1}) == {"a": 1}
+
+
+def test_dispatching_filter_contract():
+    """R: tests/test_dispatchingfilter.py:44-166."""
+    import pandas as pd
+
+    with pytest.raises(TypeError, match="must override at least one"):
+
+        class Nothing(DispatchingFilter):
+            pass
+
+    with pytest.raises(TypeError, match="overrides `backward_fields` but not `forward_fields`"):
+
+        class BackOnly(DispatchingFilter):
+            def forward_tabular(self, data):
+                return data
+
+            def backward_fields(self, data):
+                return data
+
+    class Both(DispatchingFilter):
+        def forward_fields(self, data):
+            return "fields"
+
+        def forward_tabular(self, data):
+            return "tabular"
+
+        def backward_fields(self, data):
+            return "back"
+
+    f = Both()
+    assert f.forward(FieldList([])) == "fields"
+    assert f.forward(pd.DataFrame()) == "tabular"
+    assert f.backward(FieldList([])) == "back"
+    with pytest.raises(TypeError, match="No forward method"):
+        f.forward([1, 2])
+    with pytest.raises(NotImplementedError, match="No backward method"):
+        f.backward(pd.DataFrame())
+    with pytest.raises(NotImplementedError):
+        f.backward(3)
+
+
+# ---- fields -----------------------------------------------------------------------------------
+def test_array_field_from_dict_is_latitude_major():
+    """R: tests/field_filters/test_remove_nans.py:17-45 — flattened order and meshgridded coordinates."""
+    f = ArrayField.from_dict(SPECS[0])
+    assert f.shape == (3, 2)
+    assert np.array_equal(f.to_numpy(flatten=True), np.arange(6.0))
+    lat, lon = f.grid_points()
+    assert np.array_equal(lat, [10, 10, 0, 0, -10, -10]) and np.array_equal(lon, [20, 40, 20, 40, 20, 40])
+    assert f.metadata("param") == "t" and f.metadata("param", "levelist") == ("t", 500)
+    with pytest.raises(KeyError):
+        f.metadata("nope")
+    assert f.metadata("nope", default=None) is None
+    assert f.metadata(namespace="mars") == {"param": "t", "levelist": 500}
+    assert f.to_numpy(dtype=np.float32).dtype == np.float32
+    assert f.to_numpy(flatten=True, index=[0, 5]).tolist() == [0.0, 5.0]
+    assert np.array_equal(f.values, np.arange(6.0))
+    assert f.to_numpy() is not f.to_numpy()  # always a copy (R: fields.py:198-199)
+    with pytest.raises(NotImplementedError):
+        iter(f)
+
+
+def test_derived_field_metadata_semantics():
+    """R: fields.py:468-568."""
+    f = ArrayField.from_dict(SPECS[0])
+    g = new_field_from_numpy(np.ones(6), template=f, param="x", level=None, units=lambda field, key, md: "K")
+    assert g.shape == (6,) and g.metadata("param") == "x" and g.metadata("levelist") == 500
+    assert g.metadata("level") is None  # an override to None is a value, not "missing"
+    assert g.metadata("units") == "K"  # callable overrides are invoked
+    md = g.metadata()
+    assert md.get("param") == "x" and md["levelist"] == 500 and md.get("zzz", 7) == 7
+    assert set(md.keys()) == set(f.metadata().keys())  # template's keys only (R: fields.py:508-509)
+    assert g.metadata(namespace="mars") == {"param": "x", "levelist": 500}  # overrides only for present keys
+    h = new_field_from_latitudes_longitudes(g, np.array([1.0, 2.0]), np.array([3.0, 4.0]))
+    assert h.grid_points()[0].tolist() == [1.0, 2.0] and h.to_latlon()["lon"].tolist() == [3.0, 4.0]
+    geo = h.metadata().geography
+    assert geo.shape() == (2,) and geo.mars_area() == [2.0, 3.0, 1.0, 4.0] and geo.resolution() == "unknown"
+    assert h.metadata("param") == "x"
+    c = f.clone(param="y")
+    assert c.metadata("param") == "y" and np.array_equal(c.to_numpy(), f.to_numpy())
+
+
+def test_field_selection():
+    """R: tests/test_fields.py:68-134, fields.py:767-797."""
+    f = ArrayField.from_dict(SPECS[0])
+    assert FieldSelection().match(f)
+    assert FieldSelection(param="t").match(f) and not FieldSelection(param="q").match(f)
+    assert FieldSelection(param=["q", "t"], levelist=500).match(f)
+    assert not FieldSelection(param="t", levelist=[850]).match(f)
+    assert FieldSelection(param=None, levelist=[]).match(f)
+    g = ArrayField.from_dict({k: v for k, v in SPECS[0].items() if k != "levelist"})
+    assert not FieldSelection(levelist=500).match(g)  # KeyError -> False
+    with pytest.raises(ValueError, match="Invalid keys"):
+        FieldSelection(step=1)
+    with pytest.raises(ValueError, match="Invalid value"):
+        FieldSelection(param={"a": 1})
+
+
+def test_fieldlist_surface():
+    fl = fieldlist_from_dicts(SPECS)
+    assert len(fl) == 2 and fl[1].metadata("param") == "q" and isinstance(fl[0:1], FieldList)
+    assert fl.metadata("param") == ["t", "q"]
+    assert len(fl.sel(param="q")) == 1 and len(fl.sel(param=["t", "q"], levelist=500)) == 1
+    assert fl.to_numpy(flatten=True).shape == (2, 6)
+    fl.append(fl[0])
+    assert len(fl) == 3
+
+
+# ---- C ABI ------------------------------------------------------------------------------------
+def header_symbols():
+    text = open(os.path.join(ROOT, "include", "atx.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(atx_[a-z_0-9]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    declared = header_symbols()
+    assert len(declared) >= 15
+    handle = ctypes.CDLL(native.lib_path())
+    for name in declared:
+        assert hasattr(handle, name), f"{name} declared in include/atx.h but not exported"
+    assert set(declared) == set(native.SIGNATURES), "native.py must bind exactly the header's entry points"
+
+
+def test_abi_argument_validation_without_a_gpu():
+    """Bad arguments are rejected before anything touches HIP, with the reference's exception types."""
+    lib = native.load()
+    assert lib.atx_version() == 100
+    assert lib.atx_strerror(native.ESHAPE) == b"shape mismatch"
+    assert lib.atx_regrid_ell(None, None, None, None, 1, 1, 1, 1, 1, 1, 0, 0, None, 0, None, None) == native.EINVAL
+    assert b"null" in lib.atx_last_error()
+    one = ctypes.c_void_p(16)  # never dereferenced: validation fails first
+    assert lib.atx_regrid_ell(one, one, one, None, 8, 8, 1, 4, 2, 4, 0, 0, None, 0, None, None) == native.ESHAPE
+    assert lib.atx_regrid_ell(one, one, one, None, 8, 8, 3, 4, 4, 4, 0, 0, None, 0, None, None) == native.EINVAL
+    assert lib.atx_regrid_ell(one, one, one, one, 8, 8, 99, 4, 4, 4, 0, 0, None, 0, None, None) == native.EINVAL
+    assert lib.atx_regrid_ell(one, one, one, None, 8, 8, 1, 4, 4, 4, 7, 0, None, 0, None, None) == native.EINVAL
+    assert lib.atx_pointwise_stack(one, one, 8, 4, 4, 4, 0, 0, one, 0, None, None) == native.EINVAL
+    assert lib.atx_mask_build(one, 1, one, 8, 99, 0.0, 0, None) == native.EINVAL
+    assert lib.atx_relayout(one, one, 8, 4, 4, 8, 0, 1, 0, None) == native.EINVAL  # in place
+    assert lib.atx_mask_to_index_workspace(4096 * 3) >= 16
+    with pytest.raises(RuntimeError, match="HBM-resident"):
+        import torch
+
+        native.regrid_ell(torch.zeros(4, 4), torch.zeros(4, 4), torch.zeros(4, dtype=torch.int32), None, n_src=4, n_tgt=4, k=1,
+                          n_lev=4, src_pitch=4, out_pitch=4, layout=native.COLUMNS)
+
+
+def test_level_program_layout_matches_the_c_struct():
+    import torch
+
+    prog = native.level_program([[(native.OP_AFFINE, 0, 2.0, 1.0), (native.OP_COPY, 1, 0.0, 0.0)]], torch.device("cpu"))
+    assert prog.numel() == 2 * 24 and native.LEVEL_OP_DTYPE.itemsize == 24
+    raw = prog.numpy().tobytes()
+    import struct
+
+    assert struct.unpack("<iidd", raw[:24]) == (native.OP_AFFINE, 0, 2.0, 1.0)
+    assert struct.unpack("<iidd", raw[24:]) == (native.OP_COPY, 1, 0.0, 0.0)
