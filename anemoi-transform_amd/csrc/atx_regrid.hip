@@ -21,7 +21,60 @@
 
 namespace atx {
 
-constexpr int kUnroll = 4;  // items in flight per lane (columns kernels)
+#ifndef ATX_UNROLL
+#define ATX_UNROLL 4
+#endif
+#ifndef ATX_NT_STORE
+#define ATX_NT_STORE 1
+#endif
+#ifndef ATX_NT_IDX
+#define ATX_NT_IDX 1
+#endif
+#ifndef ATX_NT_SRC
+#define ATX_NT_SRC 0
+#endif
+#ifndef ATX_NO_XCD
+#define ATX_NO_XCD 0
+#endif
+constexpr int kUnroll = ATX_UNROLL;  // items in flight per lane (columns kernels)
+
+template <typename T, int N>
+struct NativeVec {
+    typedef T type __attribute__((ext_vector_type(N)));
+};
+template <typename T>
+struct NativeVec<T, 1> {
+    typedef T type;
+};
+
+template <typename T, int N>
+__device__ __forceinline__ void store_out(Pack<T, N>* p, const Pack<T, N>& v) {
+#if ATX_NT_STORE
+    // output is written once and never re-read by this launch
+    using NV = typename NativeVec<T, N>::type;
+    __builtin_nontemporal_store(*reinterpret_cast<const NV*>(&v), reinterpret_cast<NV*>(p));
+#else
+    *p = v;
+#endif
+}
+template <typename T, int N>
+__device__ __forceinline__ Pack<T, N> load_src(const T* p) {
+#if ATX_NT_SRC
+    using NV = typename NativeVec<T, N>::type;
+    NV v = __builtin_nontemporal_load(reinterpret_cast<const NV*>(p));
+    return *reinterpret_cast<Pack<T, N>*>(&v);
+#else
+    return *reinterpret_cast<const Pack<T, N>*>(p);
+#endif
+}
+template <typename T>
+__device__ __forceinline__ T load_once(const T* p) {
+#if ATX_NT_IDX
+    return __builtin_nontemporal_load(p);
+#else
+    return *p;
+#endif
+}
 
 // ---------------------------------------------------------------------------------
 // ATX_COLUMNS, fixed k (ELL).  K > 0: compile-time k; K == 0: runtime k.
@@ -43,14 +96,18 @@ regrid_cols_ell_kernel(const T* __restrict__ src, T* __restrict__ out,
     LevelOp<T>* prog_s = reinterpret_cast<LevelOp<T>*>(
         smem + (((WEIGHTED ? (size_t)tile * k * sizeof(T) : 0) + (size_t)tile * k * sizeof(int32_t) + 15) & ~size_t(15)));
 
+#if ATX_NO_XCD
+    const unsigned tile_id = blockIdx.x;
+#else
     const unsigned tile_id = xcd_tile(blockIdx.x, n_tiles);
+#endif
     const int64_t t0 = (int64_t)tile_id * tile;
     const int nt = (int)min((int64_t)tile, n_tgt - t0);
     const int tid = threadIdx.x;
 
     for (int i = tid; i < nt * k; i += kBlock) {
-        idx_s[i] = idx[t0 * k + i];
-        if (WEIGHTED) w_s[i] = w[t0 * k + i];
+        idx_s[i] = load_once(idx + t0 * k + i);
+        if (WEIGHTED) w_s[i] = load_once(w + t0 * k + i);
     }
     if (EPI) {
         const int n_slots = C * VEC;
@@ -95,7 +152,7 @@ regrid_cols_ell_kernel(const T* __restrict__ src, T* __restrict__ out,
 #pragma unroll
                 for (int j = 0; j < (K > 0 ? K : 1); ++j) {
                     const int64_t p = idx_s[tt[u] * K + j];
-                    v[u][j] = *reinterpret_cast<const V*>(src + p * src_pitch + (int64_t)cc[u] * VEC);
+                    v[u][j] = load_src<T, VEC>(src + p * src_pitch + (int64_t)cc[u] * VEC);
                 }
             }
 #pragma unroll
@@ -152,7 +209,7 @@ regrid_cols_ell_kernel(const T* __restrict__ src, T* __restrict__ out,
                         acc[u].v[e] = apply_level_op(prog_s[s * C * VEC + cc[u] * VEC + e], acc[u].v[e], masked);
                 }
             }
-            *reinterpret_cast<V*>(out + (t0 + tt[u]) * out_pitch + (int64_t)cc[u] * VEC) = acc[u];
+            store_out(reinterpret_cast<V*>(out + (t0 + tt[u]) * out_pitch + (int64_t)cc[u] * VEC), acc[u]);
         }
     }
 }
@@ -250,7 +307,7 @@ regrid_cols_csr_kernel(const T* __restrict__ src, T* __restrict__ out,
                     acc.v[e] = apply_level_op(prog_s[s * C * VEC + c * VEC + e], acc.v[e], masked);
             }
         }
-        *reinterpret_cast<V*>(out + (t0 + t) * out_pitch + (int64_t)c * VEC) = acc;
+        store_out(reinterpret_cast<V*>(out + (t0 + t) * out_pitch + (int64_t)c * VEC), acc);
     }
 }
 
@@ -361,9 +418,12 @@ check_indices_kernel(const int32_t* __restrict__ idx, int64_t n, int64_t n_src, 
 // host-side launchers
 // ---------------------------------------------------------------------------------
 static int pick_tile(int64_t n_tgt, int C) {
-    // about 3/4 of one sweep of 256 lanes x kUnroll items per workgroup (measured best on
-    // O1280 -> 0.25 deg x137: tiles of 16-24 targets, profiles/r01_tile_sweep.log), >= 8 targets
-    int tile = (kBlock * kUnroll * 3 / 4 + C - 1) / C;
+    // Small tiles win: ~560 (target, vector) items per 256-lane workgroup, i.e. 16 targets of
+    // 137 f32 levels, rounded up to a multiple of 4 targets (measured on O1280 -> 0.25 deg:
+    // tiles of 12 / 16 beat 10, 14, 18-32 — profiles/r01_ab_variants.log).  More, shorter
+    // workgroups keep more of them in different phases (index staging / gather / store).
+    int tile = (560 + C - 1) / C;
+    tile = (tile + 3) / 4 * 4;
     if (tile < 8) tile = 8;
     if (tile > 256) tile = 256;
     if ((int64_t)tile > n_tgt) tile = (int)n_tgt;

@@ -82,7 +82,8 @@ class AtxError(RuntimeError):
 
 
 def lib_path() -> str:
-    return os.path.join(LIB_DIR, LIB_NAME)
+    """``lib/libatx.so`` next to this file; ``ATX_LIBRARY`` overrides it (A/B builds of the kernels)."""
+    return os.environ.get("ATX_LIBRARY") or os.path.join(LIB_DIR, LIB_NAME)
 
 
 def load() -> ctypes.CDLL:

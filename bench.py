@@ -60,6 +60,9 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the secondary k=1 / f64 / field-major lines")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline sample")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="collective backend for N > 1 (nccl = RCCL)")
+    ap.add_argument("--share-device", action="store_true",
+                    help="REHEARSAL ONLY: all ranks use cuda:0 (exercises the N > 1 code path on a 1-GPU box; needs --backend gloo)")
     return ap.parse_args()
 
 
@@ -125,13 +128,17 @@ def main():
 
     native.load()  # fails loudly if the HIP extension is missing
     assert torch.cuda.is_available(), "bench.py needs an MI355X"
-    dev = torch.device("cuda", local_rank)
+    dev = torch.device("cuda", 0 if args.share_device else local_rank)
     torch.cuda.set_device(dev)
     if world > 1:
         import torch.distributed as dist
 
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=dev)  # RCCL over xGMI
+        if args.backend == "nccl":
+            assert not args.share_device, "RCCL needs one GPU per rank"
+            dist.init_process_group("nccl", device_id=dev)  # RCCL over xGMI
+        else:
+            dist.init_process_group("gloo")
 
     tdtype = torch.float32 if args.dtype == "f32" else torch.float64
     np_dtype = np.float32 if args.dtype == "f32" else np.float64
@@ -238,6 +245,7 @@ def main():
             "sharding": "target points over ranks; sources exchanged once by RCCL broadcast before timing"
                         if world > 1 else "single GPU",
             "launches_per_step_per_gpu": world,
+            **({"rehearsal": "ranks share one GPU over gloo; not a scaling measurement"} if args.share_device else {}),
         },
         "roofline": {
             "bound": "hbm",
