@@ -372,9 +372,11 @@ class Pipeline(Workflow):
         return "Pipeline(" + " | ".join(repr(f) for f in self.filters) + ")"
 
     def forward(self, data: Any) -> Any:
-        for f in self.filters:
-            data = f.forward(data)
-        return data
+        # same result as `for f in filters: data = f.forward(data)`; runs of per-point filters
+        # (optionally behind a regrid) are collapsed into one kernel launch per stack
+        from .filters.fusion import forward_fused
+
+        return forward_fused(self.filters, data)
 
     def backward(self, data: Any) -> Any:
         for f in reversed(self.filters):

@@ -1,0 +1,153 @@
+"""Fused pipelines give exactly the results of the filter-by-filter pipeline (and of the oracle)."""
+
+from __future__ import annotations
+
+import numpy as np
+import pytest
+
+from anemoi_transform_amd import interp, native
+from anemoi_transform_amd.filters import create_filter_by_name
+from anemoi_transform_amd.filters import fusion
+from anemoi_transform_amd.grids import lookup
+from oracle import oracle
+
+import native_double
+from test_filters import collect_fields_by_param, synthetic_fields, test_source
+
+
+@pytest.fixture(params=["double", pytest.param("hip", marks=pytest.mark.gpu)])
+def engine(request, monkeypatch):
+    if request.param == "double":
+        native_double.install(monkeypatch)
+    return request.param
+
+
+@pytest.fixture
+def launches(monkeypatch):
+    """Counts kernel launches by wrapping the native entry points."""
+    counts = {"regrid_ell": 0, "regrid_csr": 0, "pointwise_stack": 0}
+    for name in counts:
+        real = getattr(native, name)
+
+        def wrapped(*a, _real=real, _name=name, **k):
+            counts[_name] += 1
+            return _real(*a, **k)
+
+        monkeypatch.setattr(native, name, wrapped)
+    return counts
+
+
+def config5_pipeline(matrix, mask_path=None):
+    filters = [
+        create_filter_by_name("regrid", matrix=matrix),
+        create_filter_by_name("orog_to_z"),
+        create_filter_by_name("convert", unit_in="K", unit_out="degC", param="t"),
+        create_filter_by_name("clip", param="q", minimum=270.0),
+    ]
+    if mask_path:
+        filters.append(create_filter_by_name("apply_mask", path=mask_path, mask_value=1, param=["t", "z"], rename="masked"))
+    return filters
+
+
+def setup_case(tmp_path, ragged=False):
+    src, tgt = lookup("o32"), lookup([5.0, 5.0])
+    idx, w = interp.knn_inverse_distance(src, tgt, k=4)
+    if ragged:
+        keep = (np.arange(idx.size) % 5 != 0).reshape(idx.shape)
+        matrix = dict(matrix_data=w[keep], matrix_indices=idx[keep].astype(np.int32),
+                      matrix_indptr=np.concatenate([[0], np.cumsum(keep.sum(axis=1))]).astype(np.int32),
+                      matrix_shape=np.array([len(idx), len(src["latitudes"])]))
+    else:
+        matrix = interp.ell_to_csr(idx, w, len(src["latitudes"]))
+    matrix = {**matrix, "out_latitudes": tgt["latitudes"], "out_longitudes": tgt["longitudes"]}
+    specs = synthetic_fields(src, 6, nan_frac=0.01)
+    for i, p in enumerate(["t", "orog", "q", "t", "lsm", "q"]):
+        specs[i]["param"] = p
+    rng = np.random.default_rng(4)
+    mask = (rng.random(len(tgt["latitudes"])) < 0.3).astype(float)
+    mask_path = str(tmp_path / "tmask.npy")
+    np.save(mask_path, mask)
+    return specs, matrix, mask_path, mask.astype(bool)
+
+
+@pytest.mark.parametrize("ragged", [False, True])
+def test_regrid_chain_fused_equals_unfused_and_oracle(engine, launches, tmp_path, monkeypatch, ragged):
+    specs, matrix, mask_path, mask = setup_case(tmp_path, ragged)
+    source = test_source(specs)
+
+    pipeline = source
+    for f in config5_pipeline(matrix, mask_path):
+        pipeline = pipeline | f
+    fused = list(pipeline)
+    assert launches["regrid_ell"] + launches["regrid_csr"] == 1 and launches["pointwise_stack"] == 0  # ONE launch
+
+    monkeypatch.setenv("ATX_NO_FUSION", "1")
+    pipeline = source
+    for f in config5_pipeline(matrix, mask_path):
+        pipeline = pipeline | f
+    unfused = list(pipeline)
+    assert launches["pointwise_stack"] >= 3
+
+    base = oracle.filter_regrid_matrix([dict(s) for s in specs], matrix=matrix)
+    want = oracle.filter_orog_to_z(base)
+    want = oracle.filter_rescale(want, scale=1.0, offset=-273.15, param="t")
+    want = oracle.filter_clip(want, param="q", minimum=270.0)
+    want = oracle.filter_apply_mask(want, mask_values=mask.astype(float), mask_value=1, param=["t", "z"], rename="masked")
+
+    assert [f.metadata("param") for f in fused] == [w["param"] for w in want] == [f.metadata("param") for f in unfused]
+    assert [f.metadata("param") for f in fused] == ["t_masked", "z_masked", "q", "t_masked", "lsm", "q"]
+    for a, b, w in zip(fused, unfused, want):
+        assert np.array_equal(a.to_numpy(flatten=True), b.to_numpy(flatten=True), equal_nan=True)
+        assert np.array_equal(a.to_numpy(flatten=True), np.asarray(w["values"]).ravel(), equal_nan=True)
+        assert np.array_equal(a.grid_points()[0], matrix["out_latitudes"])
+        assert a.metadata("levelist") == b.metadata("levelist")
+    assert fused[0].metadata("units") == "degC"
+
+
+def test_pointwise_run_without_regrid_is_one_launch(engine, launches):
+    src = lookup("o16")
+    specs = synthetic_fields(src, 4)
+    for i, p in enumerate(["orog", "t", "q", "z"]):
+        specs[i]["param"] = p
+    source = test_source(specs)
+    pipeline = (source | create_filter_by_name("orog_to_z") | create_filter_by_name("rescale", scale=2.0, offset=1.0, param="z")
+                | create_filter_by_name("z_to_orog"))
+    out = list(pipeline)
+    assert launches["pointwise_stack"] == 1
+    assert [f.metadata("param") for f in out] == ["orog", "t", "q", "orog"]
+    x0, x3 = specs[0]["values"], specs[3]["values"]
+    assert np.array_equal(out[0].to_numpy(), oracle.z_to_orog(oracle.rescale_forward(oracle.orog_to_z(x0), 2.0, 1.0)))
+    assert np.array_equal(out[3].to_numpy(), oracle.z_to_orog(oracle.rescale_forward(x3, 2.0, 1.0)))
+    assert out[1] is source.ds[1] and out[2] is source.ds[2]  # untouched fields pass by identity
+
+
+def test_unfusable_filters_cut_the_segment(engine, launches):
+    src, tgt = lookup("o16"), lookup([10.0, 10.0])
+    specs = synthetic_fields(src, 3, nan_frac=0.05)
+    specs[1]["param"] = "lsm"
+    specs[1]["values"] = (np.asarray(specs[1]["values"]) > 280).astype(float)
+    source = test_source(specs)
+    pipeline = (source | create_filter_by_name("regrid", in_grid="o16", out_grid=[10.0, 10.0], method="nearest")
+                | create_filter_by_name("rescale", scale=1.0, offset=-273.15, param="t")
+                | create_filter_by_name("apply_mask", mask_param="lsm", mask_value=0)  # mask from the stream: not fusable
+                | create_filter_by_name("remove_nans"))
+    out = list(pipeline)
+    base = oracle.filter_regrid_nearest([dict(s) for s in specs], in_grid=src, out_grid=tgt)
+    want = oracle.filter_remove_nans(oracle.filter_apply_mask(
+        oracle.filter_rescale(base, scale=1.0, offset=-273.15, param="t"), mask_param="lsm", mask_value=0))
+    assert len(out) == len(want) == 2
+    for f, w in zip(out, want):
+        assert np.array_equal(f.to_numpy(flatten=True), w["values"], equal_nan=True)
+        assert np.array_equal(f.grid_points()[1], w["longitudes"])
+
+
+def test_flatten_and_stage_detection():
+    a = create_filter_by_name("orog_to_z")
+    b = create_filter_by_name("rescale", scale=1.0, offset=0.0, param="t")
+    c = create_filter_by_name("remove_nans")
+    p = (a | b) | c
+    assert fusion.flatten(p.filters) == [a, b, c]
+    assert fusion.as_stage(a) is not None and fusion.as_stage(b) is not None and fusion.as_stage(c) is None
+    assert fusion.as_stage(b.reverse()) is not None
+    assert fusion.as_stage(create_filter_by_name("clip", param="t", minimum=0.0).reverse()) is None  # clip is not reversible
+    assert fusion.as_stage(create_filter_by_name("apply_mask", mask_param="lsm", mask_value=0)) is None

@@ -1,0 +1,163 @@
+"""Parity at BASELINE.json's full sizes (O1280 -> 0.25 degree, 137 levels) through
+size-independent properties, plus oracle spot checks on a sample of levels.
+
+The oracle cannot afford 137 full-size levels per test, so the full stack is checked by
+properties the operator must have whatever its size:
+  * rows of the index table that point at target t == source t reproduce the source (identity gather);
+  * weights sum to 1  =>  a constant field stays constant;
+  * linearity: R(a x + y) == a R(x) + R(y) up to rounding;
+  * the 8 target shards concatenate to the unsharded result, bit for bit;
+  * column-stack and field-major kernels agree bit for bit (same arithmetic order);
+  * compaction indices are strictly increasing and select exactly the non-NaN points;
+  * affine then inverse-affine returns the input to within 1 ulp-scale error;
+and a sample of levels is compared with the oracle directly.
+"""
+
+from __future__ import annotations
+
+import numpy as np
+import pytest
+import torch
+
+from anemoi_transform_amd import native
+from anemoi_transform_amd.gather import GatherPlan
+from anemoi_transform_amd.grids import lookup
+from anemoi_transform_amd.interp import knn_inverse_distance
+from anemoi_transform_amd.stack import COLUMNS, FIELDS, Stack
+from oracle import oracle
+
+pytestmark = pytest.mark.gpu
+
+N_LEV = 137
+
+
+@pytest.fixture(scope="module")
+def case(dev):
+    src, tgt = lookup("o1280"), lookup("0.25")
+    idx, w = knn_inverse_distance(src, tgt, k=4)
+    n_src, n_tgt = len(src["latitudes"]), len(tgt["latitudes"])
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(20260630)
+    lat = torch.from_numpy(np.deg2rad(src["latitudes"])).to(dev)
+    lon = torch.from_numpy(np.deg2rad(src["longitudes"])).to(dev)
+    x = Stack.empty(n_src, N_LEV, torch.float32, dev, COLUMNS, zero=True)
+    base = 280.0 + 30.0 * torch.sin(lat) * torch.cos(2.0 * lon)
+    for l in range(N_LEV):
+        x.data[:, l] = (base + 0.1 * l + torch.randn(n_src, dtype=torch.float64, device=dev, generator=gen)).float()
+    return dict(src=src, tgt=tgt, idx=idx, w=w, n_src=n_src, n_tgt=n_tgt, x=x,
+                plan=GatherPlan(n_src, n_tgt, index=idx, weights=w))
+
+
+def test_sample_levels_match_oracle(case):
+    out = case["plan"].apply(case["x"])
+    indptr = np.arange(case["n_tgt"] + 1) * 4
+    w32 = case["w"].astype(np.float32).reshape(-1)
+    for l in (0, 68, 136):
+        want = oracle.csr_apply(w32, case["idx"].reshape(-1), indptr, (case["n_tgt"], case["n_src"]), case["x"].level_numpy(l))
+        got = out.level_numpy(l)
+        np.testing.assert_allclose(got, want, rtol=1e-6)  # north_star tolerance for float interpolation
+        assert np.array_equal(got, want)  # and in fact identical: same order, no FMA
+
+
+def test_constant_field_is_preserved(case, dev):
+    c = Stack.empty(case["n_src"], N_LEV, torch.float32, dev, COLUMNS, zero=True)
+    levels = torch.arange(1, N_LEV + 1, dtype=torch.float32, device=dev) * 3.5
+    c.data[:, :N_LEV] = levels
+    out = case["plan"].apply(c)
+    err = (out.data[:, :N_LEV] - levels).abs().max().item()
+    assert err <= 4 * np.finfo(np.float32).eps * float(levels.max())  # sum of 4 f32-rounded weights
+
+
+def test_linearity(case, dev):
+    x = case["x"]
+    y = Stack.empty(case["n_src"], N_LEV, torch.float32, dev, COLUMNS, zero=True)
+    y.data[:, :N_LEV] = torch.rand(case["n_src"], N_LEV, device=dev) * 10.0
+    a = 0.5  # exact in binary
+    z = Stack(x.data * a + y.data, case["n_src"], N_LEV, COLUMNS)
+    rz = case["plan"].apply(z).data[:, :N_LEV]
+    combo = case["plan"].apply(x).data[:, :N_LEV] * a + case["plan"].apply(y).data[:, :N_LEV]
+    assert torch.allclose(rz, combo, rtol=1e-6, atol=1e-4)
+
+
+def test_identity_gather_is_a_bit_copy(case):
+    n = case["n_tgt"]
+    ident = GatherPlan(case["n_src"], n, index=np.arange(n))
+    out = ident.apply(case["x"])
+    assert torch.equal(out.data.view(torch.int32), case["x"].data[:n].view(torch.int32))
+    rev = GatherPlan(case["n_src"], n, index=np.arange(n)[::-1].copy())
+    out = rev.apply(case["x"])
+    assert torch.equal(out.data.view(torch.int32), case["x"].data[:n].flip(0).view(torch.int32))
+
+
+def test_shards_concatenate_bit_exact(case):
+    full = case["plan"].apply(case["x"]).data
+    parts = [case["plan"].shard(r, 8).apply(case["x"]).data for r in range(8)]
+    assert torch.equal(torch.cat(parts).view(torch.int32), full.view(torch.int32))
+
+
+def test_layouts_agree_bit_exact(case):
+    cols = case["plan"].apply(case["x"])
+    fields = case["plan"].apply(case["x"].to_layout(FIELDS))
+    assert fields.layout == FIELDS
+    assert torch.equal(fields.data[:, : case["n_tgt"]].T.contiguous().view(torch.int32),
+                       cols.data[:, :N_LEV].contiguous().view(torch.int32))
+
+
+def test_csr_path_equals_ell_path(case, dev):
+    """The general CSR kernel on the same (uniform) matrix gives the ELL kernel's bits."""
+    n_tgt = case["n_tgt"]
+    csr = GatherPlan(case["n_src"], n_tgt, csr=(case["w"].reshape(-1), case["idx"].reshape(-1), np.arange(n_tgt + 1) * 4))
+    a = csr.apply(case["x"]).data
+    b = case["plan"].apply(case["x"]).data
+    assert torch.equal(a.view(torch.int32), b.view(torch.int32))
+
+
+def test_remove_nans_compaction_properties(case, dev):
+    x = case["x"]
+    n = case["n_src"]
+    holes = torch.rand(n, device=dev, generator=None) < 0.05
+    first = x.data[:, 0].clone()
+    first[holes] = float("nan")
+    mask = torch.empty(n + 8, dtype=torch.uint8, device=dev)
+    native.mask_build(first, mask, n=n, stride=1, cmp=native.CMP_NOTNAN)
+    count = native.mask_count(mask, n)
+    assert count == int((~holes).sum().item())
+    index = native.mask_to_index(mask, n)
+    assert index.numel() == count
+    assert bool((index[1:] > index[:-1]).all())  # strictly increasing: numpy boolean-indexing order
+    assert not bool(holes[index.long()].any())
+    plan = GatherPlan(n, count, index=index.cpu().numpy())
+    out = plan.apply(x)
+    assert torch.equal(out.data.view(torch.int32), x.data[~holes].view(torch.int32))
+
+
+def test_pointwise_round_trip_and_mask_count(case, dev):
+    x = case["x"]
+    n = case["n_src"]
+    y = x.new_like()
+    fwd = native.level_program([[(native.OP_AFFINE, 0, 1.8, 32.0)] * N_LEV], dev)
+    bwd = native.level_program([[(native.OP_AFFINE_INV, 0, 1.8, 32.0)] * N_LEV], dev)
+    kw = dict(n_pts=n, n_lev=N_LEV, x_pitch=x.pitch, y_pitch=y.pitch, layout=COLUMNS)
+    native.pointwise_stack(x.data, y.data, prog=fwd, n_stage=1, **kw)
+    native.pointwise_stack(y.data, y.data, prog=bwd, n_stage=1, **kw)
+    assert torch.allclose(y.data[:, :N_LEV], x.data[:, :N_LEV], rtol=3e-7, atol=1e-4)
+    pm = (torch.rand(n, device=dev) < 0.25).to(torch.uint8)
+    pm = torch.cat([pm, torch.zeros(8, dtype=torch.uint8, device=dev)])
+    masked = native.level_program([[(native.OP_COPY, 1, 0.0, 0.0)] * N_LEV], dev)
+    native.pointwise_stack(x.data, y.data, prog=masked, n_stage=1, point_mask=pm, **kw)
+    n_nan = native.reduce(y.data[:, :N_LEV].contiguous(), native.RED_NANCOUNT)
+    assert n_nan == float(int(pm.sum().item()) * N_LEV)
+    keep = pm[:n] == 0
+    assert torch.equal(y.data[keep].view(torch.int32), x.data[keep].view(torch.int32))
+
+
+def test_empty_and_tiny_inputs(dev):
+    """Edge cases: zero targets, one target, one level, one source point."""
+    x = Stack.from_fields(np.arange(12.0).reshape(3, 4), dev=dev)
+    empty = GatherPlan(4, 0, index=np.zeros((0, 1), dtype=np.int64))
+    assert empty.apply(x).n_pts == 0
+    one = GatherPlan(4, 1, index=np.array([[3, 0]]), weights=np.array([[0.25, 0.75]]))
+    assert np.array_equal(one.apply(x).numpy()[:, 0], 0.25 * np.array([3.0, 7.0, 11.0]) + 0.75 * np.array([0.0, 4.0, 8.0]))
+    single = Stack.from_fields(np.array([[5.0]]), dev=dev)
+    assert np.array_equal(GatherPlan(1, 3, index=np.zeros(3, dtype=np.int64)).apply(single).numpy(), [[5.0, 5.0, 5.0]])
+    assert native.mask_to_index(torch.zeros(4, dtype=torch.uint8, device=dev), 0).numel() == 0
