@@ -367,3 +367,133 @@ def filter_regrid_mask(fields, *, mask: np.ndarray) -> list[dict]:
         g["latitudes"], g["longitudes"] = out_lat, out_lon
         out.append(g)
     return out
+
+
+# --------------------------------------------------------------------------------
+# mask / index builders (R: spatial.py) — per-point loops kept as in the reference
+# --------------------------------------------------------------------------------
+# R: constants.py:11-25 — earthkit-meteo constants (package absent): R_earth = 6371229 m as recalled
+# in SURVEY.md §8c, radian = pi/180 as stated by the comment at R: spatial.py:364.
+R_EARTH_KM = 6371229.0 / 1000
+RADIAN = np.pi / 180.0
+
+
+def cropping_mask(lats, lons, north, west, south, east):
+    """R: spatial.py:236-275."""
+    return (
+        (lats >= south)
+        & (lats <= north)
+        & (
+            ((lons >= west) & (lons <= east))
+            | ((lons >= west + 360) & (lons <= east + 360))
+            | ((lons >= west - 360) & (lons <= east - 360))
+        )
+    )
+
+
+def triangle_intersect(v0, v1, v2, ray_origin, ray_direction) -> bool:
+    """R: spatial.py:186-233 (Möller–Trumbore)."""
+    epsilon = 0.0000001
+    h = np.cross(ray_direction, v2 - v0)
+    a = np.dot(v1 - v0, h)
+    if -epsilon < a < epsilon:
+        return False
+    f = 1.0 / a
+    s = ray_origin - v0
+    u = f * np.dot(s, h)
+    if u < 0.0 or u > 1.0:
+        return False
+    q = np.cross(s, v1 - v0)
+    v = f * np.dot(ray_direction, q)
+    if v < 0.0 or u + v > 1.0:
+        return False
+    t = f * np.dot(v2 - v0, q)
+    return bool(t > epsilon)
+
+
+def _resolution(points) -> float:
+    """R: spatial.py:94-98."""
+    from scipy.spatial import cKDTree
+
+    distances, _ = cKDTree(points).query(points, k=2)
+    return np.min(distances[:, 1])
+
+
+def _distance_km_to_resolution(distance_km, lam_points, global_points) -> float:
+    """R: spatial.py:101-108."""
+    if isinstance(distance_km, (int, float)):
+        return distance_km / R_EARTH_KM
+    return _resolution({"lam": lam_points, "global": global_points, None: global_points}[distance_km])
+
+
+def cutout_mask(lats, lons, global_lats, global_lons, cropping_distance=2.0, neighbours=5, min_distance_km=None,
+                max_distance_km=None):
+    """R: spatial.py:294-440."""
+    from scipy.spatial import cKDTree
+
+    assert global_lats.ndim == 1 and global_lons.ndim == 1 and lats.ndim == 1 and lons.ndim == 1
+    assert global_lats.shape == global_lons.shape and lats.shape == lons.shape
+    north, south, east, west = np.amax(lats), np.amin(lats), np.amax(lons), np.amin(lons)
+    effective_cropping_distance = cropping_distance
+    if max_distance_km is not None:
+        max_lat = max(abs(north), abs(south))
+        R_earth_at_lat = R_EARTH_KM * np.cos(np.deg2rad(max_lat))
+        L_1_degree_arc_length_km = R_earth_at_lat * RADIAN
+        max_distance_degrees = max_distance_km / L_1_degree_arc_length_km
+        effective_cropping_distance = max(cropping_distance, 1.1 * max_distance_degrees)
+    mask = cropping_mask(
+        global_lats, global_lons, np.min([90.0, north + effective_cropping_distance]), west - effective_cropping_distance,
+        np.max([-90.0, south - effective_cropping_distance]), east + effective_cropping_distance,
+    )
+    global_points = np.array(latlon_to_xyz(global_lats[mask], global_lons[mask])).transpose()
+    lam_points = np.array(latlon_to_xyz(lats, lons)).transpose()
+    min_distance = _distance_km_to_resolution(min_distance_km, lam_points, global_points)
+    distances, indices = cKDTree(lam_points).query(global_points, k=neighbours)
+    zero = np.array([0.0, 0.0, 0.0])
+    inside_lam = []
+    for global_point, distance, index in zip(global_points, distances, indices):
+        inside = False
+        for j in range(neighbours):
+            inside = triangle_intersect(
+                lam_points[index[j]], lam_points[index[(j + 1) % neighbours]], lam_points[index[(j + 2) % neighbours]],
+                zero, global_point,
+            )
+            if inside:
+                break
+        close = np.min(distance) <= min_distance
+        too_far = False
+        if max_distance_km is not None:
+            too_far = np.min(distance) > (max_distance_km / R_EARTH_KM)
+        inside_lam.append(inside or close or too_far)
+    too_far_mask = False
+    if isinstance(max_distance_km, (int, float)):
+        too_far_mask = ~mask.copy()
+    mask[mask] = inside_lam
+    mask[too_far_mask] = True
+    return ~mask
+
+
+def thinning_mask(lats, lons, global_lats, global_lons, cropping_distance=2.0):
+    """R: spatial.py:443-503."""
+    from scipy.spatial import cKDTree
+
+    north, south, east, west = np.amax(lats), np.amin(lats), np.amax(lons), np.amin(lons)
+    mask = cropping_mask(
+        global_lats, global_lons, np.min([90.0, north + cropping_distance]), west - cropping_distance,
+        np.max([-90.0, south - cropping_distance]), east + cropping_distance,
+    )
+    global_points = np.array(latlon_to_xyz(global_lats[mask], global_lons[mask])).transpose()
+    points = np.array(latlon_to_xyz(lats, lons)).transpose()
+    _, indices = cKDTree(points).query(global_points, k=1)
+    return indices
+
+
+def global_on_lam_mask(lats, lons, global_lats, global_lons, distance_km=None):
+    """R: spatial.py:506-536."""
+    from scipy.spatial import cKDTree
+
+    global_points = np.array(latlon_to_xyz(global_lats, global_lons)).transpose()
+    lam_points = np.array(latlon_to_xyz(lats, lons)).transpose()
+    distance = _distance_km_to_resolution(distance_km, lam_points, global_points)
+    indices = cKDTree(global_points).query_ball_point(lam_points, distance)
+    return np.array(sorted(set(i for sublist in indices for i in sublist)))
