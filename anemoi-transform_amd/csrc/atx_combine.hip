@@ -1,0 +1,160 @@
+// Multi-input per-point transforms: one launch over all matching groups of a FieldList.
+//
+// The reference groups fields by MARS key and calls a numpy expression once per group
+// (R: filters/fields/matching.py:223-246, grouping/__init__.py:93-137).  Here the host
+// stacks the i-th operand of every group into one stack per operand, and this kernel
+// evaluates the expression for every (point, level) in one streaming pass: HBM-bound,
+// (n_in + n_out)*N*L*B algorithmic bytes, 16-byte vector accesses, grid-stride.
+#include "atx_common.hpp"
+
+namespace atx {
+
+struct CombArgs {
+    const void* in[ATX_COMB_MAX_INPUTS];
+    void* out[2];
+};
+
+// g = 9.80665 (R: constants.py:13, value pinned by filters/tabular/geopotential_to_height.py:51)
+template <typename T>
+__device__ __forceinline__ void combine_one(int op, int flags, const T* x, int n_in, T level, T& y0, T& y1) {
+    const T g = T(9.80665);
+    y1 = T(0);
+    switch (op) {
+        case ATX_COMB_SNOW_DEPTH_M: y0 = T(1000.0) * x[0] / x[1]; break;
+        case ATX_COMB_SNOW_COVER: {
+            const T tmp1 = (T(1000) * x[0]) / x[1];
+            T tmp2 = x[1];  // np.clip(rsn, 100, 400): NaN stays NaN
+            tmp2 = (tmp2 < T(100)) ? T(100) : tmp2;
+            tmp2 = (tmp2 > T(400)) ? T(400) : tmp2;
+            T sc = tanh((T(4000) * tmp1) / tmp2);
+            sc = (sc < T(0)) ? T(0) : sc;
+            sc = (sc > T(1)) ? T(1) : sc;
+            y0 = (sc > T(0.99)) ? T(1.0) : sc;
+            break;
+        }
+        case ATX_COMB_COS_SIN: {
+            T a = x[0];
+            if (flags & ATX_COMB_DEGREES) a = a * T(0.017453292519943295);  // np.deg2rad: x * (pi/180)
+            y0 = cos(a);
+            y1 = sin(a);
+            break;
+        }
+        case ATX_COMB_ATAN2: {
+            T d = atan2(x[1], x[0]);
+            if (flags & ATX_COMB_DEGREES) {
+                d = d * T(57.29577951308232);  // np.rad2deg: x * (180/pi)
+                d = (d >= T(360)) ? d - T(360) : d;
+                d = (d < T(0)) ? d + T(360) : d;
+            }
+            y0 = d;
+            break;
+        }
+        case ATX_COMB_W_TO_WZ: {
+            const T rho = (T(100) * level) / (T(287) * x[1] * (T(1) + T(0.61) * x[2]) + T(1e-8));
+            y0 = (T(-1.0) / (rho * g + T(1e-8))) * x[0];
+            break;
+        }
+        case ATX_COMB_WZ_TO_W: {
+            const T rho = (T(100) * level) / (T(287) * x[1] * (T(1) + T(0.61) * x[2]) + T(1e-8));
+            y0 = T(-1.0) * rho * g * x[0];
+            break;
+        }
+        case ATX_COMB_SUM: {
+            T s = x[0];
+            for (int i = 1; i < n_in; ++i) s = s + x[i];
+            y0 = s;
+            break;
+        }
+        default: y0 = x[0]; break;
+    }
+}
+
+template <typename T, int VEC>
+__global__ void __launch_bounds__(kBlock)
+combine_kernel(CombArgs a, int op, int flags, int n_in, int n_out, int64_t n_rows, int64_t row_len, int64_t pitch,
+               int layout, int n_lev, const double* __restrict__ level_param) {
+    using V = Pack<T, VEC>;
+    const int64_t vec_per_row = pitch / VEC;  // pitch % VEC == 0 on this path (else VEC == 1)
+    const int64_t total = n_rows * vec_per_row;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < total; i += (int64_t)gridDim.x * kBlock) {
+        const int64_t row = i / vec_per_row;
+        const int64_t col = (i - row * vec_per_row) * VEC;
+        V x[ATX_COMB_MAX_INPUTS];
+#pragma unroll
+        for (int k = 0; k < ATX_COMB_MAX_INPUTS; ++k)
+            if (k < n_in) x[k] = *reinterpret_cast<const V*>(static_cast<const T*>(a.in[k]) + row * pitch + col);
+        V y0, y1;
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+            T xe[ATX_COMB_MAX_INPUTS];
+#pragma unroll
+            for (int k = 0; k < ATX_COMB_MAX_INPUTS; ++k) xe[k] = (k < n_in) ? x[k].v[e] : T(0);
+            const int64_t level = layout == ATX_COLUMNS ? col + e : row;
+            const bool live = (col + e) < row_len;
+            T lv = T(0);
+            if (level_param && level < n_lev) lv = static_cast<T>(level_param[level]);
+            T r0, r1;
+            combine_one<T>(op, flags, xe, n_in, lv, r0, r1);
+            y0.v[e] = live ? r0 : T(0);  // padding stays zero
+            y1.v[e] = live ? r1 : T(0);
+        }
+        *reinterpret_cast<V*>(static_cast<T*>(a.out[0]) + row * pitch + col) = y0;
+        if (n_out > 1) *reinterpret_cast<V*>(static_cast<T*>(a.out[1]) + row * pitch + col) = y1;
+    }
+}
+
+template <typename T>
+static int combine_typed(const CombArgs& a, int op, int flags, int n_in, int n_out, int64_t n_pts, int n_lev, int64_t pitch,
+                         int layout, const double* level_param, hipStream_t st) {
+    constexpr int VEC = Vec16<T>::N;
+    bool vec_ok = pitch % VEC == 0;
+    for (int k = 0; k < n_in; ++k) vec_ok = vec_ok && aligned16(a.in[k]);
+    for (int k = 0; k < n_out; ++k) vec_ok = vec_ok && aligned16(a.out[k]);
+    const int64_t n_rows = layout == ATX_COLUMNS ? n_pts : n_lev;
+    const int64_t row_len = layout == ATX_COLUMNS ? n_lev : n_pts;
+    int64_t blocks = (n_rows * (pitch / (vec_ok ? VEC : 1)) + kBlock - 1) / kBlock;
+    if (blocks > 2048) blocks = 2048;
+    if (blocks < 1) blocks = 1;
+    if (vec_ok)
+        hipLaunchKernelGGL((combine_kernel<T, VEC>), dim3((unsigned)blocks), dim3(kBlock), 0, st, a, op, flags, n_in, n_out, n_rows,
+                           row_len, pitch, layout, n_lev, level_param);
+    else
+        hipLaunchKernelGGL((combine_kernel<T, 1>), dim3((unsigned)blocks), dim3(kBlock), 0, st, a, op, flags, n_in, n_out, n_rows,
+                           row_len, pitch, layout, n_lev, level_param);
+    ATX_LAUNCH_CHECK("combine_stack");
+    return ATX_OK;
+}
+
+}  // namespace atx
+
+using namespace atx;
+
+extern "C" int atx_combine_stack(int op, const void* const* inputs, int32_t n_in, void* const* outputs, int32_t n_out,
+                                 int64_t n_pts, int64_t n_lev, int64_t pitch, int dtype, int layout,
+                                 const double* level_param, int32_t flags, void* stream) {
+    static const int kIn[ATX_COMB_COUNT_] = {2, 2, 1, 2, 3, 3, -1};
+    static const int kOut[ATX_COMB_COUNT_] = {1, 1, 2, 1, 1, 1, 1};
+    ATX_REQUIRE(op >= 0 && op < ATX_COMB_COUNT_, ATX_EINVAL, "atx_combine_stack: bad operator %d", op);
+    ATX_REQUIRE(inputs && outputs, ATX_EINVAL, "atx_combine_stack: null pointer table");
+    ATX_REQUIRE(n_in >= 1 && n_in <= ATX_COMB_MAX_INPUTS, ATX_EINVAL, "atx_combine_stack: n_in=%d outside [1, %d]", n_in, ATX_COMB_MAX_INPUTS);
+    ATX_REQUIRE(kIn[op] < 0 || kIn[op] == n_in, ATX_EINVAL, "atx_combine_stack: operator %d takes %d inputs, got %d", op, kIn[op], n_in);
+    ATX_REQUIRE(kOut[op] == n_out, ATX_EINVAL, "atx_combine_stack: operator %d gives %d outputs, got %d", op, kOut[op], n_out);
+    ATX_REQUIRE(dtype == ATX_F32 || dtype == ATX_F64, ATX_EINVAL, "atx_combine_stack: bad dtype %d", dtype);
+    ATX_REQUIRE(layout == ATX_COLUMNS || layout == ATX_FIELDS, ATX_EINVAL, "atx_combine_stack: bad layout %d", layout);
+    ATX_REQUIRE(n_pts >= 0 && n_lev > 0 && n_lev <= INT32_MAX, ATX_EINVAL, "atx_combine_stack: bad sizes");
+    ATX_REQUIRE(pitch >= (layout == ATX_COLUMNS ? n_lev : n_pts), ATX_ESHAPE, "atx_combine_stack: pitch %lld too small", (long long)pitch);
+    ATX_REQUIRE(level_param || (op != ATX_COMB_W_TO_WZ && op != ATX_COMB_WZ_TO_W), ATX_EINVAL, "atx_combine_stack: operator %d needs level_param", op);
+    CombArgs a{};
+    for (int k = 0; k < n_in; ++k) {
+        ATX_REQUIRE(inputs[k], ATX_EINVAL, "atx_combine_stack: null input %d", k);
+        a.in[k] = inputs[k];
+    }
+    for (int k = 0; k < n_out; ++k) {
+        ATX_REQUIRE(outputs[k], ATX_EINVAL, "atx_combine_stack: null output %d", k);
+        a.out[k] = outputs[k];
+    }
+    if (n_pts == 0) return ATX_OK;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (dtype == ATX_F32) return combine_typed<float>(a, op, flags, n_in, n_out, n_pts, (int)n_lev, pitch, layout, level_param, s);
+    return combine_typed<double>(a, op, flags, n_in, n_out, n_pts, (int)n_lev, pitch, layout, level_param, s);
+}

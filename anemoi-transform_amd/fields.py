@@ -184,9 +184,13 @@ class Field:
 class ArrayField(Field):
     """A host field: array + metadata dict + per-point coordinates."""
 
-    def __init__(self, values: Any, metadata: dict[str, Any], latitudes: np.ndarray, longitudes: np.ndarray) -> None:
+    def __init__(self, values: Any, metadata: dict[str, Any], latitudes: np.ndarray, longitudes: np.ndarray,
+                 mars: bool = False) -> None:
         self._values = np.asarray(values)
         self._md = dict(metadata)
+        # plain list-of-dicts fields expose no "mars" namespace; the reference's MarsUserMetadata
+        # test fixture (R: tests/conftest.py:27-38) does — `mars=True` reproduces it
+        self._mars = mars
         self._latitudes = np.asarray(latitudes, dtype=np.float64)
         self._longitudes = np.asarray(longitudes, dtype=np.float64)
         self.shape = tuple(self._values.shape)
@@ -195,7 +199,7 @@ class ArrayField(Field):
         )
 
     @classmethod
-    def from_dict(cls, spec: dict[str, Any]) -> "ArrayField":
+    def from_dict(cls, spec: dict[str, Any], mars: bool = False) -> "ArrayField":
         """The ``list-of-dicts`` entry form of the reference tests (R: tests/conftest.py:63).
 
         ``values`` is ``[nlat, nlon]`` over DISTINCT ``latitudes`` / ``longitudes``
@@ -213,7 +217,12 @@ class ArrayField(Field):
             lat, lon = lat2.reshape(-1), lon2.reshape(-1)
         else:
             lat, lon = lat.reshape(-1), lon.reshape(-1)
-        return cls(values, spec, lat, lon)
+        return cls(values, spec, lat, lon, mars=mars)
+
+    def _namespace(self, namespace: str) -> dict[str, Any]:
+        if not self._mars:
+            return {}
+        return super()._namespace(namespace)
 
     def _flat(self) -> np.ndarray:
         return self._values.flatten()
@@ -423,9 +432,10 @@ def new_empty_fieldlist() -> FieldList:
     return FieldList([])
 
 
-def fieldlist_from_dicts(specs: list[dict[str, Any]]) -> FieldList:
-    """``ekd.from_source("list-of-dicts", specs)`` look-alike."""
-    return FieldList([ArrayField.from_dict(s) for s in specs])
+def fieldlist_from_dicts(specs: list[dict[str, Any]], mars: bool = False) -> FieldList:
+    """``ekd.from_source("list-of-dicts", specs)`` look-alike (``mars=True``: fields with a MARS namespace,
+    as built by R: tests/conftest.py:70-80 ``mars_test_source``)."""
+    return FieldList([ArrayField.from_dict(s, mars=mars) for s in specs])
 
 
 class FieldSelection:
@@ -531,3 +541,33 @@ def group_into_stacks(fields: Iterable[Any], positions: list[int] | None = None)
             dtype = _host_dtype(arrays)
             groups.append(StackGroup(Stack.from_fields(arrays, dtype=dtype, dev=_stack.device()), members, group_fields))
     return groups
+
+
+def fields_to_stack(fields: list[Any]) -> Stack:
+    """One HBM stack whose level ``i`` is ``fields[i]`` (all on the same grid), in that order.
+
+    Fields that already are levels of one stack are selected on the device; anything else
+    (host fields, levels of different stacks) is gathered column by column.
+    """
+    refs = [f.stack_ref() if isinstance(f, Field) else None for f in fields]
+    if all(r is not None for r in refs) and all(r[0] is refs[0][0] for r in refs):
+        return select_levels(refs[0][0], [r[1] for r in refs])
+    dev = _stack.device()
+    columns = []
+    for f, r in zip(fields, refs):
+        if r is not None:
+            columns.append(r[0].level_view(r[1]))
+        else:
+            host = np.ascontiguousarray(f.to_numpy(flatten=True))
+            if host.dtype not in (np.float32, np.float64):
+                host = host.astype(np.float64)
+            columns.append(torch.from_numpy(host).to(dev))
+    if _upload_dtype is not None:
+        dtype = _upload_dtype
+    else:
+        dtype = torch.float32 if all(c.dtype == torch.float32 for c in columns) else torch.float64
+    n_pts = columns[0].numel()
+    assert all(c.numel() == n_pts for c in columns), "fields of one stack must share a grid"
+    out = Stack.empty(n_pts, len(columns), dtype, dev, COLUMNS, zero=True)
+    out.data[:, : len(columns)] = torch.stack([c.to(dtype) for c in columns], dim=1)
+    return out

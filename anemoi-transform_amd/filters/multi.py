@@ -1,0 +1,512 @@
+"""Multi-input per-point filters: fields matched by metadata, computed for all groups in one launch.
+
+Mirror of R: filters/fields/matching.py (``MatchingSpec``, ``MatchingFieldsFilter``) and of the
+filters built on it or on the same idea:
+
+  snow_depth_m                 R: filters/fields/snow_depth_m.py
+  snow_cover                   R: filters/fields/snow_cover.py
+  cos_sin_from_rad             R: filters/fields/cos_sin_from_rad.py
+  cos_sin_mean_wave_direction  R: filters/fields/cos_sin_mean_wave_direction.py
+  w_to_wz / wz_to_w            R: filters/fields/w_to_wz.py
+  sum                          R: filters/fields/sum.py
+
+``MatchingFieldsFilter`` keeps the reference behaviour for user-defined subclasses (one
+``forward_transform(**fields)`` call per group, numpy inside).  The built-in filters derive
+from ``StackMatchingFilter``: the grouping bookkeeping is the same, but the i-th operand of
+every group is stacked into one HBM stack per operand and the expression is evaluated by a
+single ``atx_combine_stack`` launch.  Output order equals the reference's: unmatched fields
+first (in input order), then per group the returned inputs followed by the results.
+"""
+
+from __future__ import annotations
+
+import logging
+from abc import abstractmethod
+from collections import defaultdict
+from dataclasses import dataclass, replace
+from inspect import signature
+from itertools import chain
+from typing import Any, Callable, Iterable, Iterator
+
+import numpy as np
+import torch
+
+from .. import native
+from ..core import Filter, filter_registry
+from ..fields import FieldList, fields_to_stack, new_field_from_numpy, new_field_from_stack, new_fieldlist_from_list
+from ..grouping import GroupByParam, GroupByParamVertical
+
+LOG = logging.getLogger(__name__)
+
+
+@dataclass(frozen=True)
+class MatchingSpec:
+    """Which constructor arguments name the forward / backward operands (R: matching.py:35-81)."""
+
+    select: str = "param"
+    forward: tuple[str, ...] = ()
+    backward: tuple[str, ...] = ()
+    return_inputs: Any = "none"  # "all" | "none" | tuple of operand names
+    vertical: bool = False
+
+    @staticmethod
+    def _to_tuple_of_str(x: Any) -> tuple[str, ...]:
+        if isinstance(x, str):
+            return (x,)
+        try:
+            return tuple(x)
+        except TypeError as e:
+            raise TypeError(f"Expected str or iterable, got {type(x)}") from e
+
+    def __post_init__(self) -> None:
+        if self.select != "param":
+            raise NotImplementedError("Only 'select=param' is supported for now.")
+        object.__setattr__(self, "forward", self._to_tuple_of_str(self.forward))
+        object.__setattr__(self, "backward", self._to_tuple_of_str(self.backward))
+        if self.return_inputs not in ("all", "none"):
+            object.__setattr__(self, "return_inputs", self._to_tuple_of_str(self.return_inputs))
+            all_params = set(self.forward) | set(self.backward)
+            if not set(self.return_inputs).issubset(all_params):
+                raise ValueError(f"Returned input names must subset {all_params}")
+
+    def update_return_inputs(self, return_inputs: Any) -> "MatchingSpec":
+        if return_inputs not in ("all", "none"):
+            return_inputs = self._to_tuple_of_str(return_inputs)
+        if return_inputs == self.return_inputs:
+            return self
+        return replace(self, return_inputs=return_inputs)
+
+    def inputs(self, direction: str) -> tuple[str, ...]:
+        if self.return_inputs == "all":
+            return tuple(getattr(self, direction))
+        if self.return_inputs == "none":
+            return ()
+        return self.return_inputs
+
+
+def inputs_generator(input_list: Iterable[str], **kwargs: Any) -> Iterator[Any]:
+    for name in input_list:
+        if name in kwargs:
+            yield kwargs[name]
+
+
+class MatchingFieldsFilter(Filter):
+    """Converts groups of fields matched by their metadata (R: matching.py:90-311)."""
+
+    MATCHING: MatchingSpec
+
+    @staticmethod
+    def _check_expected_method_parameters(method: Callable, expected: set[str]) -> None:
+        missing = set(expected) - set(signature(method).parameters)
+        if missing:
+            raise ValueError(f"{method}: missing parameters {missing}")
+
+    def __init_subclass__(cls, **kwargs: Any) -> None:
+        super().__init_subclass__(**kwargs)
+        if cls.__dict__.get("_ABSTRACT_MATCHING_BASE"):
+            return
+        if not hasattr(cls, "MATCHING") or not isinstance(cls.MATCHING, MatchingSpec):
+            raise TypeError(f"Class {cls.__name__} must define a 'MATCHING' attribute of type MatchingSpec.")
+        fwd, bwd = set(cls.MATCHING.forward), set(cls.MATCHING.backward)
+        MatchingFieldsFilter._check_expected_method_parameters(cls.__init__, fwd | bwd)
+        MatchingFieldsFilter._check_expected_method_parameters(cls.forward_transform, fwd)
+        MatchingFieldsFilter._check_expected_method_parameters(cls.backward_transform, bwd)
+
+    def __init__(self, *args: Any, **kwargs: Any) -> None:
+        super().__init__(*args, **kwargs)
+        self._prepare_matching()
+
+    def _prepare_matching(self) -> None:
+        if hasattr(self, "return_inputs"):
+            self.MATCHING = self.MATCHING.update_return_inputs(self.return_inputs)
+        for direction in ("forward", "backward"):
+            params = getattr(self.MATCHING, direction)
+            inputs = self.MATCHING.inputs(direction=direction)
+            if inputs and params and not set(inputs).issubset(params):
+                LOG.warning(
+                    f"Some {direction} inputs will not be returned because they are not in the filter parameters: "
+                    f"{set(inputs) - set(params)}"
+                )
+
+    def _check_metadata_match(self, data: set, args: Iterable[str]) -> None:
+        if not set(args).issubset(data):
+            LOG.warning(
+                "Please ensure your filter is configured to match the input variables metadata "
+                f"current mismatch between inputs {data} and filter metadata {list(args)}"
+            )
+
+    def _grouping(self, group_by: tuple[str, ...]):
+        return GroupByParamVertical(group_by) if self.MATCHING.vertical else GroupByParam(group_by)
+
+    def forward(self, data: Any) -> FieldList:
+        names = self.MATCHING.forward
+
+        def transform(*fields: Any) -> Iterator[Any]:
+            kwargs = dict(zip(names, fields, strict=True))
+            return chain(inputs_generator(self.MATCHING.inputs(direction="forward"), **kwargs), self.forward_transform(**kwargs))
+
+        return self._transform(data, transform, *(getattr(self, n) for n in names))
+
+    def backward(self, data: Any) -> FieldList:
+        names = self.MATCHING.backward
+
+        def transform(*fields: Any) -> Iterator[Any]:
+            kwargs = dict(zip(names, fields, strict=True))
+            return chain(inputs_generator(self.MATCHING.inputs(direction="backward"), **kwargs), self.backward_transform(**kwargs))
+
+        return self._transform(data, transform, *(getattr(self, n) for n in names))
+
+    def _transform(self, data: Any, transform: Callable[..., Iterator[Any]], *group_by: str) -> FieldList:
+        data = data if isinstance(data, FieldList) else FieldList(list(data))
+        self._check_metadata_match(set(data.metadata(self.MATCHING.select)), group_by)
+        result: list[Any] = []
+        for matching in self._grouping(group_by).iterate(data, other=result.append):
+            for f in transform(*matching):
+                result.append(f)
+        return self.new_fieldlist_from_list(result)
+
+    def new_field_from_numpy(self, array: np.ndarray, *, template: Any, **kwargs: Any) -> Any:
+        return new_field_from_numpy(array, template=template, **kwargs)
+
+    def new_fieldlist_from_list(self, fields: list[Any]) -> FieldList:
+        return new_fieldlist_from_list(fields)
+
+    @abstractmethod
+    def forward_transform(self, *fields: Any) -> Iterator[Any]: ...
+
+    def backward_transform(self, *fields: Any) -> Iterator[Any]:
+        raise NotImplementedError("Backward transformation not implemented.")
+
+
+MatchingFieldsFilter._ABSTRACT_MATCHING_BASE = True
+
+
+# =================================================================================
+# stack-level execution
+# =================================================================================
+def combine_groups(
+    groups: list[tuple[Any, ...]],
+    op: int,
+    n_out: int,
+    *,
+    flags: int = 0,
+    level_values: list[float] | None = None,
+    check: Callable[[list[Any]], None] | None = None,
+) -> list[list[tuple[Any, int]]]:
+    """Evaluate one operator for all groups: returns, per group, the ``(stack, level)`` of each output.
+
+    Groups are bucketed by grid size; operand ``i`` of every group of a bucket becomes level
+    ``g`` of the i-th input stack; one ``atx_combine_stack`` launch per bucket.
+    """
+    results: list[list[tuple[Any, int]]] = [[] for _ in groups]
+    buckets: dict[int, list[int]] = defaultdict(list)
+    for gi, g in enumerate(groups):
+        buckets[int(np.prod(g[0].shape))].append(gi)
+    for members in buckets.values():
+        n_in = len(groups[members[0]])
+        ins = [fields_to_stack([groups[gi][i] for gi in members]) for i in range(n_in)]
+        dtype = torch.float32 if all(s.dtype == torch.float32 for s in ins) else torch.float64
+        ins = [s if s.dtype == dtype else type(s)(s.data.to(dtype), s.n_pts, s.n_lev, s.layout) for s in ins]
+        if check is not None:
+            check(ins)
+        outs = [ins[0].new_like(zero=False) for _ in range(n_out)]
+        level_param = None
+        if level_values is not None:
+            level_param = torch.tensor([level_values[gi] for gi in members], dtype=torch.float64, device=ins[0].device)
+        native.combine_stack(op, [s.data for s in ins], [s.data for s in outs], n_pts=ins[0].n_pts, n_lev=ins[0].n_lev,
+                             pitch=ins[0].pitch, layout=ins[0].layout, level_param=level_param, flags=flags)
+        for level, gi in enumerate(members):
+            results[gi] = [(o, level) for o in outs]
+    return results
+
+
+class StackMatchingFilter(MatchingFieldsFilter):
+    """A ``MatchingFieldsFilter`` whose per-group expression is one ``atx_combine_stack`` operator.
+
+    Subclasses describe each direction with ``<direction>_plan(**fields)`` returning
+    ``(op, flags, [(template_field, metadata), ...], level_value)`` for ONE group; the
+    operator and flags must not depend on the group.
+    """
+
+    _ABSTRACT_MATCHING_BASE = True
+
+    def forward_plan(self, **fields: Any):
+        raise NotImplementedError
+
+    def backward_plan(self, **fields: Any):
+        raise NotImplementedError("Backward transformation not implemented.")
+
+    def _check_stacks(self, direction: str, stacks: list[Any]) -> None:
+        pass
+
+    def _run(self, data: Any, direction: str) -> FieldList:
+        names = getattr(self.MATCHING, direction)
+        plan_fn = self.forward_plan if direction == "forward" else self.backward_plan
+        group_by = tuple(getattr(self, n) for n in names)
+        data = data if isinstance(data, FieldList) else FieldList(list(data))
+        self._check_metadata_match(set(data.metadata(self.MATCHING.select)), group_by)
+        result: list[Any] = []
+        groups = list(self._grouping(group_by).iterate(data, other=result.append))
+        if not groups:
+            return self.new_fieldlist_from_list(result)
+        plans = [plan_fn(**dict(zip(names, g, strict=True))) for g in groups]
+        op, flags = plans[0][0], plans[0][1]
+        level_values = [p[3] for p in plans] if plans[0][3] is not None else None
+        outs = combine_groups(groups, op, len(plans[0][2]), flags=flags, level_values=level_values,
+                              check=lambda stacks: self._check_stacks(direction, stacks))
+        for g, plan, out in zip(groups, plans, outs):
+            kwargs = dict(zip(names, g, strict=True))
+            result.extend(inputs_generator(self.MATCHING.inputs(direction=direction), **kwargs))
+            for (template, metadata), (stack, level) in zip(plan[2], out):
+                result.append(new_field_from_stack(stack, level, template=template, metadata=metadata))
+        return self.new_fieldlist_from_list(result)
+
+    def forward(self, data: Any) -> FieldList:
+        return self._run(data, "forward")
+
+    def backward(self, data: Any) -> FieldList:
+        return self._run(data, "backward")
+
+    # the per-group entry points of the reference API, for callers that use them directly
+    def forward_transform(self, *args: Any, **fields: Any) -> Iterator[Any]:
+        fields.update(dict(zip(self.MATCHING.forward, args)))
+        op, flags, outputs, level = self.forward_plan(**fields)
+        group = tuple(fields[n] for n in self.MATCHING.forward)
+        (out,) = combine_groups([group], op, len(outputs), flags=flags, level_values=None if level is None else [level],
+                                check=lambda stacks: self._check_stacks("forward", stacks))
+        for (template, metadata), (stack, lvl) in zip(outputs, out):
+            yield new_field_from_stack(stack, lvl, template=template, metadata=metadata)
+
+    def backward_transform(self, *args: Any, **fields: Any) -> Iterator[Any]:
+        fields.update(dict(zip(self.MATCHING.backward, args)))
+        op, flags, outputs, level = self.backward_plan(**fields)
+        group = tuple(fields[n] for n in self.MATCHING.backward)
+        (out,) = combine_groups([group], op, len(outputs), flags=flags, level_values=None if level is None else [level])
+        for (template, metadata), (stack, lvl) in zip(outputs, out):
+            yield new_field_from_stack(stack, lvl, template=template, metadata=metadata)
+
+
+# =================================================================================
+# the filters
+# =================================================================================
+@filter_registry.register("snow_depth_m")
+class SnowDepthM(StackMatchingFilter):
+    """Snow depth in metres: ``sde = 1000 * sd / rsn``."""
+
+    MATCHING = MatchingSpec(select="param", forward=("snow_depth", "snow_density"))
+
+    def __init__(self, *, snow_depth: str = "sd", snow_density: str = "rsn", snow_depth_m: str = "sde") -> None:
+        self.snow_depth = snow_depth
+        self.snow_density = snow_density
+        self.snow_depth_m = snow_depth_m
+        super().__init__()
+
+    def forward_plan(self, snow_depth: Any, snow_density: Any):
+        return native.COMB_SNOW_DEPTH_M, 0, [(snow_depth, dict(param=self.snow_depth_m, units="m"))], None
+
+    def forward_transform(self, snow_depth: Any = None, snow_density: Any = None) -> Iterator[Any]:
+        return super().forward_transform(snow_depth=snow_depth, snow_density=snow_density)
+
+
+@filter_registry.register("snow_cover")
+class SnowCover(StackMatchingFilter):
+    """Snow cover fraction from snow depth and snow density (R: snow_cover.py:34-39)."""
+
+    MATCHING = MatchingSpec(select="param", forward=("snow_depth", "snow_density"))
+
+    def __init__(self, *, snow_depth: str = "sd", snow_density: str = "rsn", snow_cover: str = "snowc") -> None:
+        self.snow_depth = snow_depth
+        self.snow_density = snow_density
+        self.snow_cover = snow_cover
+        super().__init__()
+
+    def forward_plan(self, snow_depth: Any, snow_density: Any):
+        return native.COMB_SNOW_COVER, 0, [(snow_depth, dict(param=self.snow_cover, units="Fraction"))], None
+
+    def forward_transform(self, snow_depth: Any = None, snow_density: Any = None) -> Iterator[Any]:
+        return super().forward_transform(snow_depth=snow_depth, snow_density=snow_density)
+
+
+def _range_check(name: str, stack: Any) -> None:
+    """R: cos_sin_from_rad.py:73-76 — radians expected in [-2 pi, 2 pi]; min / max by ``atx_reduce``."""
+    view = stack.data[:, : stack.n_lev] if stack.layout == native.COLUMNS else stack.data[:, : stack.n_pts]
+    flat = view.contiguous().reshape(-1)
+    lo = native.reduce(flat, native.RED_MIN)
+    if lo < -2 * np.pi:
+        raise ValueError(f"Param {name} is expected in radians in the range [-2pi, pi], but min={lo}")
+    hi = native.reduce(flat, native.RED_MAX)
+    if hi > 2 * np.pi:
+        raise ValueError(f"Param {name} is expected in radians in the range [-2pi, pi], but max={hi}")
+
+
+@filter_registry.register("cos_sin_from_rad")
+class CosSinFromRad(StackMatchingFilter):
+    """A direction in radians -> its cosine and sine, and back with atan2."""
+
+    MATCHING = MatchingSpec(select="param", forward=("param",), backward=("cos_param", "sin_param"))
+
+    def __init__(self, *, param: str, cos_param: str | None = None, sin_param: str | None = None) -> None:
+        self.param = param
+        self.cos_param = cos_param if cos_param is not None else f"cos_{param}"
+        self.sin_param = sin_param if sin_param is not None else f"sin_{param}"
+        super().__init__()
+
+    def forward_plan(self, param: Any):
+        return native.COMB_COS_SIN, 0, [(param, dict(param=self.cos_param)), (param, dict(param=self.sin_param))], None
+
+    def backward_plan(self, cos_param: Any, sin_param: Any):
+        return native.COMB_ATAN2, 0, [(cos_param, dict(param=self.param))], None
+
+    def _check_stacks(self, direction: str, stacks: list[Any]) -> None:
+        if direction == "forward":
+            _range_check(self.param, stacks[0])
+
+    def forward_transform(self, param: Any = None) -> Iterator[Any]:
+        return super().forward_transform(param=param)
+
+    def backward_transform(self, cos_param: Any = None, sin_param: Any = None) -> Iterator[Any]:
+        return super().backward_transform(cos_param=cos_param, sin_param=sin_param)
+
+    def patch_data_request(self, data_request: dict[str, Any]) -> dict[str, Any]:
+        param = data_request.get("param")
+        if param is None:
+            return data_request
+        if self.cos_param in param or self.sin_param in param:
+            data_request["param"] = [p for p in param if p not in (self.cos_param, self.sin_param)]
+            data_request["param"].append(self.param)
+        return data_request
+
+
+@filter_registry.register("cos_sin_mean_wave_direction")
+class CosSinWaveDirection(StackMatchingFilter):
+    """Mean wave direction in degrees -> cosine / sine, and back to [0, 360)."""
+
+    MATCHING = MatchingSpec(
+        select="param", forward=("mean_wave_direction",), backward=("cos_mean_wave_direction", "sin_mean_wave_direction")
+    )
+
+    def __init__(self, *, mean_wave_direction: str = "mwd", cos_mean_wave_direction: str = "cos_mwd",
+                 sin_mean_wave_direction: str = "sin_mwd") -> None:
+        self.mean_wave_direction = mean_wave_direction
+        self.cos_mean_wave_direction = cos_mean_wave_direction
+        self.sin_mean_wave_direction = sin_mean_wave_direction
+        super().__init__()
+
+    def forward_plan(self, mean_wave_direction: Any):
+        return native.COMB_COS_SIN, native.COMB_DEGREES, [
+            (mean_wave_direction, dict(param=self.cos_mean_wave_direction)),
+            (mean_wave_direction, dict(param=self.sin_mean_wave_direction)),
+        ], None
+
+    def backward_plan(self, cos_mean_wave_direction: Any, sin_mean_wave_direction: Any):
+        return native.COMB_ATAN2, native.COMB_DEGREES, [(cos_mean_wave_direction, dict(param=self.mean_wave_direction))], None
+
+    def forward_transform(self, mean_wave_direction: Any = None) -> Iterator[Any]:
+        return super().forward_transform(mean_wave_direction=mean_wave_direction)
+
+    def backward_transform(self, cos_mean_wave_direction: Any = None, sin_mean_wave_direction: Any = None) -> Iterator[Any]:
+        return super().backward_transform(cos_mean_wave_direction=cos_mean_wave_direction,
+                                          sin_mean_wave_direction=sin_mean_wave_direction)
+
+    def patch_data_request(self, data_request: dict[str, Any]) -> dict[str, Any]:
+        param = data_request.get("param")
+        if param is None:
+            return data_request
+        if self.cos_mean_wave_direction in param or self.sin_mean_wave_direction in param:
+            data_request["param"] = [p for p in param if p not in (self.cos_mean_wave_direction, self.sin_mean_wave_direction)]
+            data_request["param"].append(self.mean_wave_direction)
+        return data_request
+
+
+class VerticalVelocity(StackMatchingFilter):
+    """Pressure vertical velocity w [Pa/s] <-> geometric vertical velocity wz [m/s] (hydrostatic, ideal gas)."""
+
+    MATCHING = MatchingSpec(
+        select="param",
+        forward=("vertical_velocity", "temperature", "humidity"),
+        backward=("geometric_vertical_velocity", "temperature", "humidity"),
+    )
+
+    def __init__(self, *, vertical_velocity: str = "w", geometric_vertical_velocity: str = "wz", temperature: str = "t",
+                 humidity: str = "q", return_inputs: Any = "all") -> None:
+        self.return_inputs = return_inputs
+        self.vertical_velocity = vertical_velocity
+        self.geometric_vertical_velocity = geometric_vertical_velocity
+        self.temperature = temperature
+        self.humidity = humidity
+        super().__init__()
+
+    @staticmethod
+    def _level(field: Any) -> float:
+        return float(field.metadata("levelist", default=None))  # R: w_to_wz.py:97 — TypeError if the level is missing
+
+    def forward_plan(self, vertical_velocity: Any, temperature: Any, humidity: Any):
+        return (native.COMB_W_TO_WZ, 0, [(vertical_velocity, dict(param=self.geometric_vertical_velocity))],
+                self._level(vertical_velocity))
+
+    def backward_plan(self, geometric_vertical_velocity: Any, temperature: Any, humidity: Any):
+        return (native.COMB_WZ_TO_W, 0, [(geometric_vertical_velocity, dict(param=self.vertical_velocity))],
+                self._level(geometric_vertical_velocity))
+
+    def forward_transform(self, vertical_velocity: Any = None, temperature: Any = None, humidity: Any = None) -> Iterator[Any]:
+        return super().forward_transform(vertical_velocity=vertical_velocity, temperature=temperature, humidity=humidity)
+
+    def backward_transform(self, geometric_vertical_velocity: Any = None, temperature: Any = None, humidity: Any = None) -> Iterator[Any]:
+        return super().backward_transform(geometric_vertical_velocity=geometric_vertical_velocity, temperature=temperature,
+                                          humidity=humidity)
+
+
+filter_registry.register("w_to_wz", VerticalVelocity)
+filter_registry.register("wz_to_w", VerticalVelocity.reversed)
+
+
+@filter_registry.register("sum")
+class Sum(Filter):
+    """Replace ``params`` by their sum ``output``, per date / level / member (R: sum.py:25-121).
+
+    Fields are matched on their MARS namespace minus ``param`` (minus ``levelist`` with
+    ``ignore_level``); the terms are added in the order the fields appear in the input, as the
+    reference does.
+    """
+
+    def __init__(self, *, params: list[str], output: str, ignore_level: bool = False) -> None:
+        self.params = params
+        self.output = output
+        self.ignore_level = ignore_level
+
+    def forward(self, fields: Any) -> FieldList:
+        result: list[Any] = []
+        needed: dict[tuple, dict[str, Any]] = defaultdict(dict)
+        for f in fields:
+            key = dict(f.metadata(namespace="mars"))
+            param = key.pop("param", None)
+            if self.ignore_level:
+                key.pop("levelist", None)
+            if param is None:
+                param = f.metadata("param")
+            if param in self.params:
+                frozen = tuple(key.items())
+                if param in needed[frozen]:
+                    raise ValueError(f"Duplicate field {param} for {frozen}")
+                needed[frozen][param] = f
+            else:
+                result.append(f)
+        groups = []
+        for values in needed.values():
+            if len(values) != len(self.params):
+                raise ValueError("Missing fields")
+            groups.append(tuple(values.values()))
+        if groups:
+            if len(self.params) > native.COMB_MAX_INPUTS:
+                raise NotImplementedError(f"sum of more than {native.COMB_MAX_INPUTS} fields is not supported")
+            outs = combine_groups(groups, native.COMB_SUM, 1)
+            for g, out in zip(groups, outs):
+                stack, level = out[0]
+                # R: sum.py:109-117 — the sum is a flattened array; the first term is the template
+                field = new_field_from_stack(stack, level, template=g[0], metadata=dict(param=self.output))
+                field.shape = (stack.n_pts,)
+                result.append(field)
+        return new_fieldlist_from_list(result)
+
+    def backward(self, data: Any) -> Any:
+        raise NotImplementedError("Sum filter is not reversible")

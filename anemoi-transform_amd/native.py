@@ -38,6 +38,9 @@ CMP_GT, CMP_LT, CMP_EQ, CMP_NE, CMP_GE, CMP_LE, CMP_NOTNAN, CMP_ISNAN = range(8)
     OP_SET_NAN,
 ) = range(10)
 RED_MIN, RED_MAX, RED_NANCOUNT = range(3)
+COMB_SNOW_DEPTH_M, COMB_SNOW_COVER, COMB_COS_SIN, COMB_ATAN2, COMB_W_TO_WZ, COMB_WZ_TO_W, COMB_SUM = range(7)
+COMB_DEGREES = 1
+COMB_MAX_INPUTS = 8
 
 OK, EINVAL, ESHAPE, ENOTIMPL, EHIP, EALIGN, EWORKSPACE = 0, -1, -2, -3, -4, -5, -6
 
@@ -65,6 +68,11 @@ SIGNATURES: dict[str, tuple[Any, list[Any]]] = {
     "atx_pointwise_stack": (
         c_int,
         [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int64, c_int, c_int, c_void_p, c_int32, c_void_p, c_void_p],
+    ),
+    "atx_combine_stack": (
+        c_int,
+        [c_int, POINTER(c_void_p), c_int32, POINTER(c_void_p), c_int32, c_int64, c_int64, c_int64, c_int, c_int, c_void_p,
+         c_int32, c_void_p],
     ),
     "atx_mask_build": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int, c_double, c_int, c_void_p]),
     "atx_mask_count": (c_int, [c_void_p, c_int64, c_void_p, c_void_p]),
@@ -209,6 +217,18 @@ def pointwise_stack(x, y, *, n_pts, n_lev, x_pitch, y_pitch, layout, prog, n_sta
         "atx_pointwise_stack", _ptr(x), _ptr(y), n_pts, n_lev, x_pitch, y_pitch, dtype_code(x.dtype), layout,
         _ptr(prog), n_stage, _ptr(point_mask), _stream(),
     )
+
+
+def combine_stack(op: int, inputs, outputs, *, n_pts, n_lev, pitch, layout, level_param=None, flags: int = 0) -> None:
+    """Multi-input per-point operator over same-shape stacks (``atx_combine_stack``)."""
+    dtype = inputs[0].dtype
+    assert all(t.dtype == dtype for t in list(inputs) + list(outputs))
+    ins = (c_void_p * len(inputs))(*[_ptr(t) for t in inputs])
+    outs = (c_void_p * len(outputs))(*[_ptr(t) for t in outputs])
+    if level_param is not None:
+        assert level_param.dtype == torch.float64 and level_param.numel() >= n_lev
+    _call("atx_combine_stack", op, ins, len(inputs), outs, len(outputs), n_pts, n_lev, pitch, dtype_code(dtype), layout,
+          _ptr(level_param), flags, _stream())
 
 
 def mask_build(m, mask, *, n, stride=1, cmp, threshold=0.0) -> None:

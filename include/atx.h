@@ -172,6 +172,32 @@ int atx_pointwise_stack(const void* x, void* y, int64_t n_pts, int64_t n_lev,
                         const atx_level_op* prog, int32_t n_stage, const uint8_t* point_mask,
                         void* stream);
 
+/* ---- multi-input per-point transforms ------------------------------------------ */
+/* Operators of the reference's MatchingFieldsFilter family (R: filters/fields/matching.py:90-311):
+ * every input / output is a stack of the same shape, pitch and layout; level l of the
+ * outputs is computed from level l of the inputs (the fields of one matching group). */
+typedef enum {
+    ATX_COMB_SNOW_DEPTH_M = 0, /* (sd, rsn) -> 1000.0*sd/rsn            R: filters/fields/snow_depth_m.py:42      */
+    ATX_COMB_SNOW_COVER = 1,   /* (sd, rsn) -> clip(tanh(4000*(1000*sd/rsn)/clip(rsn,100,400)),0,1), >0.99 -> 1
+                                                                        R: filters/fields/snow_cover.py:34-39     */
+    ATX_COMB_COS_SIN = 2,      /* (x) -> (cos x, sin x); flag ATX_COMB_DEGREES: x = deg2rad(x) first
+                                  R: filters/fields/cos_sin_from_rad.py:78-79, cos_sin_mean_wave_direction.py:72-76 */
+    ATX_COMB_ATAN2 = 3,        /* (cos, sin) -> atan2(sin, cos); flag ATX_COMB_DEGREES: rad2deg, then wrap to [0, 360)
+                                  R: cos_sin_from_rad.py:100, cos_sin_mean_wave_direction.py:97-99                 */
+    ATX_COMB_W_TO_WZ = 4,      /* (w, t, q) -> (-1/(rho*g + 1e-8))*w, rho = (100*level)/(287*t*(1+0.61*q) + 1e-8)
+                                  level = level_param[l]              R: filters/fields/w_to_wz.py:97-99          */
+    ATX_COMB_WZ_TO_W = 5,      /* (wz, t, q) -> -1.0*rho*g*wz          R: w_to_wz.py:124-126                       */
+    ATX_COMB_SUM = 6,          /* (c0, c1, ...) -> ((c0 + c1) + ...) in input order   R: filters/fields/sum.py:109-116 */
+    ATX_COMB_COUNT_ = 7
+} atx_comb;
+#define ATX_COMB_DEGREES 1
+#define ATX_COMB_MAX_INPUTS 8
+/* inputs / outputs: HOST arrays of n_in / n_out DEVICE pointers (n_in <= ATX_COMB_MAX_INPUTS, n_out <= 2).
+ * level_param: device double[n_lev] or NULL (required by the W/WZ operators). */
+int atx_combine_stack(int op, const void* const* inputs, int32_t n_in, void* const* outputs, int32_t n_out,
+                      int64_t n_pts, int64_t n_lev, int64_t pitch, int dtype, int layout,
+                      const double* level_param, int32_t flags, void* stream);
+
 /* ---- masks ------------------------------------------------------------------ */
 
 /* mask[i] = (m[i*m_stride] CMP threshold) ? 1 : 0   for i < n.

@@ -497,3 +497,61 @@ def global_on_lam_mask(lats, lons, global_lats, global_lons, distance_km=None):
     distance = _distance_km_to_resolution(distance_km, lam_points, global_points)
     indices = cKDTree(global_points).query_ball_point(lam_points, distance)
     return np.array(sorted(set(i for sublist in indices for i in sublist)))
+
+
+# --------------------------------------------------------------------------------
+# multi-input per-point statements (MatchingFieldsFilter family)
+# --------------------------------------------------------------------------------
+def snow_depth_m(snow_depth, snow_density):
+    """R: filters/fields/snow_depth_m.py:42."""
+    return 1000.0 * snow_depth / snow_density
+
+
+def snow_cover(snow_depth, snow_density):
+    """R: filters/fields/snow_cover.py:34-39."""
+    tmp1 = (1000 * snow_depth) / snow_density
+    tmp2 = np.clip(snow_density, 100, 400)
+    sc = np.clip(np.tanh((4000 * tmp1) / tmp2), 0, 1)
+    sc[sc > 0.99] = 1.0
+    return sc
+
+
+def cos_sin(data, degrees: bool = False):
+    """R: filters/fields/cos_sin_from_rad.py:78-79; cos_sin_mean_wave_direction.py:72-76 (degrees)."""
+    if degrees:
+        data = np.deg2rad(data)
+    return np.cos(data), np.sin(data)
+
+
+def direction_from_cos_sin(cos_values, sin_values, degrees: bool = False):
+    """R: cos_sin_from_rad.py:100; cos_sin_mean_wave_direction.py:97-99 (degrees, wrapped to [0, 360))."""
+    d = np.arctan2(sin_values, cos_values)
+    if degrees:
+        d = np.rad2deg(d)
+        d = np.where(d >= 360, d - 360, d)
+        d = np.where(d < 0, d + 360, d)
+    return d
+
+
+def w_to_wz(w, t, q, level):
+    """R: filters/fields/w_to_wz.py:97-99."""
+    rho = (100 * level) / (287 * t * (1 + 0.61 * q) + 1e-8)
+    return (-1.0 / (rho * G + 1e-8)) * w
+
+
+def wz_to_w(wz, t, q, level):
+    """R: w_to_wz.py:124-126."""
+    rho = (100 * level) / (287 * t * (1 + 0.61 * q) + 1e-8)
+    return -1.0 * rho * G * wz
+
+
+def sum_fields(arrays):
+    """R: filters/fields/sum.py:109-116 — in-place accumulation in order of appearance."""
+    s = None
+    for c in arrays:
+        c = np.asarray(c).flatten()
+        if s is None:
+            s = c
+        else:
+            s += c
+    return s

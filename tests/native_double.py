@@ -107,6 +107,33 @@ def pointwise_stack(x, y, *, n_pts, n_lev, x_pitch, y_pitch, layout, prog, n_sta
     _epilogue(ys, prog, n_stage, point_mask, n_lev)
 
 
+def combine_stack(op, inputs, outputs, *, n_pts, n_lev, pitch, layout, level_param=None, flags=0):
+    xs = [np.ascontiguousarray(_levels(t, n_pts, n_lev, layout)) for t in inputs]
+    ys = [_levels(t, n_pts, n_lev, layout) for t in outputs]
+    deg = bool(flags & native.COMB_DEGREES)
+    dt = xs[0].dtype.type
+    for l in range(n_lev):
+        a = [x[l] for x in xs]
+        if op == native.COMB_SNOW_DEPTH_M:
+            ys[0][l] = oracle.snow_depth_m(a[0], a[1])
+        elif op == native.COMB_SNOW_COVER:
+            ys[0][l] = oracle.snow_cover(a[0], a[1])
+        elif op == native.COMB_COS_SIN:
+            ys[0][l], ys[1][l] = oracle.cos_sin(a[0], deg)
+        elif op == native.COMB_ATAN2:
+            ys[0][l] = oracle.direction_from_cos_sin(a[0], a[1], deg)
+        elif op == native.COMB_W_TO_WZ:
+            ys[0][l] = oracle.w_to_wz(a[0], a[1], a[2], float(level_param[l]))
+        elif op == native.COMB_WZ_TO_W:
+            ys[0][l] = oracle.wz_to_w(a[0], a[1], a[2], float(level_param[l]))
+        elif op == native.COMB_SUM:
+            ys[0][l] = oracle.sum_fields(a)
+        else:
+            raise ValueError(op)
+    for y in ys:
+        assert y.dtype.type == dt
+
+
 _CMP = {
     native.CMP_GT: ">", native.CMP_LT: "<", native.CMP_EQ: "==", native.CMP_NE: "!=", native.CMP_GE: ">=", native.CMP_LE: "<=",
 }
@@ -146,7 +173,7 @@ def relayout(src, dst, *, n_pts, n_lev, src_pitch, dst_pitch, src_layout, dst_la
     _levels(dst, n_pts, n_lev, dst_layout)[...] = _levels(src, n_pts, n_lev, src_layout)
 
 
-PATCHED = ["regrid_ell", "regrid_csr", "check_indices", "pointwise_stack", "mask_build", "mask_count", "mask_to_index",
+PATCHED = ["regrid_ell", "regrid_csr", "check_indices", "pointwise_stack", "combine_stack", "mask_build", "mask_count", "mask_to_index",
            "reduce", "relayout"]
 
 

@@ -315,7 +315,8 @@ def test_dispatching_filter_contract():
 # ---- fields -----------------------------------------------------------------------------------
 def test_array_field_from_dict_is_latitude_major():
     """R: tests/field_filters/test_remove_nans.py:17-45 — flattened order and meshgridded coordinates."""
-    f = ArrayField.from_dict(SPECS[0])
+    f = ArrayField.from_dict(SPECS[0], mars=True)
+    assert ArrayField.from_dict(SPECS[0]).metadata(namespace="mars") == {}  # plain dict fields have no MARS namespace
     assert f.shape == (3, 2)
     assert np.array_equal(f.to_numpy(flatten=True), np.arange(6.0))
     lat, lon = f.grid_points()
@@ -335,7 +336,7 @@ def test_array_field_from_dict_is_latitude_major():
 
 def test_derived_field_metadata_semantics():
     """R: fields.py:468-568."""
-    f = ArrayField.from_dict(SPECS[0])
+    f = ArrayField.from_dict(SPECS[0], mars=True)
     g = new_field_from_numpy(np.ones(6), template=f, param="x", level=None, units=lambda field, key, md: "K")
     assert g.shape == (6,) and g.metadata("param") == "x" and g.metadata("levelist") == 500
     assert g.metadata("level") is None  # an override to None is a value, not "missing"
