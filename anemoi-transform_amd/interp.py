@@ -21,6 +21,7 @@ from .grids import gaussian_latitudes, octahedral_row_lengths
 __all__ = [
     "unit_sphere_xyz",
     "nearest_grid_points",
+    "nearest_grid_points_device",
     "knn_inverse_distance",
     "ell_to_csr",
     "csr_uniform_k",
@@ -30,12 +31,69 @@ __all__ = [
 ]
 
 
+_knn_engine: str | None = None
+
+
+def knn_engine() -> str:
+    """``"ckdtree"`` (default: the reference's own builder, identical tie order) or ``"device"``
+    (``atx_knn_*`` on the GPU; set with ``set_knn_engine`` or ``ATX_KNN=device``)."""
+    import os
+
+    return _knn_engine or os.environ.get("ATX_KNN", "ckdtree")
+
+
+def set_knn_engine(name: str | None) -> None:
+    global _knn_engine
+    if name not in (None, "ckdtree", "device"):
+        raise ValueError(f"unknown k-NN engine {name!r}")
+    _knn_engine = name
+
+
 def unit_sphere_xyz(latitudes: np.ndarray, longitudes: np.ndarray) -> np.ndarray:
     """``[N, 3]`` Cartesian coordinates on the unit sphere (R: spatial.py:132-167)."""
     phi = np.deg2rad(np.asarray(latitudes, dtype=np.float64))
     lda = np.deg2rad(np.asarray(longitudes, dtype=np.float64))
     cos_phi = np.cos(phi)
     return np.array((cos_phi * np.cos(lda), cos_phi * np.sin(lda), np.sin(phi))).transpose()
+
+
+def nearest_grid_points_device(
+    source_latitudes,
+    source_longitudes,
+    target_latitudes,
+    target_longitudes,
+    max_distance: float | None = None,
+    num_neighbours_to_return: int = 1,
+    return_distances: bool = False,
+):
+    """``nearest_grid_points`` computed on the MI355X (``atx_knn_build`` / ``atx_knn_query``).
+
+    Same arguments and return values.  Distances are bit-identical to cKDTree's (the
+    coordinates are computed here on the host exactly as the reference does, and the kernel
+    repeats scipy's float64 arithmetic); indices agree wherever the candidate distances are
+    distinct — exact ties are ordered by source index (cKDTree: traversal order).
+    """
+    import torch
+
+    from . import native
+    from . import stack as _stack
+
+    k = int(num_neighbours_to_return)
+    dev = _stack.device()
+    src = torch.from_numpy(np.ascontiguousarray(unit_sphere_xyz(source_latitudes, source_longitudes))).to(dev)
+    tgt = torch.from_numpy(np.ascontiguousarray(unit_sphere_xyz(target_latitudes, target_longitudes))).to(dev)
+    idx_d, d2_d = native.KnnIndex(src).query(tgt, k)
+    indices = idx_d.cpu().numpy().astype(np.int64)
+    distances = np.sqrt(d2_d.cpu().numpy())
+    if max_distance is not None:  # cKDTree: neighbours at d >= distance_upper_bound are "missing"
+        missing = ~(distances < max_distance)
+        indices[missing] = len(src)
+        distances[missing] = np.inf
+    if k == 1:
+        indices, distances = indices[:, 0], distances[:, 0]
+    if return_distances:
+        return indices, distances
+    return indices
 
 
 def nearest_grid_points(
@@ -55,6 +113,11 @@ def nearest_grid_points(
     (R: spatial.py:630-632); the regrid filter rejects such indices before any
     gather (``native.check_indices``).
     """
+    if knn_engine() == "device":
+        return nearest_grid_points_device(
+            source_latitudes, source_longitudes, target_latitudes, target_longitudes, max_distance=max_distance,
+            num_neighbours_to_return=num_neighbours_to_return, return_distances=return_distances,
+        )
     from scipy.spatial import cKDTree
 
     tree = cKDTree(unit_sphere_xyz(source_latitudes, source_longitudes))
@@ -67,12 +130,14 @@ def nearest_grid_points(
     return indices
 
 
-def knn_inverse_distance(in_grid: dict, out_grid: dict, k: int = 4, floor: float = 1e-12):
+def knn_inverse_distance(in_grid: dict, out_grid: dict, k: int = 4, floor: float = 1e-12, device: bool = False):
     """k-NN inverse-distance weights ``w_j = (1/max(d_j, floor)) / sum``.
 
-    Returns ``(idx [Nt, k] int64, w [Nt, k] float64)``.
+    Returns ``(idx [Nt, k] int64, w [Nt, k] float64)``.  ``device=True`` runs the neighbour
+    search on the GPU (``nearest_grid_points_device``) instead of cKDTree.
     """
-    idx, dist = nearest_grid_points(
+    search = nearest_grid_points_device if device else nearest_grid_points
+    idx, dist = search(
         in_grid["latitudes"], in_grid["longitudes"], out_grid["latitudes"], out_grid["longitudes"],
         num_neighbours_to_return=k, return_distances=True,
     )

@@ -78,6 +78,9 @@ SIGNATURES: dict[str, tuple[Any, list[Any]]] = {
     "atx_mask_count": (c_int, [c_void_p, c_int64, c_void_p, c_void_p]),
     "atx_mask_to_index_workspace": (c_size_t, [c_int64]),
     "atx_mask_to_index": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "atx_knn_workspace_bytes": (c_size_t, [c_int64]),
+    "atx_knn_build": (c_int, [c_void_p, c_int64, c_void_p, c_size_t, c_void_p]),
+    "atx_knn_query": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int32, c_void_p, c_void_p, c_void_p]),
     "atx_reduce": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_int, c_void_p]),
     "atx_relayout": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int64, c_int, c_int, c_int, c_void_p]),
 }
@@ -252,6 +255,30 @@ def mask_to_index(mask, n: int | None = None) -> torch.Tensor:
     count = torch.zeros(1, dtype=torch.int64, device=mask.device)
     _call("atx_mask_to_index", _ptr(mask), n, _ptr(index), _ptr(count), _ptr(workspace), workspace.numel(), _stream())
     return index[: int(count.item())]
+
+
+class KnnIndex:
+    """A device k-NN index over source points (``atx_knn_build`` / ``atx_knn_query``)."""
+
+    def __init__(self, src_xyz: torch.Tensor) -> None:
+        assert src_xyz.dtype == torch.float64 and src_xyz.dim() == 2 and src_xyz.shape[1] == 3 and src_xyz.is_contiguous()
+        self.n_src = src_xyz.shape[0]
+        nbytes = load().atx_knn_workspace_bytes(self.n_src)
+        if nbytes == 0:
+            raise ValueError(f"cannot index {self.n_src} source points")
+        self.workspace = torch.empty(nbytes + 256, dtype=torch.uint8, device=src_xyz.device)
+        shift = (-self.workspace.data_ptr()) % 256
+        self._ws = self.workspace[shift: shift + nbytes]
+        _call("atx_knn_build", _ptr(src_xyz), self.n_src, _ptr(self._ws), nbytes, _stream())
+
+    def query(self, tgt_xyz: torch.Tensor, k: int) -> tuple[torch.Tensor, torch.Tensor]:
+        """``(indices int32 [n, k], squared distances float64 [n, k])``, nearest first."""
+        assert tgt_xyz.dtype == torch.float64 and tgt_xyz.dim() == 2 and tgt_xyz.shape[1] == 3 and tgt_xyz.is_contiguous()
+        n = tgt_xyz.shape[0]
+        idx = torch.empty((n, k), dtype=torch.int32, device=tgt_xyz.device)
+        d2 = torch.empty((n, k), dtype=torch.float64, device=tgt_xyz.device)
+        _call("atx_knn_query", _ptr(self._ws), self.n_src, _ptr(tgt_xyz), n, k, _ptr(idx), _ptr(d2), _stream())
+        return idx, d2
 
 
 def reduce(x, red: int, n: int | None = None) -> float:

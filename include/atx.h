@@ -227,6 +227,20 @@ typedef enum { ATX_RED_MIN = 0, ATX_RED_MAX = 1, ATX_RED_NANCOUNT = 2 } atx_red;
  *      tests/field_filters/test_apply_mask.py:106 `np.sum(np.isnan(result))` */
 int atx_reduce(const void* x, int64_t n, int red, double* result, int dtype, void* stream);
 
+/* ---- k-nearest-neighbour index build ---------------------------------------- */
+/* Exact k-NN on the unit sphere by chord distance — device counterpart of
+ *   R: spatial.py:587-635  cKDTree(source_xyz).query(target_xyz, k [, distance_upper_bound])
+ * xyz arrays are float64 [n, 3] computed on the host as R: spatial.py:132-167 does.
+ * atx_knn_build sorts the sources along a Morton curve and builds an implicit box tree in
+ * `workspace` (atx_knn_workspace_bytes(n_src) bytes, 256-byte aligned, owned by the caller,
+ * reusable for any number of queries).  atx_knn_query writes, per target, the k nearest
+ * source indices (int32, ascending distance, ties by lower index, n_src if fewer than k
+ * exist) and their SQUARED distances, bit-identical to scipy's float64 arithmetic. */
+size_t atx_knn_workspace_bytes(int64_t n_src);
+int atx_knn_build(const double* src_xyz, int64_t n_src, void* workspace, size_t workspace_bytes, void* stream);
+int atx_knn_query(const void* workspace, int64_t n_src, const double* tgt_xyz, int64_t n_tgt, int32_t k,
+                  int32_t* idx_out, double* d2_out, void* stream);
+
 /* ---- layout --------------------------------------------------------------- */
 /* dst[p, l] = src[p, l] between layouts / pitches (LDS-tiled transpose when the
  * layouts differ, strided copy when they agree).  No reference counterpart:
