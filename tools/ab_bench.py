@@ -79,8 +79,16 @@ def main():
 
         combos = [(name, tile) for name in libs for tile in args.tiles]
         times = {c: [] for c in combos}
-        for c in combos:  # warm-up
+        ref_out = None
+        for c in combos:  # warm-up + every variant must produce the same bits
+            out.data.fill_(float("nan"))
             run(libs[c[0]], c[1])
+            torch.cuda.synchronize()
+            if ref_out is None:
+                ref_out = out.data.clone()
+            else:
+                same = torch.equal(out.data.view(torch.int32 if not f64 else torch.int64), ref_out.view(torch.int32 if not f64 else torch.int64))
+                assert same, f"variant {c} differs from {combos[0]}"
         torch.cuda.synchronize()
         for _ in range(args.rounds):
             for c in combos:
