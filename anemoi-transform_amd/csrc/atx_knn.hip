@@ -54,8 +54,8 @@ static KnnHeader knn_layout(int64_t n_src) {
     h.off_vals_in = off;    off = align256(off + (size_t)n_src * sizeof(int32_t));
     h.off_tmp = off;
     size_t tmp = 0;
-    hipcub::DeviceRadixSort::SortPairs(nullptr, tmp, (const uint64_t*)nullptr, (uint64_t*)nullptr, (const int32_t*)nullptr,
-                                       (int32_t*)nullptr, (int)n_src, 0, 63);
+    (void)hipcub::DeviceRadixSort::SortPairs(nullptr, tmp, (const uint64_t*)nullptr, (uint64_t*)nullptr, (const int32_t*)nullptr,
+                                             (int32_t*)nullptr, (int)n_src, 0, 63);
     h.tmp_bytes = tmp;
     h.total_bytes = align256(off + tmp);
     return h;

@@ -36,6 +36,10 @@ namespace atx {
 #ifndef ATX_NO_XCD
 #define ATX_NO_XCD 0
 #endif
+#ifndef ATX_ELL_BLOCK
+#define ATX_ELL_BLOCK 256
+#endif
+constexpr int kEllBlock = ATX_ELL_BLOCK;  // lanes per workgroup of the columns ELL kernel
 constexpr int kUnroll = ATX_UNROLL;  // items in flight per lane (columns kernels)
 
 template <typename T, int N>
@@ -80,7 +84,7 @@ __device__ __forceinline__ T load_once(const T* p) {
 // ATX_COLUMNS, fixed k (ELL).  K > 0: compile-time k; K == 0: runtime k.
 // ---------------------------------------------------------------------------------
 template <typename T, int VEC, int K, bool WEIGHTED, bool EPI>
-__global__ void __launch_bounds__(kBlock)
+__global__ void __launch_bounds__(kEllBlock)
 regrid_cols_ell_kernel(const T* __restrict__ src, T* __restrict__ out,
                        const int32_t* __restrict__ idx, const T* __restrict__ w,
                        int64_t n_tgt, int k_rt, int n_lev, int C,
@@ -105,13 +109,13 @@ regrid_cols_ell_kernel(const T* __restrict__ src, T* __restrict__ out,
     const int nt = (int)min((int64_t)tile, n_tgt - t0);
     const int tid = threadIdx.x;
 
-    for (int i = tid; i < nt * k; i += kBlock) {
+    for (int i = tid; i < nt * k; i += kEllBlock) {
         idx_s[i] = load_once(idx + t0 * k + i);
         if (WEIGHTED) w_s[i] = load_once(w + t0 * k + i);
     }
     if (EPI) {
         const int n_slots = C * VEC;
-        for (int i = tid; i < n_stage * n_slots; i += kBlock) {
+        for (int i = tid; i < n_stage * n_slots; i += kEllBlock) {
             const int s = i / n_slots, l = i - s * n_slots;
             LevelOp<T> o;
             if (l < n_lev) {
@@ -125,17 +129,17 @@ regrid_cols_ell_kernel(const T* __restrict__ src, T* __restrict__ out,
     __syncthreads();
 
     const int items = nt * C;
-    const int dt = kBlock / C;
-    const int dc = kBlock - dt * C;
+    const int dt = kEllBlock / C;
+    const int dc = kEllBlock - dt * C;
     int t = tid / C;
     int c = tid - t * C;
 
-    for (int q = tid; q < items; q += kBlock * kUnroll) {
+    for (int q = tid; q < items; q += kEllBlock * kUnroll) {
         int tt[kUnroll], cc[kUnroll];
         bool ok[kUnroll];
 #pragma unroll
         for (int u = 0; u < kUnroll; ++u) {
-            ok[u] = (q + u * kBlock) < items;
+            ok[u] = (q + u * kEllBlock) < items;
             tt[u] = ok[u] ? t : 0;
             cc[u] = ok[u] ? c : 0;
             t += dt;
@@ -420,10 +424,10 @@ check_indices_kernel(const int32_t* __restrict__ idx, int64_t n, int64_t n_src, 
 static int pick_tile(int64_t n_tgt, int C) {
     // Small tiles win: ~560 (target, vector) items per 256-lane workgroup, i.e. 16 targets of
     // 137 f32 levels, rounded up to a multiple of 4 targets (measured on O1280 -> 0.25 deg:
-    // tiles of 12 / 16 beat 10, 14, 18-32 — profiles/r01_ab_variants.log).  More, shorter
+    // tiles of 12 / 16 beat 10, 14, 18-32; 64/128/512-lane workgroups reach the same plateau at
+    // the same items-per-lane ratio — profiles/r01_ab_variants.log, r01_ab_block_sizes.log).  More, shorter
     // workgroups keep more of them in different phases (index staging / gather / store).
-    int tile = (560 + C - 1) / C;
-    tile = (tile + 3) / 4 * 4;
+    int tile = (560 / C + 2) / 4 * 4;  // nearest multiple of 4 targets: 16 for 137 f32 levels, 8 for 137 f64 levels
     if (tile < 8) tile = 8;
     if (tile > 256) tile = 256;
     if ((int64_t)tile > n_tgt) tile = (int)n_tgt;
@@ -445,10 +449,10 @@ static int launch_cols_ell(const T* src, T* out, const int32_t* idx, const T* w,
     if (prog) lds += (size_t)n_stage * C * VEC * sizeof(LevelOp<T>);
     ATX_REQUIRE(lds <= 64 * 1024, ATX_ENOTIMPL, "regrid_ell: tile needs %zu B of LDS (k=%d, n_lev=%d, stages=%d)", lds, k, n_lev, n_stage);
     if (prog) {
-        hipLaunchKernelGGL((regrid_cols_ell_kernel<T, VEC, K, WEIGHTED, true>), dim3(n_tiles), dim3(kBlock), lds, stream,
+        hipLaunchKernelGGL((regrid_cols_ell_kernel<T, VEC, K, WEIGHTED, true>), dim3(n_tiles), dim3(kEllBlock), lds, stream,
                            src, out, idx, w, n_tgt, k, n_lev, C, src_pitch, out_pitch, tile, n_tiles, prog, n_stage, tgt_mask);
     } else {
-        hipLaunchKernelGGL((regrid_cols_ell_kernel<T, VEC, K, WEIGHTED, false>), dim3(n_tiles), dim3(kBlock), lds, stream,
+        hipLaunchKernelGGL((regrid_cols_ell_kernel<T, VEC, K, WEIGHTED, false>), dim3(n_tiles), dim3(kEllBlock), lds, stream,
                            src, out, idx, w, n_tgt, k, n_lev, C, src_pitch, out_pitch, tile, n_tiles, prog, n_stage, tgt_mask);
     }
     ATX_LAUNCH_CHECK("regrid_cols_ell");
