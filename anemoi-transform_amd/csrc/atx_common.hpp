@@ -124,4 +124,108 @@ __device__ __forceinline__ T apply_level_op(const LevelOp<T>& o, T x, bool maske
     return y;
 }
 
+
+// The same operator applied to a whole 16-byte vector: ONE dispatch on the operator instead of
+// one per element (the per-level programs of real pipelines are uniform over the levels a vector
+// spans almost always; kernels fall back to apply_level_op per element when they are not).
+template <typename T, int VEC>
+__device__ __forceinline__ void apply_level_op_vec(const LevelOp<T>& o, Pack<T, VEC>& v, bool masked) {
+    switch (o.op) {
+        case ATX_OP_COPY: break;
+        case ATX_OP_AFFINE:
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) v.v[e] = v.v[e] * o.p0 + o.p1;
+            break;
+        case ATX_OP_AFFINE_INV:
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) v.v[e] = (v.v[e] - o.p1) / o.p0;
+            break;
+        case ATX_OP_MUL:
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) v.v[e] = v.v[e] * o.p0;
+            break;
+        case ATX_OP_DIV:
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) v.v[e] = v.v[e] / o.p0;
+            break;
+        case ATX_OP_CLIP:
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) {
+                T y = v.v[e];
+                if (o.p0 == o.p0) y = (y < o.p0) ? o.p0 : y;
+                if (o.p1 == o.p1) y = (y > o.p1) ? o.p1 : y;
+                v.v[e] = y;
+            }
+            break;
+        case ATX_OP_IMPUTE_NAN:
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) v.v[e] = (v.v[e] != v.v[e]) ? o.p0 : v.v[e];
+            break;
+        case ATX_OP_EXP:
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) v.v[e] = exp(v.v[e]);
+            break;
+        case ATX_OP_LOG:
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) v.v[e] = log(v.v[e]);
+            break;
+        case ATX_OP_SET_NAN:
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) v.v[e] = quiet_nan<T>();
+            break;
+        default: break;
+    }
+    if (o.use_mask && masked) {
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) v.v[e] = quiet_nan<T>();
+    }
+}
+
+constexpr int kOpMixed = -1;  // marker in a per-vector operator table: the vector's levels differ
+
+__device__ __forceinline__ bool same_bits(float a, float b) { return __float_as_uint(a) == __float_as_uint(b); }
+__device__ __forceinline__ bool same_bits(double a, double b) { return __double_as_longlong(a) == __double_as_longlong(b); }
+
+// Per-vector-column view of a per-level program, built straight from global memory into LDS in ONE
+// pass (the workgroups that use it are short-lived, their prologue must stay cheap):
+// vec_ops[s*C + c] = the operator shared by the levels c*VEC .. c*VEC+VEC-1 at stage s (padding
+// levels >= n_lev join any operator), or op = kOpMixed when they differ.
+template <typename T, int VEC>
+__device__ __forceinline__ void build_vector_ops(const atx_level_op* __restrict__ prog, LevelOp<T>* __restrict__ vec_ops,
+                                                 int n_stage, int n_lev, int C, int tid, int n_threads) {
+    for (int i = tid; i < n_stage * C; i += n_threads) {
+        const int s = i / C, c = i - s * C;
+        const int64_t base = (int64_t)s * n_lev + (int64_t)c * VEC;
+        LevelOp<T> o = load_level_op<T>(prog, base);
+        bool same = true;
+#pragma unroll
+        for (int e = 1; e < VEC; ++e) {
+            if (c * VEC + e >= n_lev) continue;
+            const LevelOp<T> q = load_level_op<T>(prog, base + e);
+            same = same && q.op == o.op && q.use_mask == o.use_mask && same_bits(q.p0, o.p0) && same_bits(q.p1, o.p1);
+        }
+        if (!same) o.op = kOpMixed;
+        vec_ops[i] = o;
+    }
+}
+
+// Apply all stages to one vector of column c: vector-uniform stages through ONE dispatch, mixed ones
+// per element straight from the global program (rare).
+template <typename T, int VEC>
+__device__ __forceinline__ void apply_program_vec(const LevelOp<T>* __restrict__ vec_ops, const atx_level_op* __restrict__ prog,
+                                                  int n_stage, int n_lev, int C, int c, Pack<T, VEC>& v, bool masked) {
+    for (int s = 0; s < n_stage; ++s) {
+        const LevelOp<T> o = vec_ops[s * C + c];
+        if (o.op != kOpMixed) {
+            apply_level_op_vec<T, VEC>(o, v, masked);
+        } else {
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) {
+                const int l = c * VEC + e;
+                if (l < n_lev) v.v[e] = apply_level_op(load_level_op<T>(prog, (int64_t)s * n_lev + l), v.v[e], masked);
+            }
+        }
+    }
+}
+
 }  // namespace atx

@@ -16,7 +16,15 @@ namespace atx {
 
 constexpr int kMaxGrid = 256 * 8;  // 256 CUs x 8 workgroups
 
-// ATX_COLUMNS: item = (point p, vector c); consecutive lanes = consecutive 16 B.
+// ATX_COLUMNS.  A workgroup sweeps CONTIGUOUS chunks of rows (points).  Its lanes are laid over
+// (row-in-pass, vector column): lane = r*Cg + c with Cg = min(C, 256) columns per pass and
+// 256/Cg rows per pass, so consecutive lanes touch consecutive 16 B, a lane keeps its column(s) — its
+// operators are loop invariant — and the kPwUnroll loads a lane has in flight are adjacent passes of
+// the same chunk (NOT megabytes apart: a fixed large power-of-two distance between a lane's
+// concurrent streams aliases onto the same HBM channels and cost 25 % here).  HBM-bound; what the
+// kernel needs is memory-level parallelism: 4 independent 16-byte loads per lane.
+constexpr int kPwUnroll = 4;
+
 template <typename T, int VEC>
 __global__ void __launch_bounds__(kBlock)
 pointwise_cols_kernel(const T* __restrict__ x, T* __restrict__ y, int64_t n_pts, int n_lev, int C,
@@ -24,55 +32,46 @@ pointwise_cols_kernel(const T* __restrict__ x, T* __restrict__ y, int64_t n_pts,
                       const uint8_t* __restrict__ point_mask, int in_place) {
     using V = Pack<T, VEC>;
     extern __shared__ __align__(16) unsigned char smem[];
-    LevelOp<T>* prog_s = reinterpret_cast<LevelOp<T>*>(smem);
-    const int n_slots = C * VEC;
-    uint8_t* active_s = reinterpret_cast<uint8_t*>(prog_s + (size_t)n_stage * n_slots);  // per vector column
+    LevelOp<T>* vec_ops = reinterpret_cast<LevelOp<T>*>(smem);  // [n_stage][C]
     const int tid = threadIdx.x;
-    for (int i = tid; i < n_stage * n_slots; i += kBlock) {
-        const int s = i / n_slots, l = i - s * n_slots;
-        LevelOp<T> o;
-        if (l < n_lev) {
-            o = load_level_op<T>(prog, (int64_t)s * n_lev + l);
-        } else {
-            o.op = ATX_OP_COPY; o.use_mask = 0; o.p0 = 0; o.p1 = 0;
-        }
-        prog_s[i] = o;
-    }
-    __syncthreads();
-    for (int c = tid; c < C; c += kBlock) {
-        bool act = false;
-        for (int s = 0; s < n_stage; ++s)
-            for (int e = 0; e < VEC; ++e) {
-                const LevelOp<T>& o = prog_s[s * n_slots + c * VEC + e];
-                act = act || (o.op != ATX_OP_COPY) || (o.use_mask != 0);
-            }
-        active_s[c] = act ? 1 : 0;
-    }
+    build_vector_ops<T, VEC>(prog, vec_ops, n_stage, n_lev, C, tid, kBlock);
     __syncthreads();
 
-    const int64_t stride = (int64_t)gridDim.x * kBlock;
-    const int64_t dp = stride / C;
-    const int dc = (int)(stride - dp * C);
-    const int64_t q0 = (int64_t)blockIdx.x * kBlock + tid;
-    int64_t p = q0 / C;
-    int c = (int)(q0 - p * C);
-    while (p < n_pts) {
-        const bool act = active_s[c] != 0;
-        if (act || !in_place) {
-            V v = *reinterpret_cast<const V*>(x + p * x_pitch + (int64_t)c * VEC);
-            if (act) {
-                const bool masked = point_mask ? (point_mask[p] != 0) : false;
-                for (int s = 0; s < n_stage; ++s) {
-#pragma unroll
-                    for (int e = 0; e < VEC; ++e)
-                        v.v[e] = apply_level_op(prog_s[s * n_slots + c * VEC + e], v.v[e], masked);
-                }
-            }
-            *reinterpret_cast<V*>(y + p * y_pitch + (int64_t)c * VEC) = v;
+    const int Cg = C < kBlock ? C : kBlock;
+    const int rows_per_pass = kBlock / Cg;
+    const int r = tid / Cg;
+    const int cl = tid - r * Cg;
+    if (r >= rows_per_pass) return;  // lanes beyond the last whole row of a pass idle (after the barrier)
+    const int64_t chunk = (int64_t)rows_per_pass * kPwUnroll;
+
+    for (int c = cl; c < C; c += Cg) {
+        bool act = false;
+        for (int s = 0; s < n_stage; ++s) {
+            const LevelOp<T> o = vec_ops[s * C + c];
+            act = act || o.op != ATX_OP_COPY || o.use_mask != 0;
         }
-        p += dp;
-        c += dc;
-        if (c >= C) { c -= C; ++p; }
+        if (!act && in_place) continue;  // untouched levels of an in-place call: nothing to move
+        for (int64_t row0 = (int64_t)blockIdx.x * chunk; row0 < n_pts; row0 += (int64_t)gridDim.x * chunk) {
+            V v[kPwUnroll];
+            int64_t pp[kPwUnroll];
+            bool ok[kPwUnroll];
+#pragma unroll
+            for (int u = 0; u < kPwUnroll; ++u) {
+                pp[u] = row0 + (int64_t)u * rows_per_pass + r;
+                ok[u] = pp[u] < n_pts;
+                if (!ok[u]) pp[u] = row0;
+                v[u] = *reinterpret_cast<const V*>(x + pp[u] * x_pitch + (int64_t)c * VEC);
+            }
+#pragma unroll
+            for (int u = 0; u < kPwUnroll; ++u) {
+                if (!ok[u]) continue;
+                if (act) {
+                    const bool masked = point_mask ? (point_mask[pp[u]] != 0) : false;
+                    apply_program_vec<T, VEC>(vec_ops, prog, n_stage, n_lev, C, c, v[u], masked);
+                }
+                *reinterpret_cast<V*>(y + pp[u] * y_pitch + (int64_t)c * VEC) = v[u];
+            }
+        }
     }
 }
 
@@ -94,16 +93,30 @@ pointwise_fields_kernel(const T* __restrict__ x, T* __restrict__ y, int64_t n_pt
     const T* xs = x + (int64_t)l * x_pitch;
     T* ys = y + (int64_t)l * y_pitch;
     const int64_t n_vec = n_pts / VEC;
-    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n_vec; i += (int64_t)gridDim.x * kBlock) {
-        V v = *reinterpret_cast<const V*>(xs + i * VEC);
-        if (act) {
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    for (int64_t i0 = (int64_t)blockIdx.x * kBlock + threadIdx.x; i0 < n_vec; i0 += stride * kPwUnroll) {
+        V v[kPwUnroll];
+        int64_t ii[kPwUnroll];
+        bool ok[kPwUnroll];
 #pragma unroll
-            for (int e = 0; e < VEC; ++e) {
-                const bool masked = point_mask ? (point_mask[i * VEC + e] != 0) : false;
-                for (int s = 0; s < n_stage; ++s) v.v[e] = apply_level_op(ops[s], v.v[e], masked);
-            }
+        for (int u = 0; u < kPwUnroll; ++u) {
+            ii[u] = i0 + (int64_t)u * stride;
+            ok[u] = ii[u] < n_vec;
+            if (!ok[u]) ii[u] = i0;
+            v[u] = *reinterpret_cast<const V*>(xs + ii[u] * VEC);
         }
-        *reinterpret_cast<V*>(ys + i * VEC) = v;
+#pragma unroll
+        for (int u = 0; u < kPwUnroll; ++u) {
+            if (!ok[u]) continue;
+            if (act) {
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) {
+                    const bool masked = point_mask ? (point_mask[ii[u] * VEC + e] != 0) : false;
+                    for (int s = 0; s < n_stage; ++s) v[u].v[e] = apply_level_op(ops[s], v[u].v[e], masked);
+                }
+            }
+            *reinterpret_cast<V*>(ys + ii[u] * VEC) = v[u];
+        }
     }
     // tail points (n_pts % VEC) by the first lanes of block 0
     if (blockIdx.x == 0) {
@@ -324,19 +337,20 @@ static int pointwise_typed(const void* x_, void* y_, int64_t n_pts, int n_lev, i
     const bool vec_ok = aligned16(x_) && aligned16(y_) && (xp % VEC == 0) && (yp % VEC == 0);
     if (layout == ATX_COLUMNS) {
         const int64_t covered = ((int64_t)(n_lev + VEC - 1) / VEC) * VEC;
-        if (vec_ok && covered <= xp && covered <= yp) {
-            const int C = (n_lev + VEC - 1) / VEC;
-            const size_t lds = (size_t)n_stage * C * VEC * sizeof(LevelOp<T>) + (size_t)C;
-            ATX_REQUIRE(lds <= 64 * 1024, ATX_ENOTIMPL, "pointwise: program needs %zu B of LDS", lds);
-            hipLaunchKernelGGL((pointwise_cols_kernel<T, VEC>), dim3(grid_for(n_pts * C)), dim3(kBlock), lds, st, x, y, n_pts,
-                               n_lev, C, xp, yp, prog, n_stage, mask, in_place);
-        } else {
-            const int C = n_lev;
-            const size_t lds = (size_t)n_stage * C * sizeof(LevelOp<T>) + (size_t)C;
-            ATX_REQUIRE(lds <= 64 * 1024, ATX_ENOTIMPL, "pointwise: program needs %zu B of LDS", lds);
-            hipLaunchKernelGGL((pointwise_cols_kernel<T, 1>), dim3(grid_for(n_pts * C)), dim3(kBlock), lds, st, x, y, n_pts,
-                               n_lev, C, xp, yp, prog, n_stage, mask, in_place);
-        }
+        const bool wide = vec_ok && covered <= xp && covered <= yp;
+        const int C = wide ? (n_lev + VEC - 1) / VEC : n_lev;
+        const size_t lds = (size_t)n_stage * C * sizeof(LevelOp<T>);
+        ATX_REQUIRE(lds <= 64 * 1024, ATX_ENOTIMPL, "pointwise: program needs %zu B of LDS", lds);
+        const int Cg = C < kBlock ? C : kBlock;
+        const int64_t chunk = (int64_t)(kBlock / Cg) * kPwUnroll;  // rows one workgroup moves per iteration
+        int64_t blocks = (n_pts + chunk - 1) / chunk;
+        if (blocks > kMaxGrid) blocks = kMaxGrid;
+        if (wide)
+            hipLaunchKernelGGL((pointwise_cols_kernel<T, VEC>), dim3((unsigned)blocks), dim3(kBlock), lds, st, x, y, n_pts, n_lev, C, xp,
+                               yp, prog, n_stage, mask, in_place);
+        else
+            hipLaunchKernelGGL((pointwise_cols_kernel<T, 1>), dim3((unsigned)blocks), dim3(kBlock), lds, st, x, y, n_pts, n_lev, C, xp,
+                               yp, prog, n_stage, mask, in_place);
     } else {
         ATX_REQUIRE(n_lev <= 65535, ATX_ENOTIMPL, "pointwise: n_lev=%d exceeds grid.y", n_lev);
         unsigned gx = grid_for((n_pts + VEC - 1) / VEC);

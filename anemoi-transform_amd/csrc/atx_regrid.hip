@@ -92,6 +92,9 @@ regrid_cols_ell_kernel(const T* __restrict__ src, T* __restrict__ out,
                        const atx_level_op* __restrict__ prog, int n_stage,
                        const uint8_t* __restrict__ tgt_mask) {
     using V = Pack<T, VEC>;
+    // items in flight per lane: the epilogue variant trades half of them for registers (its operator
+    // dispatch would otherwise push the kernel from 5 to 2-4 waves per SIMD; 2 vs 4 in flight costs ~1 %)
+    constexpr int kU = EPI ? (kUnroll > 2 ? 2 : kUnroll) : kUnroll;
     extern __shared__ __align__(16) unsigned char smem[];
     const int k = K > 0 ? K : k_rt;
     // LDS carve: weights (widest type first), indices, then the level program
@@ -113,19 +116,8 @@ regrid_cols_ell_kernel(const T* __restrict__ src, T* __restrict__ out,
         idx_s[i] = load_once(idx + t0 * k + i);
         if (WEIGHTED) w_s[i] = load_once(w + t0 * k + i);
     }
-    if (EPI) {
-        const int n_slots = C * VEC;
-        for (int i = tid; i < n_stage * n_slots; i += kEllBlock) {
-            const int s = i / n_slots, l = i - s * n_slots;
-            LevelOp<T> o;
-            if (l < n_lev) {
-                o = load_level_op<T>(prog, (int64_t)s * n_lev + l);
-            } else {
-                o.op = ATX_OP_COPY; o.use_mask = 0; o.p0 = 0; o.p1 = 0;
-            }
-            prog_s[i] = o;
-        }
-    }
+    LevelOp<T>* vops_s = prog_s;  // [n_stage][C] vector-column operators
+    if (EPI) build_vector_ops<T, VEC>(prog, vops_s, n_stage, n_lev, C, tid, kEllBlock);
     __syncthreads();
 
     const int items = nt * C;
@@ -134,11 +126,11 @@ regrid_cols_ell_kernel(const T* __restrict__ src, T* __restrict__ out,
     int t = tid / C;
     int c = tid - t * C;
 
-    for (int q = tid; q < items; q += kEllBlock * kUnroll) {
-        int tt[kUnroll], cc[kUnroll];
-        bool ok[kUnroll];
+    for (int q = tid; q < items; q += kEllBlock * kU) {
+        int tt[kU], cc[kU];
+        bool ok[kU];
 #pragma unroll
-        for (int u = 0; u < kUnroll; ++u) {
+        for (int u = 0; u < kU; ++u) {
             ok[u] = (q + u * kEllBlock) < items;
             tt[u] = ok[u] ? t : 0;
             cc[u] = ok[u] ? c : 0;
@@ -147,12 +139,12 @@ regrid_cols_ell_kernel(const T* __restrict__ src, T* __restrict__ out,
             if (c >= C) { c -= C; ++t; }
         }
 
-        V acc[kUnroll];
+        V acc[kU];
         if (K > 0) {
-            // all K*kUnroll loads are independent: issue them before any arithmetic
-            V v[kUnroll][K > 0 ? K : 1];
+            // all K*kU loads are independent: issue them before any arithmetic
+            V v[kU][K > 0 ? K : 1];
 #pragma unroll
-            for (int u = 0; u < kUnroll; ++u) {
+            for (int u = 0; u < kU; ++u) {
 #pragma unroll
                 for (int j = 0; j < (K > 0 ? K : 1); ++j) {
                     const int64_t p = idx_s[tt[u] * K + j];
@@ -160,7 +152,7 @@ regrid_cols_ell_kernel(const T* __restrict__ src, T* __restrict__ out,
                 }
             }
 #pragma unroll
-            for (int u = 0; u < kUnroll; ++u) {
+            for (int u = 0; u < kU; ++u) {
                 if (WEIGHTED) {
 #pragma unroll
                     for (int e = 0; e < VEC; ++e) acc[u].v[e] = T(0);
@@ -176,7 +168,7 @@ regrid_cols_ell_kernel(const T* __restrict__ src, T* __restrict__ out,
             }
         } else {
 #pragma unroll
-            for (int u = 0; u < kUnroll; ++u) {
+            for (int u = 0; u < kU; ++u) {
 #pragma unroll
                 for (int e = 0; e < VEC; ++e) acc[u].v[e] = T(0);
                 const int base = tt[u] * k;
@@ -203,15 +195,11 @@ regrid_cols_ell_kernel(const T* __restrict__ src, T* __restrict__ out,
         }
 
 #pragma unroll
-        for (int u = 0; u < kUnroll; ++u) {
+        for (int u = 0; u < kU; ++u) {
             if (!ok[u]) continue;
             if (EPI) {
                 const bool masked = tgt_mask ? (tgt_mask[t0 + tt[u]] != 0) : false;
-                for (int s = 0; s < n_stage; ++s) {
-#pragma unroll
-                    for (int e = 0; e < VEC; ++e)
-                        acc[u].v[e] = apply_level_op(prog_s[s * C * VEC + cc[u] * VEC + e], acc[u].v[e], masked);
-                }
+                apply_program_vec<T, VEC>(vops_s, prog, n_stage, n_lev, C, cc[u], acc[u], masked);
             }
             store_out(reinterpret_cast<V*>(out + (t0 + tt[u]) * out_pitch + (int64_t)cc[u] * VEC), acc[u]);
         }
@@ -245,19 +233,8 @@ regrid_cols_csr_kernel(const T* __restrict__ src, T* __restrict__ out,
     const int tid = threadIdx.x;
 
     for (int i = tid; i <= nt; i += kBlock) rp_s[i] = indptr[t0 + i];
-    if (EPI) {
-        const int n_slots = C * VEC;
-        for (int i = tid; i < n_stage * n_slots; i += kBlock) {
-            const int s = i / n_slots, l = i - s * n_slots;
-            LevelOp<T> o;
-            if (l < n_lev) {
-                o = load_level_op<T>(prog, (int64_t)s * n_lev + l);
-            } else {
-                o.op = ATX_OP_COPY; o.use_mask = 0; o.p0 = 0; o.p1 = 0;
-            }
-            prog_s[i] = o;
-        }
-    }
+    LevelOp<T>* vops_s = prog_s;  // [n_stage][C] vector-column operators
+    if (EPI) build_vector_ops<T, VEC>(prog, vops_s, n_stage, n_lev, C, tid, kBlock);
     __syncthreads();
     const int64_t base = rp_s[0];
     const int nnz_tile = rp_s[nt] - rp_s[0];
@@ -305,11 +282,7 @@ regrid_cols_csr_kernel(const T* __restrict__ src, T* __restrict__ out,
         }
         if (EPI) {
             const bool masked = tgt_mask ? (tgt_mask[t0 + t] != 0) : false;
-            for (int s = 0; s < n_stage; ++s) {
-#pragma unroll
-                for (int e = 0; e < VEC; ++e)
-                    acc.v[e] = apply_level_op(prog_s[s * C * VEC + c * VEC + e], acc.v[e], masked);
-            }
+            apply_program_vec<T, VEC>(vops_s, prog, n_stage, n_lev, C, c, acc, masked);
         }
         store_out(reinterpret_cast<V*>(out + (t0 + t) * out_pitch + (int64_t)c * VEC), acc);
     }
@@ -446,7 +419,7 @@ static int launch_cols_ell(const T* src, T* out, const int32_t* idx, const T* w,
     const unsigned n_tiles = (unsigned)((n_tgt + tile - 1) / tile);
     size_t lds = (size_t)tile * k * (sizeof(int32_t) + (WEIGHTED ? sizeof(T) : 0));
     lds = (lds + 15) & ~size_t(15);
-    if (prog) lds += (size_t)n_stage * C * VEC * sizeof(LevelOp<T>);
+    if (prog) lds += (size_t)n_stage * C * sizeof(LevelOp<T>);
     ATX_REQUIRE(lds <= 64 * 1024, ATX_ENOTIMPL, "regrid_ell: tile needs %zu B of LDS (k=%d, n_lev=%d, stages=%d)", lds, k, n_lev, n_stage);
     if (prog) {
         hipLaunchKernelGGL((regrid_cols_ell_kernel<T, VEC, K, WEIGHTED, true>), dim3(n_tiles), dim3(kEllBlock), lds, stream,
@@ -551,7 +524,7 @@ static int launch_cols_csr(const T* src, T* out, const int32_t* indptr, const in
     if (cap > 4096) cap = 4096;
     size_t lds = (size_t)cap * (sizeof(T) + sizeof(int32_t)) + (size_t)(tile + 1) * sizeof(int32_t);
     lds = (lds + 15) & ~size_t(15);
-    if (prog) lds += (size_t)n_stage * C * VEC * sizeof(LevelOp<T>);
+    if (prog) lds += (size_t)n_stage * C * sizeof(LevelOp<T>);
     ATX_REQUIRE(lds <= 64 * 1024, ATX_ENOTIMPL, "regrid_csr: tile needs %zu B of LDS", lds);
     if (prog) {
         hipLaunchKernelGGL((regrid_cols_csr_kernel<T, VEC, true>), dim3(n_tiles), dim3(kBlock), lds, st, src, out, indptr,

@@ -1,0 +1,134 @@
+#!/usr/bin/env python3
+"""Per-kernel timing of libatx at BASELINE sizes (O1280 stack of 137 levels), with the HBM roofline
+fraction of each on its ALGORITHMIC bytes.  One JSON document on stdout / --out.
+
+    python tools/kernel_bench.py --out gpurun_out/kernels.json
+"""
+
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import __graft_entry__ as graft  # noqa: E402
+import bench  # noqa: E402
+
+PEAK = 8e12
+
+
+def timeit(fn, n=10, warm=2):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(n):
+        fn()
+    b.record()
+    torch.cuda.synchronize()
+    return a.elapsed_time(b) / n
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--out", default=None)
+    ap.add_argument("--levels", type=int, default=137)
+    args = ap.parse_args()
+    graft.load_package()
+    from anemoi_transform_amd import interp, native
+    from anemoi_transform_amd.gather import GatherPlan
+    from anemoi_transform_amd.grids import lookup
+    from anemoi_transform_amd.stack import COLUMNS, FIELDS, Stack
+
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    L = args.levels
+    src_grid, tgt_grid = lookup("o1280"), lookup("0.25")
+    n_src, n_tgt = len(src_grid["latitudes"]), len(tgt_grid["latitudes"])
+    idx, w = interp.knn_inverse_distance(src_grid, tgt_grid, k=4)
+    res = {}
+
+    def record(name, ms, alg_bytes, note=""):
+        res[name] = {"ms": ms, "algorithmic_bytes": alg_bytes, "GBs": alg_bytes / ms / 1e6, "frac_of_8TBs": alg_bytes / (ms * 1e-3) / PEAK,
+                     "note": note}
+        print(f"{name:42s} {ms:9.4f} ms  {alg_bytes / ms / 1e6:9.1f} GB/s  frac {alg_bytes / (ms * 1e-3) / PEAK:.3f}  {note}", flush=True)
+
+    for tdt, npdt, B, tag in ((torch.float32, np.float32, 4, "f32"), (torch.float64, np.float64, 8, "f64")):
+        x = bench.synth_stack(src_grid, L, tdt, dev, 0, COLUMNS)
+        U4, U1 = int(np.unique(idx).size), int(np.unique(idx[:, 0]).size)
+        # ---- regrid variants
+        plan4 = GatherPlan(n_src, n_tgt, index=idx, weights=w)
+        plan1 = GatherPlan(n_src, n_tgt, index=idx[:, 0])
+        record(f"regrid_ell k=4 {tag} columns", timeit(lambda: plan4.apply(x)), bench.algorithmic_bytes(L, B, U4, n_tgt, 4), "incl. output allocation")
+        record(f"regrid_ell k=1 {tag} columns", timeit(lambda: plan1.apply(x)), bench.algorithmic_bytes(L, B, U1, n_tgt, 1))
+        keep = (np.arange(idx.size) % 9 != 0).reshape(idx.shape)
+        indptr = np.concatenate([[0], np.cumsum(keep.sum(axis=1))])
+        csr = GatherPlan(n_src, n_tgt, csr=(w[keep], idx[keep], indptr))
+        nnz = int(keep.sum())
+        record(f"regrid_csr ragged(3-4) {tag} columns", timeit(lambda: csr.apply(x)),
+               L * B * (int(np.unique(idx[keep]).size) + n_tgt) + nnz * (4 + B) + 4 * n_tgt)
+        prog = native.level_program([[(native.OP_MUL, 0, 9.80665, 0.0)] * L, [(native.OP_AFFINE, 0, 1.0, -273.15)] * L], dev)
+        record(f"regrid_ell k=4 {tag} + 2-stage epilogue", timeit(lambda: plan4.apply(x, prog=prog, n_stage=2)),
+               bench.algorithmic_bytes(L, B, U4, n_tgt, 4), "fused regrid -> orog_to_z -> rescale")
+        # ---- per-point
+        y = x.new_like()
+        p1 = native.level_program([[(native.OP_AFFINE, 0, 1.0, -273.15)] * L], dev)
+        kw = dict(n_pts=n_src, n_lev=L, x_pitch=x.pitch, y_pitch=y.pitch, layout=COLUMNS)
+        stack_bytes = n_src * L * B
+        record(f"pointwise affine {tag} out-of-place", timeit(lambda: native.pointwise_stack(x.data, y.data, prog=p1, n_stage=1, **kw)), 2 * stack_bytes)
+        record(f"pointwise affine {tag} in-place", timeit(lambda: native.pointwise_stack(y.data, y.data, prog=p1, n_stage=1, **kw)), 2 * stack_bytes)
+        pm = (torch.rand(n_src + 8, device=dev) < 0.3).to(torch.uint8)
+        pmask = native.level_program([[(native.OP_COPY, 1, 0.0, 0.0)] * L], dev)
+        record(f"apply_mask {tag}", timeit(lambda: native.pointwise_stack(x.data, y.data, prog=pmask, n_stage=1, point_mask=pm, **kw)), 2 * stack_bytes + n_src)
+        one = native.level_program([[(native.OP_AFFINE, 0, 2.0, 1.0)] + [(native.OP_COPY, 0, 0.0, 0.0)] * (L - 1)], dev)
+        record(f"pointwise 1 of {L} levels selected {tag} in-place", timeit(lambda: native.pointwise_stack(y.data, y.data, prog=one, n_stage=1, **kw)),
+               2 * n_src * B, "untouched levels are skipped; 16-B vector granularity")
+        # ---- multi-input
+        z = x.new_like()
+        record(f"combine snow_cover (2->1) {tag}", timeit(lambda: native.combine_stack(native.COMB_SNOW_COVER, [x.data, y.data], [z.data],
+               n_pts=n_src, n_lev=L, pitch=x.pitch, layout=COLUMNS)), 3 * stack_bytes)
+        # ---- layout
+        f = Stack.empty(n_src, L, tdt, dev, FIELDS)
+        record(f"relayout columns->fields {tag}", timeit(lambda: native.relayout(x.data, f.data, n_pts=n_src, n_lev=L, src_pitch=x.pitch,
+               dst_pitch=f.pitch, src_layout=COLUMNS, dst_layout=FIELDS)), 2 * stack_bytes)
+        record(f"relayout fields->columns {tag}", timeit(lambda: native.relayout(f.data, y.data, n_pts=n_src, n_lev=L, src_pitch=f.pitch,
+               dst_pitch=y.pitch, src_layout=FIELDS, dst_layout=COLUMNS)), 2 * stack_bytes)
+        # ---- regrid on field-major
+        record(f"regrid_ell k=4 {tag} fields", timeit(lambda: plan4.apply(f)), bench.algorithmic_bytes(L, B, U4, n_tgt, 4))
+        # ---- masks / reductions on one field
+        first = f.data[0].contiguous()
+        mask = torch.empty(n_src + 8, dtype=torch.uint8, device=dev)
+        record(f"mask_build {tag} (1 field)", timeit(lambda: native.mask_build(first, mask, n=n_src, cmp=native.CMP_GT, threshold=280.0)), n_src * (B + 1))
+        record(f"reduce min {tag} (1 field)", timeit(lambda: native.reduce(first, native.RED_MIN)), n_src * B, "includes the device->host read of the result")
+        del x, y, z, f
+        torch.cuda.empty_cache()
+
+    m = (torch.rand(n_src, device=dev) < 0.7).to(torch.uint8)
+    cnt = int(m.sum().item())
+    record("mask_to_index (6.6M points, 70% kept)", timeit(lambda: native.mask_to_index(m, n_src)), 2 * n_src + 4 * cnt, "includes workspace allocation + count read-back")
+
+    # ---- k-NN precompute
+    sxyz = torch.from_numpy(np.ascontiguousarray(interp.unit_sphere_xyz(src_grid["latitudes"], src_grid["longitudes"]))).to(dev)
+    txyz = torch.from_numpy(np.ascontiguousarray(interp.unit_sphere_xyz(tgt_grid["latitudes"], tgt_grid["longitudes"]))).to(dev)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    index = native.KnnIndex(sxyz)
+    torch.cuda.synchronize()
+    res["knn_build O1280"] = {"ms": (time.perf_counter() - t0) * 1e3}
+    for k in (1, 4):
+        res[f"knn_query O1280->0.25 k={k}"] = {"ms": timeit(lambda: index.query(txyz, k), n=3, warm=1)}
+    print({k: v for k, v in res.items() if k.startswith("knn")})
+    if args.out:
+        json.dump(res, open(args.out, "w"), indent=1)
+
+
+if __name__ == "__main__":
+    main()
