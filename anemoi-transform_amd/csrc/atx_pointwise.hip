@@ -24,6 +24,36 @@ constexpr int kMaxGrid = 256 * 8;  // 256 CUs x 8 workgroups
 // concurrent streams aliases onto the same HBM channels and cost 25 % here).  HBM-bound; what the
 // kernel needs is memory-level parallelism: 4 independent 16-byte loads per lane.
 constexpr int kPwUnroll = 4;
+#ifndef ATX_PW_NT
+#define ATX_PW_NT 0  // 0: plain, 1: nt stores, 2: nt loads + nt stores
+#endif
+template <typename T, int N>
+struct PwNative {
+    typedef T type __attribute__((ext_vector_type(N)));
+};
+template <typename T>
+struct PwNative<T, 1> {
+    typedef T type;
+};
+template <typename T, int N>
+__device__ __forceinline__ Pack<T, N> pw_load(const T* p) {
+#if ATX_PW_NT >= 2
+    using NV = typename PwNative<T, N>::type;
+    NV v = __builtin_nontemporal_load(reinterpret_cast<const NV*>(p));
+    return *reinterpret_cast<Pack<T, N>*>(&v);
+#else
+    return *reinterpret_cast<const Pack<T, N>*>(p);
+#endif
+}
+template <typename T, int N>
+__device__ __forceinline__ void pw_store(T* p, const Pack<T, N>& v) {
+#if ATX_PW_NT >= 1
+    using NV = typename PwNative<T, N>::type;
+    __builtin_nontemporal_store(*reinterpret_cast<const NV*>(&v), reinterpret_cast<NV*>(p));
+#else
+    *reinterpret_cast<Pack<T, N>*>(p) = v;
+#endif
+}
 
 template <typename T, int VEC>
 __global__ void __launch_bounds__(kBlock)
@@ -60,7 +90,7 @@ pointwise_cols_kernel(const T* __restrict__ x, T* __restrict__ y, int64_t n_pts,
                 pp[u] = row0 + (int64_t)u * rows_per_pass + r;
                 ok[u] = pp[u] < n_pts;
                 if (!ok[u]) pp[u] = row0;
-                v[u] = *reinterpret_cast<const V*>(x + pp[u] * x_pitch + (int64_t)c * VEC);
+                v[u] = pw_load<T, VEC>(x + pp[u] * x_pitch + (int64_t)c * VEC);
             }
 #pragma unroll
             for (int u = 0; u < kPwUnroll; ++u) {
@@ -69,7 +99,7 @@ pointwise_cols_kernel(const T* __restrict__ x, T* __restrict__ y, int64_t n_pts,
                     const bool masked = point_mask ? (point_mask[pp[u]] != 0) : false;
                     apply_program_vec<T, VEC>(vec_ops, prog, n_stage, n_lev, C, c, v[u], masked);
                 }
-                *reinterpret_cast<V*>(y + pp[u] * y_pitch + (int64_t)c * VEC) = v[u];
+                pw_store<T, VEC>(y + pp[u] * y_pitch + (int64_t)c * VEC, v[u]);
             }
         }
     }

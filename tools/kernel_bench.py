@@ -80,6 +80,8 @@ def main():
                bench.algorithmic_bytes(L, B, U4, n_tgt, 4), "fused regrid -> orog_to_z -> rescale")
         # ---- per-point
         y = x.new_like()
+        record(f"(ceiling) torch copy_ of the stack {tag}", timeit(lambda: y.data.copy_(x.data)), 2 * x.data.numel() * B,
+               "device-to-device copy of the same bytes: the practical read+write streaming rate")
         p1 = native.level_program([[(native.OP_AFFINE, 0, 1.0, -273.15)] * L], dev)
         kw = dict(n_pts=n_src, n_lev=L, x_pitch=x.pitch, y_pitch=y.pitch, layout=COLUMNS)
         stack_bytes = n_src * L * B
