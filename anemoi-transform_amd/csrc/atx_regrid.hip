@@ -83,7 +83,7 @@ __device__ __forceinline__ T load_once(const T* p) {
 // ---------------------------------------------------------------------------------
 // ATX_COLUMNS, fixed k (ELL).  K > 0: compile-time k; K == 0: runtime k.
 // ---------------------------------------------------------------------------------
-template <typename T, int VEC, int K, bool WEIGHTED, bool EPI>
+template <typename T, int VEC, int K, bool WEIGHTED, bool EPI, bool PAD>
 __global__ void __launch_bounds__(kEllBlock)
 regrid_cols_ell_kernel(const T* __restrict__ src, T* __restrict__ out,
                        const int32_t* __restrict__ idx, const T* __restrict__ w,
@@ -147,7 +147,8 @@ regrid_cols_ell_kernel(const T* __restrict__ src, T* __restrict__ out,
             for (int u = 0; u < kU; ++u) {
 #pragma unroll
                 for (int j = 0; j < (K > 0 ? K : 1); ++j) {
-                    const int64_t p = idx_s[tt[u] * K + j];
+                    int64_t p = idx_s[tt[u] * K + j];
+                    if (PAD && p < 0) p = 0;  // absent entry of a padded row: load anything valid, skipped below
                     v[u][j] = load_src<T, VEC>(src + p * src_pitch + (int64_t)cc[u] * VEC);
                 }
             }
@@ -159,8 +160,10 @@ regrid_cols_ell_kernel(const T* __restrict__ src, T* __restrict__ out,
 #pragma unroll
                     for (int j = 0; j < (K > 0 ? K : 1); ++j) {
                         const T wj = w_s[tt[u] * K + j];
+                        if (!PAD || idx_s[tt[u] * K + j] >= 0) {
 #pragma unroll
-                        for (int e = 0; e < VEC; ++e) acc[u].v[e] = acc[u].v[e] + wj * v[u][j].v[e];
+                            for (int e = 0; e < VEC; ++e) acc[u].v[e] = acc[u].v[e] + wj * v[u][j].v[e];
+                        }
                     }
                 } else {
                     acc[u] = v[u][0];
@@ -175,21 +178,22 @@ regrid_cols_ell_kernel(const T* __restrict__ src, T* __restrict__ out,
                 int j = 0;
                 for (; j + 2 <= k; j += 2) {
                     const int64_t pa = idx_s[base + j], pb = idx_s[base + j + 1];
-                    const V va = *reinterpret_cast<const V*>(src + pa * src_pitch + (int64_t)cc[u] * VEC);
-                    const V vb = *reinterpret_cast<const V*>(src + pb * src_pitch + (int64_t)cc[u] * VEC);
+                    const V va = *reinterpret_cast<const V*>(src + ((PAD && pa < 0) ? 0 : pa) * src_pitch + (int64_t)cc[u] * VEC);
+                    const V vb = *reinterpret_cast<const V*>(src + ((PAD && pb < 0) ? 0 : pb) * src_pitch + (int64_t)cc[u] * VEC);
                     const T wa = WEIGHTED ? w_s[base + j] : T(1), wb = WEIGHTED ? w_s[base + j + 1] : T(1);
 #pragma unroll
                     for (int e = 0; e < VEC; ++e) {
-                        acc[u].v[e] = acc[u].v[e] + wa * va.v[e];
-                        acc[u].v[e] = acc[u].v[e] + wb * vb.v[e];
+                        if (!PAD || pa >= 0) acc[u].v[e] = acc[u].v[e] + wa * va.v[e];
+                        if (!PAD || pb >= 0) acc[u].v[e] = acc[u].v[e] + wb * vb.v[e];
                     }
                 }
                 if (j < k) {
                     const int64_t pa = idx_s[base + j];
-                    const V va = *reinterpret_cast<const V*>(src + pa * src_pitch + (int64_t)cc[u] * VEC);
+                    const V va = *reinterpret_cast<const V*>(src + ((PAD && pa < 0) ? 0 : pa) * src_pitch + (int64_t)cc[u] * VEC);
                     const T wa = WEIGHTED ? w_s[base + j] : T(1);
 #pragma unroll
-                    for (int e = 0; e < VEC; ++e) acc[u].v[e] = acc[u].v[e] + wa * va.v[e];
+                    for (int e = 0; e < VEC; ++e)
+                        if (!PAD || pa >= 0) acc[u].v[e] = acc[u].v[e] + wa * va.v[e];
                 }
             }
         }
@@ -291,7 +295,7 @@ regrid_cols_csr_kernel(const T* __restrict__ src, T* __restrict__ out,
 // ---------------------------------------------------------------------------------
 // ATX_FIELDS, fixed k.  lane = target; grid.y = level chunk.
 // ---------------------------------------------------------------------------------
-template <typename T, int K, bool WEIGHTED, bool EPI>
+template <typename T, int K, bool WEIGHTED, bool EPI, bool PAD>
 __global__ void __launch_bounds__(kBlock)
 regrid_fields_ell_kernel(const T* __restrict__ src, T* __restrict__ out,
                          const int32_t* __restrict__ idx, const T* __restrict__ w,
@@ -310,10 +314,13 @@ regrid_fields_ell_kernel(const T* __restrict__ src, T* __restrict__ out,
     if (K > 0) {
         int64_t p[K > 0 ? K : 1];
         T wj[K > 0 ? K : 1];
+        bool present[K > 0 ? K : 1];
 #pragma unroll
         for (int j = 0; j < (K > 0 ? K : 1); ++j) {
             p[j] = idx[t * K + j];
             wj[j] = WEIGHTED ? w[t * K + j] : T(1);
+            present[j] = !PAD || p[j] >= 0;  // absent entry of a padded row
+            if (!present[j]) p[j] = 0;
         }
 #pragma unroll 4
         for (int l = l0; l < l1; ++l) {
@@ -322,7 +329,10 @@ regrid_fields_ell_kernel(const T* __restrict__ src, T* __restrict__ out,
             if (WEIGHTED) {
                 acc = T(0);
 #pragma unroll
-                for (int j = 0; j < (K > 0 ? K : 1); ++j) acc = acc + wj[j] * s[p[j]];
+                for (int j = 0; j < (K > 0 ? K : 1); ++j) {
+                    const T term = wj[j] * s[p[j]];
+                    if (present[j]) acc = acc + term;
+                }
             } else {
                 acc = s[p[0]];
             }
@@ -338,7 +348,8 @@ regrid_fields_ell_kernel(const T* __restrict__ src, T* __restrict__ out,
             T acc = T(0);
             for (int j = 0; j < k; ++j) {
                 const T wv = WEIGHTED ? w[t * k + j] : T(1);
-                acc = acc + wv * s[idx[t * k + j]];
+                const int64_t pj = idx[t * k + j];
+                if (!PAD || pj >= 0) acc = acc + wv * s[pj];
             }
             if (EPI) {
                 for (int st = 0; st < n_stage; ++st)
@@ -409,7 +420,7 @@ static int pick_tile(int64_t n_tgt, int C) {
 
 static int g_tile_override = 0;  // tuning hook (atx_set_tuning)
 
-template <typename T, int VEC, int K, bool WEIGHTED>
+template <typename T, int VEC, int K, bool WEIGHTED, bool PAD = false>
 static int launch_cols_ell(const T* src, T* out, const int32_t* idx, const T* w, int64_t n_tgt, int k,
                            int n_lev, int64_t src_pitch, int64_t out_pitch, const atx_level_op* prog,
                            int n_stage, const uint8_t* tgt_mask, hipStream_t stream) {
@@ -422,10 +433,10 @@ static int launch_cols_ell(const T* src, T* out, const int32_t* idx, const T* w,
     if (prog) lds += (size_t)n_stage * C * sizeof(LevelOp<T>);
     ATX_REQUIRE(lds <= 64 * 1024, ATX_ENOTIMPL, "regrid_ell: tile needs %zu B of LDS (k=%d, n_lev=%d, stages=%d)", lds, k, n_lev, n_stage);
     if (prog) {
-        hipLaunchKernelGGL((regrid_cols_ell_kernel<T, VEC, K, WEIGHTED, true>), dim3(n_tiles), dim3(kEllBlock), lds, stream,
+        hipLaunchKernelGGL((regrid_cols_ell_kernel<T, VEC, K, WEIGHTED, true, PAD>), dim3(n_tiles), dim3(kEllBlock), lds, stream,
                            src, out, idx, w, n_tgt, k, n_lev, C, src_pitch, out_pitch, tile, n_tiles, prog, n_stage, tgt_mask);
     } else {
-        hipLaunchKernelGGL((regrid_cols_ell_kernel<T, VEC, K, WEIGHTED, false>), dim3(n_tiles), dim3(kEllBlock), lds, stream,
+        hipLaunchKernelGGL((regrid_cols_ell_kernel<T, VEC, K, WEIGHTED, false, PAD>), dim3(n_tiles), dim3(kEllBlock), lds, stream,
                            src, out, idx, w, n_tgt, k, n_lev, C, src_pitch, out_pitch, tile, n_tiles, prog, n_stage, tgt_mask);
     }
     ATX_LAUNCH_CHECK("regrid_cols_ell");
@@ -434,9 +445,16 @@ static int launch_cols_ell(const T* src, T* out, const int32_t* idx, const T* w,
 
 template <typename T, int VEC>
 static int dispatch_cols_ell(const T* src, T* out, const int32_t* idx, const T* w, int64_t n_tgt, int k,
-                             int n_lev, int64_t sp, int64_t op, const atx_level_op* prog, int n_stage,
+                             int n_lev, int64_t sp, int64_t op, bool pad, const atx_level_op* prog, int n_stage,
                              const uint8_t* m, hipStream_t st) {
     if (!w) return launch_cols_ell<T, VEC, 1, false>(src, out, idx, w, n_tgt, k, n_lev, sp, op, prog, n_stage, m, st);
+    if (pad) {  // padded ragged rows: the common widths compile-time, the rest runtime
+        switch (k) {
+            case 3: return launch_cols_ell<T, VEC, 3, true, true>(src, out, idx, w, n_tgt, k, n_lev, sp, op, prog, n_stage, m, st);
+            case 4: return launch_cols_ell<T, VEC, 4, true, true>(src, out, idx, w, n_tgt, k, n_lev, sp, op, prog, n_stage, m, st);
+            default: return launch_cols_ell<T, VEC, 0, true, true>(src, out, idx, w, n_tgt, k, n_lev, sp, op, prog, n_stage, m, st);
+        }
+    }
     switch (k) {
         case 1: return launch_cols_ell<T, VEC, 1, true>(src, out, idx, w, n_tgt, k, n_lev, sp, op, prog, n_stage, m, st);
         case 2: return launch_cols_ell<T, VEC, 2, true>(src, out, idx, w, n_tgt, k, n_lev, sp, op, prog, n_stage, m, st);
@@ -452,7 +470,7 @@ static int pick_lev_chunk(int n_lev) {
     return (n_lev + chunks - 1) / chunks;
 }
 
-template <typename T, int K, bool WEIGHTED>
+template <typename T, int K, bool WEIGHTED, bool PAD = false>
 static int launch_fields_ell(const T* src, T* out, const int32_t* idx, const T* w, int64_t n_tgt, int k,
                              int n_lev, int64_t sp, int64_t op, const atx_level_op* prog, int n_stage,
                              const uint8_t* m, hipStream_t st) {
@@ -461,10 +479,10 @@ static int launch_fields_ell(const T* src, T* out, const int32_t* idx, const T* 
     const unsigned n_chunks = (unsigned)((n_lev + lev_chunk - 1) / lev_chunk);
     ATX_REQUIRE(n_chunks <= 65535, ATX_ENOTIMPL, "regrid_ell: too many level chunks (%u)", n_chunks);
     if (prog) {
-        hipLaunchKernelGGL((regrid_fields_ell_kernel<T, K, WEIGHTED, true>), dim3(n_tiles, n_chunks), dim3(kBlock), 0, st,
+        hipLaunchKernelGGL((regrid_fields_ell_kernel<T, K, WEIGHTED, true, PAD>), dim3(n_tiles, n_chunks), dim3(kBlock), 0, st,
                            src, out, idx, w, n_tgt, k, n_lev, sp, op, lev_chunk, n_tiles, prog, n_stage, m);
     } else {
-        hipLaunchKernelGGL((regrid_fields_ell_kernel<T, K, WEIGHTED, false>), dim3(n_tiles, n_chunks), dim3(kBlock), 0, st,
+        hipLaunchKernelGGL((regrid_fields_ell_kernel<T, K, WEIGHTED, false, PAD>), dim3(n_tiles, n_chunks), dim3(kBlock), 0, st,
                            src, out, idx, w, n_tgt, k, n_lev, sp, op, lev_chunk, n_tiles, prog, n_stage, m);
     }
     ATX_LAUNCH_CHECK("regrid_fields_ell");
@@ -473,9 +491,16 @@ static int launch_fields_ell(const T* src, T* out, const int32_t* idx, const T* 
 
 template <typename T>
 static int dispatch_fields_ell(const T* src, T* out, const int32_t* idx, const T* w, int64_t n_tgt, int k,
-                               int n_lev, int64_t sp, int64_t op, const atx_level_op* prog, int n_stage,
+                               int n_lev, int64_t sp, int64_t op, bool pad, const atx_level_op* prog, int n_stage,
                                const uint8_t* m, hipStream_t st) {
     if (!w) return launch_fields_ell<T, 1, false>(src, out, idx, w, n_tgt, k, n_lev, sp, op, prog, n_stage, m, st);
+    if (pad) {
+        switch (k) {
+            case 3: return launch_fields_ell<T, 3, true, true>(src, out, idx, w, n_tgt, k, n_lev, sp, op, prog, n_stage, m, st);
+            case 4: return launch_fields_ell<T, 4, true, true>(src, out, idx, w, n_tgt, k, n_lev, sp, op, prog, n_stage, m, st);
+            default: return launch_fields_ell<T, 0, true, true>(src, out, idx, w, n_tgt, k, n_lev, sp, op, prog, n_stage, m, st);
+        }
+    }
     switch (k) {
         case 1: return launch_fields_ell<T, 1, true>(src, out, idx, w, n_tgt, k, n_lev, sp, op, prog, n_stage, m, st);
         case 2: return launch_fields_ell<T, 2, true>(src, out, idx, w, n_tgt, k, n_lev, sp, op, prog, n_stage, m, st);
@@ -493,7 +518,7 @@ static bool cols_vector_ok(const void* src, const void* out, int64_t sp, int64_t
 
 template <typename T>
 static int regrid_ell_typed(const void* src_, void* out_, const int32_t* idx, const void* w_, int64_t n_tgt, int k,
-                            int n_lev, int64_t sp, int64_t op, int layout, const atx_level_op* prog, int n_stage,
+                            int n_lev, int64_t sp, int64_t op, int layout, bool pad, const atx_level_op* prog, int n_stage,
                             const uint8_t* m, hipStream_t st) {
     const T* src = static_cast<const T*>(src_);
     T* out = static_cast<T*>(out_);
@@ -504,10 +529,10 @@ static int regrid_ell_typed(const void* src_, void* out_, const int32_t* idx, co
         // last (partial) vector inside the pitch
         const int64_t covered = ((int64_t)(n_lev + VEC - 1) / VEC) * VEC;
         if (cols_vector_ok<T>(src_, out_, sp, op) && covered <= sp && covered <= op)
-            return dispatch_cols_ell<T, VEC>(src, out, idx, w, n_tgt, k, n_lev, sp, op, prog, n_stage, m, st);
-        return dispatch_cols_ell<T, 1>(src, out, idx, w, n_tgt, k, n_lev, sp, op, prog, n_stage, m, st);
+            return dispatch_cols_ell<T, VEC>(src, out, idx, w, n_tgt, k, n_lev, sp, op, pad, prog, n_stage, m, st);
+        return dispatch_cols_ell<T, 1>(src, out, idx, w, n_tgt, k, n_lev, sp, op, pad, prog, n_stage, m, st);
     }
-    return dispatch_fields_ell<T>(src, out, idx, w, n_tgt, k, n_lev, sp, op, prog, n_stage, m, st);
+    return dispatch_fields_ell<T>(src, out, idx, w, n_tgt, k, n_lev, sp, op, pad, prog, n_stage, m, st);
 }
 
 template <typename T, int VEC>
@@ -597,20 +622,23 @@ extern "C" int atx_set_tuning(int tile) {
 
 extern "C" int atx_regrid_ell(const void* src, void* out, const int32_t* idx, const void* w, int64_t n_src,
                               int64_t n_tgt, int32_t k, int64_t n_lev, int64_t src_pitch, int64_t out_pitch,
-                              int dtype, int layout, const atx_level_op* prog, int32_t n_stage,
+                              int dtype, int layout, int32_t flags, const atx_level_op* prog, int32_t n_stage,
                               const uint8_t* tgt_mask, void* stream) {
     int st = check_stack_args("atx_regrid_ell", src, out, n_src, n_tgt, n_lev, src_pitch, out_pitch, dtype, layout);
     if (st != ATX_OK) return st;
     ATX_REQUIRE(idx, ATX_EINVAL, "atx_regrid_ell: null idx");
     ATX_REQUIRE(k >= 1 && k <= 64, ATX_EINVAL, "atx_regrid_ell: k=%d outside [1, 64]", k);
     ATX_REQUIRE(w || k == 1, ATX_EINVAL, "atx_regrid_ell: a pure gather (w == NULL) needs k == 1, got %d", k);
+    ATX_REQUIRE((flags & ~ATX_ELL_PADDED) == 0, ATX_EINVAL, "atx_regrid_ell: unknown flags 0x%x", flags);
+    ATX_REQUIRE(!(flags & ATX_ELL_PADDED) || w, ATX_EINVAL, "atx_regrid_ell: ATX_ELL_PADDED needs weights");
+    const bool pad = (flags & ATX_ELL_PADDED) != 0;
     ATX_REQUIRE((prog == nullptr) == (n_stage == 0) && n_stage >= 0 && n_stage <= 8, ATX_EINVAL,
                 "atx_regrid_ell: prog/n_stage mismatch (n_stage=%d)", n_stage);
     if (n_tgt == 0) return ATX_OK;
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (dtype == ATX_F32)
-        return regrid_ell_typed<float>(src, out, idx, w, n_tgt, k, (int)n_lev, src_pitch, out_pitch, layout, prog, n_stage, tgt_mask, s);
-    return regrid_ell_typed<double>(src, out, idx, w, n_tgt, k, (int)n_lev, src_pitch, out_pitch, layout, prog, n_stage, tgt_mask, s);
+        return regrid_ell_typed<float>(src, out, idx, w, n_tgt, k, (int)n_lev, src_pitch, out_pitch, layout, pad, prog, n_stage, tgt_mask, s);
+    return regrid_ell_typed<double>(src, out, idx, w, n_tgt, k, (int)n_lev, src_pitch, out_pitch, layout, pad, prog, n_stage, tgt_mask, s);
 }
 
 extern "C" int atx_regrid_csr(const void* src, void* out, const int32_t* indptr, const int32_t* indices,

@@ -70,6 +70,7 @@ def source_band(plan: GatherPlan) -> tuple[int, int]:
     target slice this is a narrow band of the source grid — with column stacks one contiguous
     slab of HBM, so a rank can be fed its band instead of the whole stack."""
     idx = plan.index if plan.kind == "ell" else plan.indices
+    idx = idx[idx >= 0]  # padded rows mark absent entries with -1
     if idx.size == 0:
         return 0, 0
     return int(idx.min()), int(idx.max()) + 1
@@ -78,7 +79,8 @@ def source_band(plan: GatherPlan) -> tuple[int, int]:
 def rebase_plan(plan: GatherPlan, lo: int, hi: int) -> GatherPlan:
     """The same plan expressed against the source slab ``[lo, hi)``."""
     if plan.kind == "ell":
-        return GatherPlan(hi - lo, plan.n_tgt, index=plan.index.astype(np.int64) - lo, weights=plan.weights)
+        index = plan.index.astype(np.int64)
+        return GatherPlan(hi - lo, plan.n_tgt, index=np.where(index >= 0, index - lo, -1), weights=plan.weights, padded=plan.padded)
     return GatherPlan(hi - lo, plan.n_tgt, csr=(plan.data, plan.indices.astype(np.int64) - lo, plan.indptr))
 
 

@@ -35,9 +35,11 @@ class GatherPlan:
         index: np.ndarray | None = None,  # [n_tgt] or [n_tgt, k]
         weights: np.ndarray | None = None,  # [n_tgt, k] or None (pure gather)
         csr: tuple[np.ndarray, np.ndarray, np.ndarray] | None = None,  # (data, indices, indptr)
+        padded: bool = False,  # index -1 marks an absent entry of a padded ragged row
     ) -> None:
         self.n_src = int(n_src)
         self.n_tgt = int(n_tgt)
+        self.padded = bool(padded)
         self._device: dict[tuple[str, torch.dtype], tuple[torch.Tensor, ...]] = {}
         if csr is not None:
             data, indices, indptr = csr
@@ -60,7 +62,16 @@ class GatherPlan:
                 raise ValueError(f"index table has {index.shape[0]} rows for {self.n_tgt} target points")
             self.kind = "ell"
             self.k = int(index.shape[1])
-            self.index = self._check(np.ascontiguousarray(index))
+            if self.padded:
+                if weights is None:
+                    raise ValueError("padded rows need weights")
+                present = index >= 0
+                if np.any(index[~present] != -1):
+                    raise ValueError("padded rows use -1 for absent entries")
+                self._check(index[present])
+                self.index = np.ascontiguousarray(index).astype(np.int32)
+            else:
+                self.index = self._check(np.ascontiguousarray(index))
             self.weights = None if weights is None else np.ascontiguousarray(weights, dtype=np.float64).reshape(index.shape)
             if self.weights is None and self.k != 1:
                 raise ValueError("a gather without weights needs exactly one index per target point")
@@ -85,10 +96,31 @@ class GatherPlan:
 
         n_tgt, n_src = (int(s) for s in matrix["matrix_shape"])
         data, indices, indptr = matrix["matrix_data"], matrix["matrix_indices"], matrix["matrix_indptr"]
-        k = csr_uniform_k(np.asarray(indptr))
+        indptr = np.asarray(indptr)
+        k = csr_uniform_k(indptr)
         if k is not None and k <= 64 and len(indptr) == n_tgt + 1:
             return cls(n_src, n_tgt, index=np.asarray(indices).reshape(n_tgt, k), weights=np.asarray(data).reshape(n_tgt, k))
+        padded = cls._padded_rows(n_src, n_tgt, np.asarray(data), np.asarray(indices), indptr)
+        if padded is not None:
+            return padded
         return cls(n_src, n_tgt, csr=(data, indices, indptr))
+
+    @classmethod
+    def _padded_rows(cls, n_src, n_tgt, data, indices, indptr, max_k: int = 8, min_fill: float = 0.6) -> "GatherPlan | None":
+        """Short ragged rows as fixed-k rows padded with the index -1 (skipped by the kernel): the fast
+        fixed-k kernel, the CSR summation order, no arithmetic on the padding."""
+        if len(indptr) != n_tgt + 1 or n_tgt == 0:
+            return None
+        lengths = np.diff(indptr.astype(np.int64))
+        k = int(lengths.max()) if lengths.size else 0
+        if k < 1 or k > max_k or lengths.sum() < min_fill * k * n_tgt:
+            return None
+        cols = np.arange(k)[None, :]
+        present = cols < lengths[:, None]
+        pos = np.minimum(indptr[:-1].astype(np.int64)[:, None] + cols, max(len(indices) - 1, 0))
+        index = np.where(present, np.asarray(indices, dtype=np.int64)[pos], -1)
+        weights = np.where(present, np.asarray(data, dtype=np.float64)[pos], 0.0)
+        return cls(n_src, n_tgt, index=index, weights=weights, padded=True)
 
     @classmethod
     def from_mask(cls, mask: np.ndarray, n_src: int | None = None) -> "GatherPlan":
@@ -109,7 +141,7 @@ class GatherPlan:
         lo, hi = shard_bounds(self.n_tgt, rank, world)
         if self.kind == "ell":
             return GatherPlan(self.n_src, hi - lo, index=self.index[lo:hi],
-                              weights=None if self.weights is None else self.weights[lo:hi])
+                              weights=None if self.weights is None else self.weights[lo:hi], padded=self.padded)
         p0, p1 = int(self.indptr[lo]), int(self.indptr[hi])
         return GatherPlan(self.n_src, hi - lo, csr=(self.data[p0:p1], self.indices[p0:p1], self.indptr[lo:hi + 1] - p0))
 
@@ -143,6 +175,7 @@ class GatherPlan:
             native.regrid_ell(
                 src.data, out.data, idx, w, n_src=self.n_src, n_tgt=self.n_tgt, k=self.k, n_lev=src.n_lev,
                 src_pitch=src.pitch, out_pitch=out.pitch, layout=src.layout, prog=prog, n_stage=n_stage, tgt_mask=tgt_mask,
+                padded=self.padded,
             )
         else:
             indptr, indices, data = self._tensors(src.device, src.dtype)

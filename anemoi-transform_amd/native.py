@@ -56,7 +56,7 @@ SIGNATURES: dict[str, tuple[Any, list[Any]]] = {
     "atx_set_tuning": (c_int, [c_int]),
     "atx_regrid_ell": (
         c_int,
-        [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int32, c_int64, c_int64, c_int64, c_int, c_int,
+        [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int32, c_int64, c_int64, c_int64, c_int, c_int, c_int32,
          c_void_p, c_int32, c_void_p, c_void_p],
     ),
     "atx_regrid_csr": (
@@ -170,16 +170,20 @@ def set_tuning(tile: int) -> None:
 # --------------------------------------------------------------------------------
 # tensor-level wrappers (these are what the filters call)
 # --------------------------------------------------------------------------------
+ELL_PADDED = 1
+
+
 def regrid_ell(src, out, idx, w, *, n_src, n_tgt, k, n_lev, src_pitch, out_pitch, layout, prog=None, n_stage=0,
-               tgt_mask=None) -> None:
-    """out[t, l] = sum_j w[t, j] * src[idx[t, j], l]; ``w is None`` -> pure k = 1 gather."""
+               tgt_mask=None, padded: bool = False) -> None:
+    """out[t, l] = sum_j w[t, j] * src[idx[t, j], l]; ``w is None`` -> pure k = 1 gather;
+    ``padded``: negative indices are absent entries of padded ragged rows (ATX_ELL_PADDED)."""
     assert src.dtype == out.dtype, (src.dtype, out.dtype)
     assert idx.dtype == torch.int32
     if w is not None:
         assert w.dtype == src.dtype, (w.dtype, src.dtype)
     _call(
         "atx_regrid_ell", _ptr(src), _ptr(out), _ptr(idx), _ptr(w), n_src, n_tgt, k, n_lev, src_pitch, out_pitch,
-        dtype_code(src.dtype), layout, _ptr(prog), n_stage, _ptr(tgt_mask), _stream(),
+        dtype_code(src.dtype), layout, ELL_PADDED if padded else 0, _ptr(prog), n_stage, _ptr(tgt_mask), _stream(),
     )
 
 

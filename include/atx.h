@@ -125,6 +125,10 @@ int atx_set_tuning(int tile);
  *   w != NULL : R: regrid.py:310 `data = self.matrix @ data` for a CSR matrix whose
  *     rows all hold k entries (k-NN weights, bilinear).
  * idx: int32 [n_tgt*k], every value in [0, n_src) (check with atx_check_indices).
+ * flags: 0, or ATX_ELL_PADDED (needs weights): a NEGATIVE index marks an absent entry of a padded
+ *      row and is skipped (not multiplied by zero), so ragged rows of at most k entries (e.g. MIR's
+ *      3-4 entries per row) run on this kernel with exactly the CSR summation order; a row of only
+ *      absent entries gives 0 as scipy does.
  * w  : dtype  [n_tgt*k].
  * prog (optional, device, n_stage*n_lev entries): per-level epilogue applied to
  *   the interpolated value before it is stored (the fused regrid -> per-point
@@ -133,9 +137,10 @@ int atx_set_tuning(int tile);
  * Requirements: ATX_COLUMNS with 16-byte aligned bases and pitches that are
  *   multiples of 16 bytes take the vector path; anything else a scalar path.
  */
+#define ATX_ELL_PADDED 1
 int atx_regrid_ell(const void* src, void* out, const int32_t* idx, const void* w,
                    int64_t n_src, int64_t n_tgt, int32_t k, int64_t n_lev,
-                   int64_t src_pitch, int64_t out_pitch, int dtype, int layout,
+                   int64_t src_pitch, int64_t out_pitch, int dtype, int layout, int32_t flags,
                    const atx_level_op* prog, int32_t n_stage, const uint8_t* tgt_mask,
                    void* stream);
 

@@ -70,7 +70,8 @@ def _epilogue(levels: np.ndarray, prog, n_stage, mask, n_lev):
             levels[l] = _apply_op(table[s, l], levels[l].copy(), m)
 
 
-def regrid_ell(src, out, idx, w, *, n_src, n_tgt, k, n_lev, src_pitch, out_pitch, layout, prog=None, n_stage=0, tgt_mask=None):
+def regrid_ell(src, out, idx, w, *, n_src, n_tgt, k, n_lev, src_pitch, out_pitch, layout, prog=None, n_stage=0, tgt_mask=None,
+               padded=False):
     x = _levels(src, n_src, n_lev, layout)
     y = _levels(out, n_tgt, n_lev, layout)
     index = idx.numpy().reshape(n_tgt, k)
@@ -79,10 +80,12 @@ def regrid_ell(src, out, idx, w, *, n_src, n_tgt, k, n_lev, src_pitch, out_pitch
         for l in range(n_lev):
             y[l] = oracle.gather_nn(x[l], index[:, 0])
     else:
-        weights = w.numpy().reshape(-1)
-        indptr = np.arange(n_tgt + 1) * k
+        weights = w.numpy().reshape(n_tgt, k)
+        assert padded or (index >= 0).all()
+        present = index >= 0  # ATX_ELL_PADDED: negative index = absent entry of a padded row (atx.h)
+        indptr = np.concatenate([[0], np.cumsum(present.sum(axis=1))])
         for l in range(n_lev):
-            y[l] = oracle.csr_apply(weights, index.reshape(-1), indptr, (n_tgt, n_src), np.ascontiguousarray(x[l]))
+            y[l] = oracle.csr_apply(weights[present], index[present], indptr, (n_tgt, n_src), np.ascontiguousarray(x[l]))
     _epilogue(y, prog, n_stage, tgt_mask, n_lev)
 
 

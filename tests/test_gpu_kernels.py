@@ -343,3 +343,40 @@ def test_relayout_round_trip(dev, tdtype, np_dtype, n_lev, n_pts):
     back = cols.to_layout(FIELDS)
     assert np.array_equal(back.data.cpu().numpy().view(itype), x.view(itype))
     assert np.array_equal(cols.level_numpy(n_lev - 1).view(itype), x[-1].view(itype))
+
+
+@pytest.mark.parametrize("tdtype,np_dtype", DTYPES)
+@pytest.mark.parametrize("layout", LAYOUTS)
+def test_padded_ragged_rows_run_on_the_fixed_k_kernel(dev, tdtype, np_dtype, layout):
+    """Short ragged CSR rows (0..4 entries, like MIR's matrices) become fixed-k rows padded with index -1;
+    absent entries are skipped, not multiplied by zero: inf / NaN in the source behave as in scipy."""
+    from anemoi_transform_amd.gather import GatherPlan
+
+    rng = np.random.default_rng(31)
+    n_src, n_tgt, n_lev = 3000, 2111, 9
+    x = make_fields(rng, n_lev, n_src, np_dtype, nan_frac=0.02)
+    x[:, rng.integers(0, n_src, 40)] = np.inf
+    x[:, rng.integers(0, n_src, 40)] = -np.inf
+    lengths = rng.choice([0, 2, 3, 4, 4, 4], size=n_tgt)
+    indptr = np.concatenate([[0], np.cumsum(lengths)]).astype(np.int32)
+    indices = rng.integers(0, n_src, size=int(indptr[-1])).astype(np.int32)
+    data = rng.random(int(indptr[-1]))
+    plan = GatherPlan.from_matrix(dict(matrix_data=data, matrix_indices=indices, matrix_indptr=indptr, matrix_shape=(n_tgt, n_src)))
+    assert plan.kind == "ell" and plan.padded and plan.k == 4 and (plan.index == -1).any()
+    src = Stack.from_fields(x, dev=dev, layout=layout)
+    got = plan.apply(src).numpy()
+    with np.errstate(invalid="ignore"):
+        want = np.stack([oracle.csr_apply(data.astype(np_dtype), indices, indptr, (n_tgt, n_src), f) for f in x])
+    if np_dtype == np.float64:
+        assert np.array_equal(got, want, equal_nan=True)
+    else:
+        np.testing.assert_allclose(got, want, rtol=RTOL_F32, atol=1e-4, equal_nan=True)
+    assert np.array_equal(np.isnan(got), np.isnan(want)) and np.array_equal(np.isinf(got), np.isinf(want))
+    assert (got[:, lengths == 0] == 0).all()  # an empty row is 0, as in scipy
+    # shards of a padded plan stay padded and concatenate to the same result
+    parts = [plan.shard(r, 3).apply(src).numpy() for r in range(3)]
+    assert np.array_equal(np.concatenate(parts, axis=1), got, equal_nan=True)
+    # long or very sparse rows keep the general CSR kernel
+    long_rows = GatherPlan.from_matrix(dict(matrix_data=np.ones(39), matrix_indices=np.arange(39, dtype=np.int32),
+                                            matrix_indptr=np.array([0, 20, 39], dtype=np.int32), matrix_shape=(2, 100)))
+    assert long_rows.kind == "csr"

@@ -74,7 +74,7 @@ def main():
         def run(h, tile):
             h.atx_set_tuning(tile)
             rc = h.atx_regrid_ell(src.data.data_ptr(), out.data.data_ptr(), idx.data_ptr(), None if w is None else w.data_ptr(),
-                                  n_src, n_tgt, k, args.levels, src.pitch, out.pitch, 1 if f64 else 0, 0, None, 0, None, stream)
+                                  n_src, n_tgt, k, args.levels, src.pitch, out.pitch, 1 if f64 else 0, 0, 0, None, 0, None, stream)
             assert rc == 0, h.atx_last_error()
 
         combos = [(name, tile) for name in libs for tile in args.tiles]

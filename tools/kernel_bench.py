@@ -73,8 +73,11 @@ def main():
         indptr = np.concatenate([[0], np.cumsum(keep.sum(axis=1))])
         csr = GatherPlan(n_src, n_tgt, csr=(w[keep], idx[keep], indptr))
         nnz = int(keep.sum())
-        record(f"regrid_csr ragged(3-4) {tag} columns", timeit(lambda: csr.apply(x)),
-               L * B * (int(np.unique(idx[keep]).size) + n_tgt) + nnz * (4 + B) + 4 * n_tgt)
+        csr_bytes = L * B * (int(np.unique(idx[keep]).size) + n_tgt) + nnz * (4 + B) + 4 * n_tgt
+        record(f"regrid_csr ragged(3-4) {tag} columns", timeit(lambda: csr.apply(x)), csr_bytes, "general CSR kernel")
+        padded = GatherPlan.from_matrix(dict(matrix_data=w[keep], matrix_indices=idx[keep], matrix_indptr=indptr, matrix_shape=(n_tgt, n_src)))
+        assert padded.padded
+        record(f"regrid ragged(3-4) as padded fixed-k {tag}", timeit(lambda: padded.apply(x)), csr_bytes, "what regrid(matrix=...) uses for short ragged rows")
         prog = native.level_program([[(native.OP_MUL, 0, 9.80665, 0.0)] * L, [(native.OP_AFFINE, 0, 1.0, -273.15)] * L], dev)
         record(f"regrid_ell k=4 {tag} + 2-stage epilogue", timeit(lambda: plan4.apply(x, prog=prog, n_stage=2)),
                bench.algorithmic_bytes(L, B, U4, n_tgt, 4), "fused regrid -> orog_to_z -> rescale")
