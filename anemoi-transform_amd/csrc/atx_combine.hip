@@ -65,6 +65,7 @@ __device__ __forceinline__ void combine_one(int op, int flags, const T* x, int n
             y0 = s;
             break;
         }
+        case ATX_COMB_SUB: y0 = x[0] - x[1]; break;
         default: y0 = x[0]; break;
     }
 }
@@ -132,8 +133,8 @@ using namespace atx;
 extern "C" int atx_combine_stack(int op, const void* const* inputs, int32_t n_in, void* const* outputs, int32_t n_out,
                                  int64_t n_pts, int64_t n_lev, int64_t pitch, int dtype, int layout,
                                  const double* level_param, int32_t flags, void* stream) {
-    static const int kIn[ATX_COMB_COUNT_] = {2, 2, 1, 2, 3, 3, -1};
-    static const int kOut[ATX_COMB_COUNT_] = {1, 1, 2, 1, 1, 1, 1};
+    static const int kIn[ATX_COMB_COUNT_] = {2, 2, 1, 2, 3, 3, -1, 2};
+    static const int kOut[ATX_COMB_COUNT_] = {1, 1, 2, 1, 1, 1, 1, 1};
     ATX_REQUIRE(op >= 0 && op < ATX_COMB_COUNT_, ATX_EINVAL, "atx_combine_stack: bad operator %d", op);
     ATX_REQUIRE(inputs && outputs, ATX_EINVAL, "atx_combine_stack: null pointer table");
     ATX_REQUIRE(n_in >= 1 && n_in <= ATX_COMB_MAX_INPUTS, ATX_EINVAL, "atx_combine_stack: n_in=%d outside [1, %d]", n_in, ATX_COMB_MAX_INPUTS);

@@ -510,3 +510,48 @@ class Sum(Filter):
 
     def backward(self, data: Any) -> Any:
         raise NotImplementedError("Sum filter is not reversible")
+
+
+@filter_registry.register("accum_to_interval")
+class AccumToInterval(Filter):
+    """Accumulated-since-start fields -> per-interval values by differencing consecutive valid times
+    (R: filters/fields/accum_to_interval.py:24-101).  Fields are grouped by (param, level, levelType) and
+    sorted by ``valid_datetime``; the first of each selected group becomes zeros (``zero_left``) or is kept.
+    All differences of all groups are ONE ``atx_combine_stack`` launch (current stack minus previous stack)."""
+
+    def __init__(self, variables: Iterable[str], window: str | None = None, zero_left: bool = True, **kwargs: Any) -> None:
+        self.variables = set(variables)
+        self.zero_left = bool(zero_left)
+        self.window = window  # accepted for YAML recipes, not used by the algorithm
+
+    @staticmethod
+    def _identifier(f: Any) -> tuple:
+        return (f.metadata("param"), f.metadata("level", default=None), f.metadata("levelType", default=None))
+
+    def forward(self, fields: Any) -> FieldList:
+        groups: dict[tuple, list[Any]] = {}
+        for f in fields:
+            groups.setdefault(self._identifier(f), []).append(f)
+        for key, members in groups.items():
+            groups[key] = sorted(members, key=lambda x: x.metadata("valid_datetime"))
+
+        pairs = []  # (current, previous) of every selected group, in output order
+        for (param, _, _), members in groups.items():
+            if param in self.variables:
+                pairs.extend((members[i], members[i - 1]) for i in range(1, len(members)))
+        diffs = iter(combine_groups(pairs, native.COMB_SUB, 1)) if pairs else iter(())
+
+        out: list[Any] = []
+        for (param, _, _), members in groups.items():
+            if param not in self.variables or len(members) == 0:
+                out.extend(members)
+                continue
+            first = members[0]
+            if self.zero_left:
+                out.append(new_field_from_numpy(np.zeros_like(first.to_numpy()), template=first))
+            else:
+                out.append(first)
+            for i in range(1, len(members)):
+                stack, level = next(diffs)[0]
+                out.append(new_field_from_stack(stack, level, template=members[i]))
+        return new_fieldlist_from_list(out)

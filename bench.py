@@ -315,6 +315,24 @@ def main():
             alg1 = algorithmic_bytes(args.levels, itemsize, int(np.unique(idx64[:, 0]).size), n_tgt, 1)
             extras["nearest_k1"] = {"value": n_tgt * args.levels / (ms1 * 1e-3), "avg_launch_ms": ms1,
                                     "achieved_GBs": alg1 / (ms1 * 1e-3) / 1e9, "frac": alg1 / (ms1 * 1e-3) / 1e9 / HBM_PEAK_GBS}
+            # config-5 shape on the same stack: regrid -> orog_to_z -> convert fused in ONE launch
+            prog = native.level_program([[(native.OP_MUL, 0, 9.80665, 0.0)] * args.levels,
+                                         [(native.OP_AFFINE, 0, 1.0, -273.15)] * args.levels], dev)
+            msf, _ = time_launches(lambda: native.regrid_ell(
+                stacks[0].data, outs[0].data, idx_d, w_d, n_src=n_src, n_tgt=n_tgt, k=args.k, n_lev=args.levels,
+                src_pitch=stacks[0].pitch, out_pitch=outs[0].pitch, layout=stacks[0].layout, prog=prog, n_stage=2), 10, 2)
+            extras["fused_regrid_orog_to_z_convert"] = {"value": n_tgt * args.levels / (msf * 1e-3), "avg_launch_ms": msf,
+                                                        "achieved_GBs": alg / (msf * 1e-3) / 1e9,
+                                                        "frac": alg / (msf * 1e-3) / 1e9 / HBM_PEAK_GBS}
+            # the one-off index build on the device instead of cKDTree (interp.nearest_grid_points_device)
+            from anemoi_transform_amd import interp as _interp
+
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            di, dd = _interp.nearest_grid_points_device(src_grid["latitudes"], src_grid["longitudes"], tgt_grid["latitudes"],
+                                                        tgt_grid["longitudes"], num_neighbours_to_return=args.k, return_distances=True)
+            extras["knn_device_s"] = time.perf_counter() - t0
+            extras["knn_rows_identical_to_ckdtree"] = float((di.reshape(n_tgt, -1) == idx64).all(axis=1).mean())
             del stacks, outs, mine
             torch.cuda.empty_cache()
             for name, dt, npdt, isz, lay in (("f64_columns", torch.float64, np.float64, 8, COLUMNS),

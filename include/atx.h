@@ -193,7 +193,8 @@ typedef enum {
                                   level = level_param[l]              R: filters/fields/w_to_wz.py:97-99          */
     ATX_COMB_WZ_TO_W = 5,      /* (wz, t, q) -> -1.0*rho*g*wz          R: w_to_wz.py:124-126                       */
     ATX_COMB_SUM = 6,          /* (c0, c1, ...) -> ((c0 + c1) + ...) in input order   R: filters/fields/sum.py:109-116 */
-    ATX_COMB_COUNT_ = 7
+    ATX_COMB_SUB = 7,          /* (a, b) -> a - b                      R: filters/fields/accum_to_interval.py:98   */
+    ATX_COMB_COUNT_ = 8
 } atx_comb;
 #define ATX_COMB_DEGREES 1
 #define ATX_COMB_MAX_INPUTS 8

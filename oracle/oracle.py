@@ -555,3 +555,34 @@ def sum_fields(arrays):
         else:
             s += c
     return s
+
+
+def interval_difference(current, previous):
+    """R: filters/fields/accum_to_interval.py:98 ``fl[i].to_numpy() - fl[i - 1].to_numpy()``."""
+    return current - previous
+
+
+def filter_accum_to_interval(fields: list[dict], *, variables, zero_left: bool = True) -> list[dict]:
+    """R: accum_to_interval.py:73-101 — per (param, level, levelType) group sorted by valid_datetime."""
+    variables = set(variables)
+    groups: dict[tuple, list[dict]] = {}
+    for f in fields:
+        groups.setdefault((f.get("param"), f.get("level"), f.get("levelType")), []).append(f)
+    for k, fl in groups.items():
+        groups[k] = sorted(fl, key=lambda x: x["valid_datetime"])
+    out = []
+    for (param_name, _, _), fl in groups.items():
+        if param_name not in variables or len(fl) == 0:
+            out.extend(fl)
+            continue
+        if zero_left:
+            g = dict(fl[0])
+            g["values"] = np.zeros_like(np.asarray(fl[0]["values"]))
+            out.append(g)
+        else:
+            out.append(fl[0])
+        for i in range(1, len(fl)):
+            g = dict(fl[i])
+            g["values"] = interval_difference(np.asarray(fl[i]["values"]), np.asarray(fl[i - 1]["values"]))
+            out.append(g)
+    return out

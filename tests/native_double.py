@@ -131,6 +131,8 @@ def combine_stack(op, inputs, outputs, *, n_pts, n_lev, pitch, layout, level_par
             ys[0][l] = oracle.wz_to_w(a[0], a[1], a[2], float(level_param[l]))
         elif op == native.COMB_SUM:
             ys[0][l] = oracle.sum_fields(a)
+        elif op == native.COMB_SUB:
+            ys[0][l] = oracle.interval_difference(a[0], a[1])
         else:
             raise ValueError(op)
     for y in ys:

@@ -294,3 +294,22 @@ def test_combine_kernel_vs_oracle(dev, tdtype, np_dtype, rtol, layout):
     assert np.array_equal(run(native.COMB_SUM, terms, 1)[0], np.stack([oracle.sum_fields([x[l] for x in terms]) for l in range(n_lev)]))
     with pytest.raises(ValueError):
         run(native.COMB_SNOW_COVER, [a], 1)
+
+
+def test_accum_to_interval(engine):
+    """R: tests/field_filters/test_accum_to_interval.py — differencing within (param, level) groups by valid time."""
+    rng = np.random.default_rng(8)
+    times = ["2020-01-01T06:00:00", "2020-01-01T00:00:00", "2020-01-01T12:00:00", "2020-01-01T18:00:00"]
+    acc = {t: np.cumsum(rng.random((3, 2)), axis=0) * (i + 1) for i, t in enumerate(sorted(times))}
+    specs = []
+    for t in times:  # deliberately not in time order
+        specs.append({"param": "tp", "values": acc[t], "latitudes": MD["latitudes"], "longitudes": MD["longitudes"], "valid_datetime": t})
+        specs.append({"param": "2t", "values": acc[t] + 270.0, "latitudes": MD["latitudes"], "longitudes": MD["longitudes"], "valid_datetime": t})
+    for zero_left in (True, False):
+        out = list(test_source(specs) | create_filter_by_name("accum_to_interval", variables=["tp"], zero_left=zero_left))
+        want = oracle.filter_accum_to_interval([dict(s) for s in specs], variables=["tp"], zero_left=zero_left)
+        assert [(f.metadata("param"), f.metadata("valid_datetime")) for f in out] == [(w["param"], w["valid_datetime"]) for w in want]
+        for f, w in zip(out, want):
+            assert np.array_equal(f.to_numpy(), np.asarray(w["values"]))
+    tp = [f for f in out if f.metadata("param") == "tp"]
+    assert [f.metadata("valid_datetime") for f in tp] == sorted(times)
