@@ -1,0 +1,115 @@
+"""BASELINE.json configs 2, 4 and 5 as parity cases on one MI355X (config 3 is tests/test_gpu_fullsize.py
+and the bench; config 1 is tests/test_filters.py::test_config1_32x64_single_field_plumbing).
+
+  config 2  O96 -> 1 degree lat-lon, bilinear (k = 4 matrix in the reference's npz format), 1 surface field
+  config 4  O1280 -> N320-sized target, variables x 137 levels x timesteps batched, target points sharded 8 ways.
+            The N320 point table is not available offline: the octahedral O320 grid (421 120 points)
+            stands in as the target; 2 variables x 2 timesteps instead of 6 x 4 keep the test short — the
+            sharding logic does not depend on the count.
+  config 5  regrid + orog_to_z + unit convert chained on O2560-shaped fields (26.3 M points x 137 levels, 14.4 GB)
+"""
+
+from __future__ import annotations
+
+import numpy as np
+import pytest
+import torch
+
+from anemoi_transform_amd import interp, native
+from anemoi_transform_amd.gather import GatherPlan
+from anemoi_transform_amd.grids import lookup
+from anemoi_transform_amd.stack import COLUMNS, Stack
+from oracle import oracle
+
+pytestmark = pytest.mark.gpu
+
+
+def synth(grid, n_lev, dev, seed, dtype=torch.float32):
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(seed)
+    n = len(grid["latitudes"])
+    lat = torch.from_numpy(np.deg2rad(grid["latitudes"])).to(dev)
+    lon = torch.from_numpy(np.deg2rad(grid["longitudes"])).to(dev)
+    st = Stack.empty(n, n_lev, dtype, dev, COLUMNS, zero=True)
+    base = 280.0 + 30.0 * torch.sin(lat) * torch.cos(2.0 * lon)
+    for l in range(n_lev):
+        st.data[:, l] = (base + 0.1 * l + torch.randn(n, dtype=torch.float64, device=dev, generator=gen)).to(dtype)
+    return st
+
+
+def test_config2_o96_to_1deg_bilinear(dev, tmp_path):
+    from anemoi_transform_amd.fields import fieldlist_from_dicts
+    from anemoi_transform_amd.filters import create_filter_by_name
+
+    src, tgt = lookup("o96"), lookup([1.0, 1.0])
+    matrix = interp.bilinear_octahedral(96, tgt)
+    assert tuple(matrix["matrix_shape"]) == (65160, 40320) and len(matrix["matrix_data"]) == 260640
+    path = str(tmp_path / "o96-to-1deg-bilinear.npz")
+    interp.save_matrix_npz(path, matrix, src, tgt)
+    rng = np.random.default_rng(20260630)
+    lat, lon = np.deg2rad(src["latitudes"]), np.deg2rad(src["longitudes"])
+    for np_dtype in (np.float64, np.float32):
+        values = (280 + 30 * np.sin(lat) * np.cos(2 * lon) + rng.standard_normal(len(lat))).astype(np_dtype)
+        fields = fieldlist_from_dicts([{"param": "2t", "values": values, "latitudes": src["latitudes"], "longitudes": src["longitudes"]}])
+        out = create_filter_by_name("regrid", matrix=path).forward(fields)[0]
+        want = oracle.csr_apply(matrix["matrix_data"].astype(np_dtype), matrix["matrix_indices"], matrix["matrix_indptr"],
+                                matrix["matrix_shape"], values)
+        got = out.to_numpy()
+        assert got.dtype == np_dtype and got.shape == (65160,)
+        if np_dtype == np.float64:
+            assert np.array_equal(got, want)
+        else:
+            np.testing.assert_allclose(got, want, rtol=1e-6)
+
+
+def test_config4_batched_stacks_target_sharded_8_ways(dev):
+    src, tgt = lookup("o1280"), lookup("o320")
+    n_src, n_tgt, n_lev = len(src["latitudes"]), len(tgt["latitudes"]), 137
+    assert n_tgt == 421120
+    idx, w = interp.knn_inverse_distance(src, tgt, k=4, device=True)
+    plan = GatherPlan(n_src, n_tgt, index=idx, weights=w)
+    shards = [plan.shard(r, 8) for r in range(8)]
+    assert sum(s.n_tgt for s in shards) == n_tgt and max(s.n_tgt for s in shards) - min(s.n_tgt for s in shards) <= 1
+    indptr = np.arange(n_tgt + 1) * 4
+    for stack_id in range(4):  # 2 variables x 2 timesteps
+        x = synth(src, n_lev, dev, 100 + stack_id)
+        full = plan.apply(x)
+        parts = torch.cat([s.apply(x).data for s in shards])
+        assert torch.equal(parts.view(torch.int32), full.data.view(torch.int32))  # shards == unsharded, bit for bit
+        for l in (0, 136):
+            want = oracle.csr_apply(w.astype(np.float32).reshape(-1), idx.reshape(-1), indptr, (n_tgt, n_src), x.level_numpy(l))
+            assert np.array_equal(full.level_numpy(l), want)
+        del x, full, parts
+    # a rank only needs the latitude band of the source its slice references: a contiguous slab of the column stack
+    from anemoi_transform_amd.distributed import rebase_plan, source_band
+
+    x = synth(src, 8, dev, 7)
+    for r in (0, 3, 7):
+        lo, hi = source_band(shards[r])
+        assert (hi - lo) < 0.2 * n_src
+        slab = Stack(x.data[lo:hi], hi - lo, x.n_lev, COLUMNS)
+        assert torch.equal(rebase_plan(shards[r], lo, hi).apply(slab).data, shards[r].apply(x).data)
+
+
+def test_config5_chained_filters_on_o2560(dev):
+    src, tgt = lookup("o2560"), lookup("0.25")
+    n_src, n_tgt, n_lev = len(src["latitudes"]), len(tgt["latitudes"]), 137
+    assert n_src == 26306560
+    idx, w = interp.knn_inverse_distance(src, tgt, k=4, device=True)  # cKDTree needs ~1 min here; the device build < 2 s
+    plan = GatherPlan(n_src, n_tgt, index=idx, weights=w)
+    x = synth(src, n_lev, dev, 5)
+    # levels 0..135: temperature -> degC; level 136: orography -> geopotential -> (no convert)
+    s_orog = [(native.OP_COPY, 0, 0.0, 0.0)] * (n_lev - 1) + [(native.OP_MUL, 0, oracle.G, 0.0)]
+    s_conv = [(native.OP_AFFINE, 0, 1.0, -273.15)] * (n_lev - 1) + [(native.OP_COPY, 0, 0.0, 0.0)]
+    prog = native.level_program([s_orog, s_conv], dev)
+    fused = plan.apply(x, prog=prog, n_stage=2)
+    plain = plan.apply(x)
+    chained = plain.new_like()
+    native.pointwise_stack(plain.data, chained.data, n_pts=n_tgt, n_lev=n_lev, x_pitch=plain.pitch, y_pitch=chained.pitch,
+                           layout=COLUMNS, prog=prog, n_stage=2)
+    assert torch.equal(fused.data[:, :n_lev].contiguous().view(torch.int32), chained.data[:, :n_lev].contiguous().view(torch.int32))
+    indptr = np.arange(n_tgt + 1) * 4
+    w32 = w.astype(np.float32).reshape(-1)
+    for l, fn in ((0, lambda v: oracle.rescale_forward(v, np.float32(1.0), np.float32(-273.15))), (136, lambda v: v * np.float32(oracle.G))):
+        base = oracle.csr_apply(w32, idx.reshape(-1), indptr, (n_tgt, n_src), x.level_numpy(l))
+        assert np.array_equal(fused.level_numpy(l), fn(base))
