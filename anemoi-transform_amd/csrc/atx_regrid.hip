@@ -71,6 +71,17 @@ __device__ __forceinline__ Pack<T, N> load_src(const T* p) {
     return *reinterpret_cast<const Pack<T, N>*>(p);
 #endif
 }
+#ifndef ATX_FIELDS_NT
+#define ATX_FIELDS_NT 0
+#endif
+template <typename T>
+__device__ __forceinline__ void store_scalar(T* p, T v) {
+#if ATX_FIELDS_NT
+    __builtin_nontemporal_store(v, p);
+#else
+    *p = v;
+#endif
+}
 template <typename T>
 __device__ __forceinline__ T load_once(const T* p) {
 #if ATX_NT_IDX
@@ -322,7 +333,10 @@ regrid_fields_ell_kernel(const T* __restrict__ src, T* __restrict__ out,
             present[j] = !PAD || p[j] >= 0;  // absent entry of a padded row
             if (!present[j]) p[j] = 0;
         }
-#pragma unroll 4
+#ifndef ATX_FIELDS_UNROLL
+#define ATX_FIELDS_UNROLL 4
+#endif
+#pragma unroll ATX_FIELDS_UNROLL
         for (int l = l0; l < l1; ++l) {
             const T* s = src + (int64_t)l * src_pitch;
             T acc;
@@ -340,7 +354,7 @@ regrid_fields_ell_kernel(const T* __restrict__ src, T* __restrict__ out,
                 for (int st = 0; st < n_stage; ++st)
                     acc = apply_level_op(load_level_op<T>(prog, (int64_t)st * n_lev + l), acc, masked);
             }
-            out[(int64_t)l * out_pitch + t] = acc;
+            store_scalar(out + (int64_t)l * out_pitch + t, acc);
         }
     } else {
         for (int l = l0; l < l1; ++l) {

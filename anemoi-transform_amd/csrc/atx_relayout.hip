@@ -3,7 +3,8 @@
 // engine's native HBM layout).
 //
 // A workgroup moves TP points x LC levels through LDS.  On the FIELDS side a wave
-// touches 256 contiguous bytes of one level; on the COLUMNS side the TP columns of
+// touches 128 contiguous bytes of one level (small tiles = many resident workgroups: measured
+// best, 256-B tiles -25 %, 512-B tiles -50 %); on the COLUMNS side the TP columns of
 // the tile form one contiguous TP*pitch run, swept by consecutive lanes.  The LDS
 // tile is [point][level] with an odd row length (in 4-byte words for f32) so both
 // phases are bank-conflict free for f32 and at most 2-way for f64.
@@ -25,6 +26,7 @@ transpose_kernel(const T* __restrict__ src, T* __restrict__ dst, int64_t n_pts, 
 
     // fields side: element (p, l) at base[l*pitch + p]; columns side: base[p*pitch + l]
     if (TO_COLUMNS) {
+#pragma unroll 4
         for (int i = tid; i < nl * TP; i += kBlock) {
             const int l = i / TP, p = i - l * TP;
             if (p < np) tile[p * LCpad + l] = src[(int64_t)(l0 + l) * src_pitch + p0 + p];
@@ -35,6 +37,7 @@ transpose_kernel(const T* __restrict__ src, T* __restrict__ dst, int64_t n_pts, 
             dst[(p0 + p) * dst_pitch + l0 + l] = tile[p * LCpad + l];
         }
     } else {
+#pragma unroll 4
         for (int i = tid; i < np * nl; i += kBlock) {
             const int p = i / nl, l = i - p * nl;
             tile[p * LCpad + l] = src[(p0 + p) * src_pitch + l0 + l];
@@ -73,7 +76,10 @@ static int relayout_typed(const void* src_, void* dst_, int64_t n_pts, int n_lev
         ATX_LAUNCH_CHECK("pitched_copy");
         return ATX_OK;
     }
-    const int TP = 256 / (int)sizeof(T);  // 256 contiguous bytes per level on the fields side
+#ifndef ATX_TP_BYTES
+#define ATX_TP_BYTES 128
+#endif
+    const int TP = ATX_TP_BYTES / (int)sizeof(T);  // contiguous bytes per level on the fields side
     int LC = n_lev < 160 ? n_lev : 128;
     const int LCpad = LC | 1;
     const size_t lds = (size_t)TP * LCpad * sizeof(T);
