@@ -548,7 +548,7 @@ class AccumToInterval(Filter):
                 continue
             first = members[0]
             if self.zero_left:
-                out.append(new_field_from_numpy(np.zeros_like(first.to_numpy()), template=first))
+                out.append(new_field_from_numpy(np.zeros(first.shape), template=first))  # np.zeros_like(first.to_numpy())
             else:
                 out.append(first)
             for i in range(1, len(members)):

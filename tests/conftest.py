@@ -13,6 +13,8 @@ if ROOT not in sys.path:
 
 import __graft_entry__ as graft  # noqa: E402
 
+if not os.path.exists(graft.LIB):  # fresh checkout: build libatx.so (hipcc cross-compiles without a GPU)
+    graft.build()
 graft.load_package()
 
 
