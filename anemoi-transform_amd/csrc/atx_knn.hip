@@ -221,6 +221,65 @@ static unsigned blocks_for(int64_t n) {
 
 using namespace atx;
 
+// ---- cutout mask: ray / triangle tests for every global point -------------------------------
+// np.cross / np.dot of 3-vectors, in the reference's operation order (no contraction).
+__device__ __forceinline__ void cross3(const double a[3], const double b[3], double c[3]) {
+    c[0] = a[1] * b[2] - a[2] * b[1];
+    c[1] = a[2] * b[0] - a[0] * b[2];
+    c[2] = a[0] * b[1] - a[1] * b[0];
+}
+__device__ __forceinline__ double dot3(const double a[3], const double b[3]) {
+    double s = a[0] * b[0];
+    s = s + a[1] * b[1];
+    s = s + a[2] * b[2];
+    return s;
+}
+
+__global__ void __launch_bounds__(kBlock)
+cutout_inside_kernel(const double* __restrict__ g, int64_t n, const double* __restrict__ lam, const int32_t* __restrict__ nb,
+                     int k, uint8_t* __restrict__ inside) {
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    const double d[3] = {g[i * 3], g[i * 3 + 1], g[i * 3 + 2]};
+    const double epsilon = 0.0000001;
+    bool hit = false;
+    for (int j = 0; j < k && !hit; ++j) {
+        const int64_t i0 = nb[i * k + j], i1 = nb[i * k + (j + 1) % k], i2 = nb[i * k + (j + 2) % k];
+        double v0[3], e1[3], e2[3], s[3], h[3], q[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            v0[c] = lam[i0 * 3 + c];
+            e1[c] = lam[i1 * 3 + c] - v0[c];
+            e2[c] = lam[i2 * 3 + c] - v0[c];
+            s[c] = 0.0 - v0[c];  // ray origin = centre of the Earth
+        }
+        cross3(d, e2, h);
+        const double a = dot3(e1, h);
+        if (-epsilon < a && a < epsilon) continue;
+        const double f = 1.0 / a;
+        const double u = f * dot3(s, h);
+        if (u < 0.0 || u > 1.0) continue;
+        cross3(s, e1, q);
+        const double v = f * dot3(d, q);
+        if (v < 0.0 || u + v > 1.0) continue;
+        const double t = f * dot3(e2, q);
+        hit = t > epsilon;
+    }
+    inside[i] = hit ? 1 : 0;
+}
+
+extern "C" int atx_cutout_inside(const double* global_xyz, int64_t n, const double* lam_xyz, int64_t n_lam,
+                                 const int32_t* neighbours, int32_t k, uint8_t* inside, void* stream) {
+    ATX_REQUIRE(global_xyz && lam_xyz && neighbours && inside, ATX_EINVAL, "atx_cutout_inside: null pointer");
+    ATX_REQUIRE(n >= 0 && n_lam > 0 && k >= 1 && k <= kMaxK, ATX_EINVAL, "atx_cutout_inside: bad sizes (n=%lld, n_lam=%lld, k=%d)",
+                (long long)n, (long long)n_lam, k);
+    if (n == 0) return ATX_OK;
+    hipLaunchKernelGGL(cutout_inside_kernel, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0,
+                       static_cast<hipStream_t>(stream), global_xyz, n, lam_xyz, neighbours, k, inside);
+    ATX_LAUNCH_CHECK("cutout_inside");
+    return ATX_OK;
+}
+
 extern "C" size_t atx_knn_workspace_bytes(int64_t n_src) {
     if (n_src <= 0 || n_src > INT32_MAX) return 0;
     return knn_layout(n_src).total_bytes;

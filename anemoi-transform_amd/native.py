@@ -81,6 +81,7 @@ SIGNATURES: dict[str, tuple[Any, list[Any]]] = {
     "atx_knn_workspace_bytes": (c_size_t, [c_int64]),
     "atx_knn_build": (c_int, [c_void_p, c_int64, c_void_p, c_size_t, c_void_p]),
     "atx_knn_query": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int32, c_void_p, c_void_p, c_void_p]),
+    "atx_cutout_inside": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int32, c_void_p, c_void_p]),
     "atx_reduce": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_int, c_void_p]),
     "atx_relayout": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int64, c_int, c_int, c_int, c_void_p]),
 }
@@ -283,6 +284,15 @@ class KnnIndex:
         d2 = torch.empty((n, k), dtype=torch.float64, device=tgt_xyz.device)
         _call("atx_knn_query", _ptr(self._ws), self.n_src, _ptr(tgt_xyz), n, k, _ptr(idx), _ptr(d2), _stream())
         return idx, d2
+
+
+def cutout_inside(global_xyz: torch.Tensor, lam_xyz: torch.Tensor, neighbours: torch.Tensor) -> torch.Tensor:
+    """uint8 [n]: the ray through each global point hits a triangle of its nearest LAM points (``atx_cutout_inside``)."""
+    assert global_xyz.dtype == lam_xyz.dtype == torch.float64 and neighbours.dtype == torch.int32
+    n, k = neighbours.shape
+    inside = torch.empty(max(n, 1), dtype=torch.uint8, device=global_xyz.device)
+    _call("atx_cutout_inside", _ptr(global_xyz), n, _ptr(lam_xyz), lam_xyz.shape[0], _ptr(neighbours), k, _ptr(inside), _stream())
+    return inside[:n]
 
 
 def reduce(x, red: int, n: int | None = None) -> float:

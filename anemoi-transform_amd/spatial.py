@@ -92,9 +92,13 @@ def cutout_mask(
     min_distance_km: int | float | None = None,
     max_distance_km: int | float | None = None,
     plot: str | None = None,
+    device: bool = False,
 ) -> np.ndarray:
     """Mask of the GLOBAL points to keep around a limited-area grid: ``False`` for points inside the
-    LAM, closer than ``min_distance_km`` or further than ``max_distance_km`` (R: spatial.py:294-440)."""
+    LAM, closer than ``min_distance_km`` or further than ``max_distance_km`` (R: spatial.py:294-440).
+
+    ``device=True`` runs the neighbour search (``atx_knn_*``) and the ray/triangle tests
+    (``atx_cutout_inside``) on the GPU — SURVEY.md §8f rank 4; same result."""
     assert cropping_distance >= 0.0, "cropping_distance must be non-negative"
     assert min_distance_km is None or min_distance_km >= 0.0, "min_distance_km must be non-negative"
     assert max_distance_km is None or max_distance_km >= 0.0, "max_distance_km must be non-negative"
@@ -118,18 +122,20 @@ def cutout_mask(
     lam_points = unit_sphere_xyz(lats, lons)
     min_distance = _distance_km_to_resolution(min_distance_km, lam_points, global_points)
 
-    distances, indices = cKDTree(lam_points).query(global_points, k=neighbours)
-    distances = distances.reshape(len(global_points), -1)
-    indices = indices.reshape(len(global_points), -1)
-
-    inside = np.zeros(len(global_points), dtype=bool)
-    for j in range(neighbours):  # any of the `neighbours` triangles of consecutive nearest points
-        inside |= rays_hit_triangles(
-            global_points,
-            lam_points[indices[:, j]],
-            lam_points[indices[:, (j + 1) % neighbours]],
-            lam_points[indices[:, (j + 2) % neighbours]],
-        )
+    if device:
+        distances, inside = _device_neighbours_and_inside(lam_points, global_points, neighbours)
+    else:
+        distances, indices = cKDTree(lam_points).query(global_points, k=neighbours)
+        distances = distances.reshape(len(global_points), -1)
+        indices = indices.reshape(len(global_points), -1)
+        inside = np.zeros(len(global_points), dtype=bool)
+        for j in range(neighbours):  # any of the `neighbours` triangles of consecutive nearest points
+            inside |= rays_hit_triangles(
+                global_points,
+                lam_points[indices[:, j]],
+                lam_points[indices[:, (j + 1) % neighbours]],
+                lam_points[indices[:, (j + 2) % neighbours]],
+            )
     nearest = np.min(distances, axis=1) if len(global_points) else np.zeros(0)
     exclude = inside | (nearest <= min_distance)
     if max_distance_km is not None:
@@ -141,6 +147,23 @@ def cutout_mask(
     mask[mask] = exclude
     mask[too_far_mask] = True
     return ~mask
+
+
+def _device_neighbours_and_inside(lam_points: np.ndarray, global_points: np.ndarray, neighbours: int):
+    """k nearest LAM points of every global point and the ray/triangle verdict, on the GPU."""
+    import torch
+
+    from . import native
+    from . import stack as _stack
+
+    if len(global_points) == 0:
+        return np.zeros((0, neighbours)), np.zeros(0, dtype=bool)
+    dev = _stack.device()
+    lam_d = torch.from_numpy(np.ascontiguousarray(lam_points)).to(dev)
+    glob_d = torch.from_numpy(np.ascontiguousarray(global_points)).to(dev)
+    idx, d2 = native.KnnIndex(lam_d).query(glob_d, neighbours)
+    inside = native.cutout_inside(glob_d, lam_d, idx)
+    return np.sqrt(d2.cpu().numpy()), inside.cpu().numpy().astype(bool)
 
 
 def thinning_mask(lats, lons, global_lats, global_lons, cropping_distance: float = 2.0) -> np.ndarray:
@@ -158,14 +181,26 @@ def thinning_mask(lats, lons, global_lats, global_lons, cropping_distance: float
     return indices
 
 
-def global_on_lam_mask(lats, lons, global_lats, global_lons, distance_km: float | None = None) -> np.ndarray:
+def global_on_lam_mask(lats, lons, global_lats, global_lons, distance_km: float | None = None, device: bool = False) -> np.ndarray:
     """Sorted unique indices of the global points within ``distance_km`` of any LAM point
-    (R: spatial.py:506-536) — the ``mask`` of ``regrid(mask=...)``."""
+    (R: spatial.py:506-536) — the ``mask`` of ``regrid(mask=...)``.  ``device=True``: one k = 1
+    search of the LAM points from every global point on the GPU instead of a ball query per LAM point."""
     from scipy.spatial import cKDTree
 
     _check_latlon_arrays(lats, lons, global_lats, global_lons)
     global_points = unit_sphere_xyz(global_lats, global_lons)
     lam_points = unit_sphere_xyz(lats, lons)
     distance = _distance_km_to_resolution(distance_km, lam_points, global_points)
+    if device:
+        import torch
+
+        from . import native
+        from . import stack as _stack
+
+        dev = _stack.device()
+        lam_d = torch.from_numpy(np.ascontiguousarray(lam_points)).to(dev)
+        glob_d = torch.from_numpy(np.ascontiguousarray(global_points)).to(dev)
+        _, d2 = native.KnnIndex(lam_d).query(glob_d, 1)
+        return np.flatnonzero(d2.cpu().numpy()[:, 0] <= distance * distance)
     found = cKDTree(global_points).query_ball_point(lam_points, distance)
     return np.array(sorted(set(i for sub in found for i in sub)))

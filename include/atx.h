@@ -247,6 +247,16 @@ int atx_knn_build(const double* src_xyz, int64_t n_src, void* workspace, size_t 
 int atx_knn_query(const void* workspace, int64_t n_src, const double* tgt_xyz, int64_t n_tgt, int32_t k,
                   int32_t* idx_out, double* d2_out, void* stream);
 
+/* ---- mask builders ------------------------------------------------------------- */
+/* inside[i] = 1 if the ray from the Earth's centre through global point i hits any of the `k`
+ * triangles (nb[i][j], nb[i][(j+1)%k], nb[i][(j+2)%k]) of its k nearest limited-area points
+ * (Moeller-Trumbore, epsilon 1e-7) — the per-point loop of
+ *   R: spatial.py:404-424 (cutout_mask) over R: spatial.py:186-233 (Triangle3D.intersect)
+ * evaluated for all points at once.  global_xyz [n,3] and lam_xyz [n_lam,3] float64 unit-sphere
+ * coordinates, neighbours int32 [n,k] (from atx_knn_query), inside uint8 [n]. */
+int atx_cutout_inside(const double* global_xyz, int64_t n, const double* lam_xyz, int64_t n_lam,
+                      const int32_t* neighbours, int32_t k, uint8_t* inside, void* stream);
+
 /* ---- layout --------------------------------------------------------------- */
 /* dst[p, l] = src[p, l] between layouts / pitches (LDS-tiled transpose when the
  * layouts differ, strided copy when they agree).  No reference counterpart:

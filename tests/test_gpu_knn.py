@@ -96,3 +96,36 @@ def test_knn_full_size_o1280_to_quarter_degree(dev):
     same = ~differ
     assert np.array_equal(got_i[same], want_i[same])
     assert differ.mean() < 0.05
+
+
+def test_device_mask_builders_equal_the_host_ones(dev):
+    """cutout_mask / global_on_lam_mask with device=True (atx_knn + atx_cutout_inside) against the host builders
+    (which are pinned to the reference's known answers in tests/test_spatial.py) — and on those known answers."""
+    from anemoi_transform_amd import spatial
+
+    def lam_grid(lat0, lat1, lon0, lon1, n):
+        lats, lons = np.meshgrid(np.linspace(lat0, lat1, n), np.linspace(lon0, lon1, n))
+        return lats.flatten(), lons.flatten()
+
+    lam_lats, lam_lons = lam_grid(44.0, 46.0, 0.0, 2.0, 11)
+    g_lats = np.array([43.1, 44.0, 45.0, 45.5, 46.0, 50.0])
+    g_lons = np.array([359.1, 359.5, 0.0, 1.0, 2.0, 0.0])
+    for cd in (1.0, 3.0, 5.0):  # R: tests/test_spatial.py:20-50
+        m = spatial.cutout_mask(lam_lats, lam_lons, g_lats, g_lons, cropping_distance=cd, max_distance_km=250.0, device=True)
+        assert np.array_equal(m, [True, False, False, False, False, False])
+    m = spatial.cutout_mask(lam_lats, lam_lons, np.array([44.0, 45.0, 46.0, 46.1, 47.5]), np.array([0.0, 1.0, 2.0, -0.1, -1.5]),
+                            min_distance_km=100.0, device=True)
+    assert np.array_equal(m, [False, False, False, False, True])  # R: tests/test_spatial.py:53-79
+
+    rng = np.random.default_rng(12)
+    lam_lats, lam_lons = lam_grid(35.0, 55.0, -5.0, 20.0, 60)
+    lam_lats = lam_lats + rng.normal(0, 0.02, lam_lats.shape)
+    glob = lookup("o160")
+    for kw in (dict(), dict(min_distance_km=50.0), dict(max_distance_km=500.0, neighbours=4)):
+        a = spatial.cutout_mask(lam_lats, lam_lons, glob["latitudes"], glob["longitudes"], device=True, **kw)
+        b = spatial.cutout_mask(lam_lats, lam_lons, glob["latitudes"], glob["longitudes"], **kw)
+        assert np.array_equal(a, b), kw
+        assert a.any() and not a.all()
+    a = spatial.global_on_lam_mask(lam_lats, lam_lons, glob["latitudes"], glob["longitudes"], distance_km=40.0, device=True)
+    b = spatial.global_on_lam_mask(lam_lats, lam_lons, glob["latitudes"], glob["longitudes"], distance_km=40.0)
+    assert np.array_equal(a, b) and len(a) > 100
