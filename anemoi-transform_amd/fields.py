@@ -471,15 +471,17 @@ class FieldSelection:
 class StackGroup:
     """Fields of a FieldList that share a grid, as one HBM stack.
 
-    ``positions[i]`` is the index in the FieldList of the field stored at level ``i``.
+    ``positions[i]`` is the index in the FieldList of ``fields[i]``, which is stored at level
+    ``levels[i]`` of ``stack`` (``levels == range(n)`` unless the group is a sparse view of a bigger stack).
     """
 
-    __slots__ = ("stack", "positions", "fields")
+    __slots__ = ("stack", "positions", "fields", "levels")
 
-    def __init__(self, stack: Stack, positions: list[int], fields: list[Any]) -> None:
+    def __init__(self, stack: Stack, positions: list[int], fields: list[Any], levels: list[int] | None = None) -> None:
         self.stack = stack
         self.positions = positions
         self.fields = fields
+        self.levels = list(range(len(fields))) if levels is None else levels
 
 
 _upload_dtype: torch.dtype | None = None
@@ -511,12 +513,15 @@ def select_levels(stack: Stack, levels: list[int]) -> Stack:
     return out
 
 
-def group_into_stacks(fields: Iterable[Any], positions: list[int] | None = None) -> list[StackGroup]:
+def group_into_stacks(fields: Iterable[Any], positions: list[int] | None = None, sparse_ok: bool = False) -> list[StackGroup]:
     """Partition fields into stacks: device fields by the stack they live in, host fields by grid size.
 
     Host groups are uploaded once (one H2D copy + one relayout launch); device groups
     that cover a whole stack in order are used in place, others are compacted on the
-    device.  ``positions`` restricts the grouping to a subset of the list.
+    device — unless ``sparse_ok`` and the group covers at least half of its stack: then the stack
+    itself is returned with ``levels`` naming the members (a per-level operator can leave the other
+    levels alone, which is cheaper than copying most of the stack first).  ``positions`` restricts
+    the grouping to a subset of the list.
     """
     fields = list(fields)
     wanted = range(len(fields)) if positions is None else positions
@@ -535,7 +540,10 @@ def group_into_stacks(fields: Iterable[Any], positions: list[int] | None = None)
         if key[0] == "hbm":
             stack = group_fields[0].stack_ref()[0]
             levels = [f.stack_ref()[1] for f in group_fields]
-            groups.append(StackGroup(select_levels(stack, levels), members, group_fields))
+            if sparse_ok and levels != list(range(stack.n_lev)) and len(set(levels)) == len(levels) and 2 * len(levels) >= stack.n_lev:
+                groups.append(StackGroup(stack, members, group_fields, levels))
+            else:
+                groups.append(StackGroup(select_levels(stack, levels), members, group_fields))
         else:
             arrays = [f.to_numpy(flatten=True) for f in group_fields]
             dtype = _host_dtype(arrays)

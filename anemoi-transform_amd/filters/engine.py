@@ -63,7 +63,7 @@ def run_level_ops(
     if not positions:
         return FieldList(out)
 
-    for group in group_into_stacks(fields, positions):
+    for group in group_into_stacks(fields, positions, sparse_ok=True):
         src = group.stack
         if point_mask is not None:
             # R: apply_mask.py:185 would raise IndexError on a mask of the wrong length
@@ -73,13 +73,15 @@ def run_level_ops(
                     f"field has {src.n_pts}"
                 )
         dst = src.new_like()
-        stage = [level_op(f) for f in group.fields]
+        stage: list[LevelOp] = [(native.OP_COPY, 0, 0.0, 0.0)] * src.n_lev  # levels outside the group: untouched
+        for level, f in zip(group.levels, group.fields):
+            stage[level] = level_op(f)
         prog = native.level_program([stage], src.device)
         native.pointwise_stack(
             src.data, dst.data, n_pts=src.n_pts, n_lev=src.n_lev, x_pitch=src.pitch, y_pitch=dst.pitch,
             layout=src.layout, prog=prog, n_stage=1,
             point_mask=None if point_mask is None else point_mask.tensor,
         )
-        for level, (pos, f) in enumerate(zip(group.positions, group.fields)):
+        for level, pos, f in zip(group.levels, group.positions, group.fields):
             out[pos] = new_field_from_stack(dst, level, template=f, metadata=new_metadata(f))
     return FieldList(out)

@@ -119,16 +119,22 @@ def _run_segment(data: Any, head: RegridFilter | None, stages: list[Stage]) -> F
         positions = [i for i in range(n) if touched[i]]
         if not positions:
             return FieldList(out)
-        for group in group_into_stacks(fields, positions):
+        for group in group_into_stacks(fields, positions, sparse_ok=True):
             src = group.stack
             if mask is not None and mask.n_points != src.n_pts:
                 raise IndexError(f"boolean index did not match indexed array: mask has {mask.n_points} points, field has {src.n_pts}")
             dst = src.new_like()
-            prog = native.level_program([[row[p] for p in group.positions] for row in ops], src.device)
+            stages = []
+            for row in ops:
+                stage = [COPY] * src.n_lev
+                for level, p in zip(group.levels, group.positions):
+                    stage[level] = row[p]
+                stages.append(stage)
+            prog = native.level_program(stages, src.device)
             native.pointwise_stack(src.data, dst.data, n_pts=src.n_pts, n_lev=src.n_lev, x_pitch=src.pitch, y_pitch=dst.pitch,
                                    layout=src.layout, prog=prog, n_stage=len(ops),
                                    point_mask=None if mask is None else mask.tensor)
-            for level, pos in enumerate(group.positions):
+            for level, pos in zip(group.levels, group.positions):
                 out[pos] = new_field_from_stack(dst, level, template=proxies[pos])
         return FieldList(out)
 

@@ -604,3 +604,62 @@ def test_every_registered_filter_is_a_factory():
                           "z_to_orog": "height_to_geopotential", "clipper": "clip", "replace_nans": "impute_nans"}.items():
         assert filter_registry.lookup(alias) is filter_registry.lookup(target)
     assert create_filter_by_name("noop", context="ctx").context == "ctx"
+
+
+class ForeignField:
+    """A field that is NOT one of ours — the surface an earthkit-data field offers to the filters
+    (SURVEY.md §8b): to_numpy / metadata / grid_points / shape."""
+
+    def __init__(self, values, lat, lon, **md):
+        self._v, self._lat, self._lon, self._md = np.asarray(values), lat, lon, md
+        self.shape = self._v.shape
+
+    def to_numpy(self, flatten=False, dtype=None, index=None):
+        v = self._v.astype(dtype) if dtype is not None else self._v.copy()
+        return v.flatten() if flatten else v
+
+    def grid_points(self):
+        return self._lat, self._lon
+
+    def metadata(self, *keys, namespace=None, default=None, **kw):
+        if namespace:
+            return {}
+        if not keys:
+            md = self._md
+
+            class View:
+                def get(self, key, default=None):
+                    return md.get(key, default)
+
+                def keys(self):
+                    return md.keys()
+
+                def __getitem__(self, key):
+                    return md[key]
+
+            return View()
+        out = []
+        for k in keys:
+            if k not in self._md:
+                raise KeyError(k)
+            out.append(self._md[k])
+        return out[0] if len(out) == 1 else tuple(out)
+
+
+def test_foreign_fields_are_accepted(engine):
+    """Fields from another library (earthkit-data when installed) go through the same filters."""
+    from anemoi_transform_amd.fields import FieldList
+    from anemoi_transform_amd.grids import lookup
+
+    src, tgt = lookup("o16"), lookup([20.0, 20.0])
+    rng = np.random.default_rng(2)
+    fields = FieldList([ForeignField(280 + rng.standard_normal(len(src["latitudes"])), src["latitudes"], src["longitudes"],
+                                     param=p, levelist=l) for p, l in (("t", 500), ("orog", 0), ("t", 850))])
+    out = (create_filter_by_name("regrid", out_grid=tgt, method="nearest") | create_filter_by_name("orog_to_z")
+           | create_filter_by_name("rescale", scale=1.0, offset=-273.15, param="t")).forward(fields)
+    idx = oracle.nearest_grid_points(src["latitudes"], src["longitudes"], tgt["latitudes"], tgt["longitudes"])
+    assert [f.metadata("param") for f in out] == ["t", "z", "t"] and [f.metadata("levelist") for f in out] == [500, 0, 850]
+    assert np.array_equal(out[0].to_numpy(), oracle.rescale_forward(fields[0].to_numpy()[idx], 1.0, -273.15))
+    assert np.array_equal(out[1].to_numpy(), oracle.orog_to_z(fields[1].to_numpy()[idx]))
+    assert np.array_equal(out[2].grid_points()[0], tgt["latitudes"])
+    assert out[0].metadata().get("param") == "t" and "levelist" in list(out[0].metadata().keys())

@@ -151,3 +151,28 @@ def test_flatten_and_stage_detection():
     assert fusion.as_stage(b.reverse()) is not None
     assert fusion.as_stage(create_filter_by_name("clip", param="t", minimum=0.0).reverse()) is None  # clip is not reversible
     assert fusion.as_stage(create_filter_by_name("apply_mask", mask_param="lsm", mask_value=0)) is None
+
+
+def test_sparse_selection_on_a_device_stack_keeps_levels_in_place(engine):
+    """A per-point filter that selects most (>= half) of the levels of an HBM stack transforms the stack as a
+    whole (unselected levels untouched) instead of copying the selected levels out first."""
+    src, tgt = lookup("o16"), lookup([20.0, 20.0])
+    specs = synthetic_fields(src, 6, nan_frac=0.01)
+    for i, p in enumerate(["t", "t", "q", "t", "t", "orog"]):
+        specs[i]["param"] = p
+    on_device = create_filter_by_name("regrid", out_grid=tgt, method="nearest").forward(test_source(specs).ds)
+    stack = on_device[0].stack_ref()[0]
+    assert all(f.stack_ref()[0] is stack for f in on_device)
+    out = create_filter_by_name("rescale", scale=2.0, offset=-1.0, param="t").forward(on_device)
+    new_stack = out[0].stack_ref()[0]
+    assert new_stack is not stack and new_stack.n_lev == stack.n_lev
+    for i, f in enumerate(out):
+        if specs[i]["param"] == "t":
+            assert f.stack_ref() == (new_stack, i)  # same level index in the new stack: no compaction copy
+            assert np.array_equal(f.to_numpy(), oracle.rescale_forward(on_device[i].to_numpy(), 2.0, -1.0), equal_nan=True)
+        else:
+            assert f is on_device[i]
+    # a minority selection is compacted as before
+    out = create_filter_by_name("orog_to_z").forward(on_device)
+    assert out[5].stack_ref()[0].n_lev == 1 and out[0] is on_device[0]
+    assert np.array_equal(out[5].to_numpy(), oracle.orog_to_z(on_device[5].to_numpy()), equal_nan=True)
