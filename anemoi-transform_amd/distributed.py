@@ -6,7 +6,8 @@ single-process loop.  The partitioning follows SURVEY.md §8e:
 
 * row ``t`` of the interpolation operator reads only source points and writes only
   target ``t``, so ``[0, n_tgt)`` is cut into ``world`` contiguous slices
-  (``GatherPlan.shard``) and the slices never talk to each other;
+  (``GatherPlan.shard``; boundaries balanced by HBM traffic, not by count) and the slices never talk
+  to each other;
 * every rank needs the source stack: it is broadcast ONCE (``broadcast_stack``,
   one RCCL broadcast of the contiguous stack tensor) — or, better, each rank only
   loads the band of source columns its slice references (``source_band``): in the
@@ -23,7 +24,7 @@ import numpy as np
 import torch
 import torch.distributed as dist
 
-from .gather import GatherPlan, shard_bounds
+from .gather import GatherPlan
 from .stack import COLUMNS, Stack
 
 
@@ -91,13 +92,14 @@ def sharded_regrid(plan: GatherPlan, src: Stack, rank: int | None = None, world:
     return plan.shard(rank, world).apply(src)
 
 
-def gather_target_shards(local: Stack, n_tgt: int) -> Stack:
-    """All target slices on every rank (column layout: each slice is a contiguous row range)."""
+def gather_target_shards(local: Stack, plan: GatherPlan) -> Stack:
+    """All target slices of ``plan`` on every rank (column layout: each slice is a contiguous row range)."""
     assert local.layout == COLUMNS, "target shards are row ranges of a column stack"
     rank, world = dist.get_rank(), dist.get_world_size()
+    n_tgt = plan.n_tgt
     full = Stack.empty(n_tgt, local.n_lev, local.dtype, local.device, COLUMNS)
     for r in range(world):
-        lo, hi = shard_bounds(n_tgt, r, world)
+        lo, hi = plan.shard_range(r, world)
         if r == rank:
             assert local.n_pts == hi - lo
             full.data[lo:hi].copy_(local.data)

@@ -143,9 +143,7 @@ def _run_segment(data: Any, head: RegridFilter | None, stages: list[Stage]) -> F
         plan = interp.plan_for(group.fields[0])
         lat, lon = interp.out_latlon(group.fields[0])
         if head.shard is not None:
-            from ..gather import shard_bounds
-
-            lo, hi = shard_bounds(plan.n_tgt, *head.shard)
+            lo, hi = plan.shard_range(*head.shard)
             plan, lat, lon = interp._sharded(plan, head.shard), lat[lo:hi], lon[lo:hi]
         kwargs = {}
         if any(touched[p] for p in group.positions):

@@ -63,9 +63,7 @@ class _Interpolator:
             plan = self.plan_for(group.fields[0])
             lat, lon = self.out_latlon(group.fields[0])
             if shard is not None:
-                from ..gather import shard_bounds
-
-                lo, hi = shard_bounds(plan.n_tgt, *shard)
+                lo, hi = plan.shard_range(*shard)
                 plan, lat, lon = self._sharded(plan, shard), lat[lo:hi], lon[lo:hi]
             regridded = plan.apply(group.stack)
             for level, (pos, f) in enumerate(zip(group.positions, group.fields)):

@@ -26,6 +26,12 @@ from . import native
 from .stack import Stack
 
 
+# Cost of one target column relative to one first-touched source column in ``GatherPlan.bounds``: the stored column plus
+# its k table entries are 1.06 column-equivalents at 137 f32 levels; a least-squares fit of measured per-shard times
+# on MI355X (O1280 -> 0.25 degree, 8 shards, equal-count and balanced cuts) gives 1.10.
+TARGET_COST = 1.1
+
+
 class GatherPlan:
     def __init__(
         self,
@@ -136,9 +142,47 @@ class GatherPlan:
             index = np.where(index < 0, index + n_src, index)  # numpy indexing accepts negatives
         return cls(n_src, len(index), index=index)
 
+    def bounds(self, world: int) -> list[int]:
+        """Target boundaries ``b[0] = 0 <= ... <= b[world] = n_tgt`` of the ``world`` contiguous shards,
+        balanced by estimated HBM TRAFFIC rather than by target count.
+
+        A shard's cost is the number of distinct source columns it reads plus (weighted) the target columns
+        it writes.  On a lat-lon target grid equal-count shards are badly unbalanced — near the poles many
+        targets share few source columns: measured 0.31 ms (polar) vs 0.57 ms (equatorial) per step on
+        O1280 -> 0.25 degree at 8 shards, which would cap weak scaling at 82 %; balanced: within a few %
+        (profiles/r01_shard_balance.log).
+        """
+        cached = self.__dict__.setdefault("_bounds", {})
+        if world not in cached:
+            if world <= 1 or self.n_tgt == 0:
+                cached[world] = [0] + [self.n_tgt] * max(world, 1)
+            else:
+                if self.kind == "ell":
+                    flat = self.index.reshape(-1).astype(np.int64)
+                    row_of = np.arange(flat.size) // self.k
+                    valid = flat >= 0
+                    flat, row_of = flat[valid], row_of[valid]
+                else:
+                    flat = self.indices.astype(np.int64)
+                    row_of = np.repeat(np.arange(self.n_tgt), np.diff(self.indptr))
+                # source columns first referenced by each target, in target order
+                _, first = np.unique(flat, return_index=True)
+                new_sources = np.bincount(row_of[first], minlength=self.n_tgt).astype(np.float64)
+                cost = np.cumsum(new_sources + TARGET_COST)
+                edges = np.searchsorted(cost, cost[-1] * np.arange(1, world) / world, side="left") + 1
+                b = [0] + [int(min(max(e, 0), self.n_tgt)) for e in edges] + [self.n_tgt]
+                for i in range(1, len(b)):
+                    b[i] = max(b[i], b[i - 1])
+                cached[world] = b
+        return cached[world]
+
+    def shard_range(self, rank: int, world: int) -> tuple[int, int]:
+        b = self.bounds(world)
+        return b[rank], b[rank + 1]
+
     def shard(self, rank: int, world: int) -> "GatherPlan":
-        """The contiguous ``rank``-th of ``world`` slices of the target points."""
-        lo, hi = shard_bounds(self.n_tgt, rank, world)
+        """The ``rank``-th of ``world`` contiguous, traffic-balanced slices of the target points."""
+        lo, hi = self.shard_range(rank, world)
         if self.kind == "ell":
             return GatherPlan(self.n_src, hi - lo, index=self.index[lo:hi],
                               weights=None if self.weights is None else self.weights[lo:hi], padded=self.padded)

@@ -155,8 +155,11 @@ def main():
     precompute_s = time.perf_counter() - t0
     n_unique = int(np.unique(idx64).size)
 
-    # target-point shard of this rank (contiguous, balanced)
-    bounds = [(n_tgt * r) // world for r in range(world + 1)]
+    # target-point shard of this rank: contiguous, balanced by HBM traffic (GatherPlan.bounds) — equal-count
+    # shards of a lat-lon target are 1.8x apart in cost (polar targets share their source columns)
+    from anemoi_transform_amd.gather import GatherPlan
+
+    bounds = GatherPlan(n_src, n_tgt, index=idx64, weights=w64).bounds(world)
     lo, hi = bounds[rank], bounds[rank + 1]
     idx_d = torch.from_numpy(idx64[lo:hi].astype(np.int32)).to(dev)
     w_d = torch.from_numpy(w64[lo:hi].astype(np_dtype)).to(dev)
@@ -206,7 +209,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    units_per_step = n_tgt * args.levels * world  # all ranks: N stacks x full target grid
+    units_per_step = n_tgt * args.levels * world  # all ranks together: N stacks x the full target grid (shards tile it)
     value = units_per_step * args.steps / elapsed
 
     # ---- roofline of the dominant kernel, HIP events around single launches
@@ -242,7 +245,7 @@ def main():
                         f"k={args.k} inverse-distance regrid x {args.levels} levels per stack",
             "layout": args.layout,
             "stacks_per_step": world,
-            "sharding": "target points over ranks; sources exchanged once by RCCL broadcast before timing"
+            "sharding": "target points over ranks (contiguous, traffic-balanced); sources exchanged once by RCCL broadcast before timing"
                         if world > 1 else "single GPU",
             "launches_per_step_per_gpu": world,
             **({"rehearsal": "ranks share one GPU over gloo; not a scaling measurement"} if args.share_device else {}),

@@ -75,7 +75,7 @@ def _worker(rank: int, world: int, port: int, kind: str, tmpdir: str) -> None:
         expect = 280.0 + np.random.default_rng(100 + r).standard_normal((n_lev, n_src))
         assert np.array_equal(st.numpy(), expect)
         local = atxd.sharded_regrid(plan, st)
-        full = atxd.gather_target_shards(local, n_tgt)
+        full = atxd.gather_target_shards(local, plan)
         want = np.stack([oracle.csr_apply(data, indices, indptr, (n_tgt, n_src), f) for f in expect])
         assert np.array_equal(full.numpy(), want), f"rank {rank} stack {r}"
 

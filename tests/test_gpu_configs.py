@@ -69,7 +69,8 @@ def test_config4_batched_stacks_target_sharded_8_ways(dev):
     idx, w = interp.knn_inverse_distance(src, tgt, k=4, device=True)
     plan = GatherPlan(n_src, n_tgt, index=idx, weights=w)
     shards = [plan.shard(r, 8) for r in range(8)]
-    assert sum(s.n_tgt for s in shards) == n_tgt and max(s.n_tgt for s in shards) - min(s.n_tgt for s in shards) <= 1
+    assert sum(s.n_tgt for s in shards) == n_tgt  # contiguous shards, balanced by traffic (near equal on this grid pair)
+    assert max(s.n_tgt for s in shards) < 1.05 * min(s.n_tgt for s in shards)
     indptr = np.arange(n_tgt + 1) * 4
     for stack_id in range(4):  # 2 variables x 2 timesteps
         x = synth(src, n_lev, dev, 100 + stack_id)

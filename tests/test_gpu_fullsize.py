@@ -93,6 +93,11 @@ def test_shards_concatenate_bit_exact(case):
     full = case["plan"].apply(case["x"]).data
     parts = [case["plan"].shard(r, 8).apply(case["x"]).data for r in range(8)]
     assert torch.equal(torch.cat(parts).view(torch.int32), full.view(torch.int32))
+    # shard boundaries are balanced by traffic: polar shards of the lat-lon target hold more targets
+    sizes = [p.shape[0] for p in parts]
+    assert sizes[0] > 1.3 * sizes[3] and sizes[7] > 1.3 * sizes[4] and sum(sizes) == case["n_tgt"]
+    cost = [np.unique(case["idx"][b0:b1]).size + 1.1 * (b1 - b0) for b0, b1 in zip(case["plan"].bounds(8)[:-1], case["plan"].bounds(8)[1:])]
+    assert max(cost) < 1.1 * min(cost)
 
 
 def test_layouts_agree_bit_exact(case):

@@ -119,9 +119,13 @@ def test_gather_plan_validation_and_sharding():
     parts = [plan.shard(r, 3) for r in range(3)]
     assert sum(p.n_tgt for p in parts) == 7
     assert np.array_equal(np.concatenate([p.index for p in parts]), plan.index)
+    b = plan.bounds(3)
+    assert b[0] == 0 and b[-1] == 7 and all(b[i] <= b[i + 1] for i in range(3))
     csr = GatherPlan(10, 3, csr=(np.ones(5), np.array([1, 2, 3, 4, 5]), np.array([0, 2, 2, 5])))
     s = csr.shard(1, 2)
-    assert s.n_tgt == 2 and np.array_equal(s.indptr, [0, 0, 3]) and np.array_equal(s.indices, [3, 4, 5])
+    assert s.n_tgt == csr.bounds(2)[2] - csr.bounds(2)[1] and s.indptr[0] == 0 and s.indptr[-1] == len(s.indices)
+    both = [csr.shard(r, 2) for r in range(2)]
+    assert np.array_equal(np.concatenate([p.indices for p in both]), csr.indices)
     assert [shard_bounds(10, r, 4) for r in range(4)] == [(0, 2), (2, 5), (5, 7), (7, 10)]
     m = GatherPlan.from_mask(np.array([True, False, True, True]))
     assert m.k == 1 and np.array_equal(m.index[:, 0], [0, 2, 3])

@@ -1,0 +1,41 @@
+#!/usr/bin/env python3
+"""Per-shard cost of the target-sharded regrid on ONE GPU: time of `world` launches (one per stack) for
+every rank's shard, with equal-count and with traffic-balanced shard boundaries.  The slowest rank sets the
+multi-GPU step time, so max/mean over ranks bounds the weak-scaling efficiency."""
+import os, sys, time
+import numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import __graft_entry__ as graft, bench
+graft.load_package()
+from anemoi_transform_amd import native, interp
+from anemoi_transform_amd.gather import GatherPlan
+from anemoi_transform_amd.grids import lookup
+from anemoi_transform_amd.stack import COLUMNS, Stack
+
+dev = torch.device('cuda', 0); torch.cuda.set_device(dev)
+src, tgt = lookup('o1280'), lookup('0.25')
+n_src, n_tgt, L = len(src['latitudes']), len(tgt['latitudes']), 137
+idx, w = interp.knn_inverse_distance(src, tgt, k=4, device=True)
+plan = GatherPlan(n_src, n_tgt, index=idx, weights=w)
+world = int(sys.argv[1]) if len(sys.argv) > 1 else 8
+stacks = [bench.synth_stack(src, L, torch.float32, dev, s, COLUMNS) for s in range(world)]
+for name, bounds in (("equal-count", [(n_tgt * r) // world for r in range(world + 1)]),
+                     ("traffic-balanced", plan.bounds(world))):
+    if bounds is None:
+        continue
+    times = []
+    for r in range(world):
+        lo, hi = bounds[r], bounds[r + 1]
+        idx_d = torch.from_numpy(idx[lo:hi].astype(np.int32)).to(dev); w_d = torch.from_numpy(w[lo:hi].astype(np.float32)).to(dev)
+        outs = [Stack.empty(hi - lo, L, torch.float32, dev, COLUMNS) for _ in range(world)]
+        def step():
+            for s, o in zip(stacks, outs):
+                native.regrid_ell(s.data, o.data, idx_d, w_d, n_src=n_src, n_tgt=hi - lo, k=4, n_lev=L, src_pitch=s.pitch, out_pitch=o.pitch, layout=COLUMNS)
+        for _ in range(3): step()
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for _ in range(10): step()
+        torch.cuda.synchronize(); times.append((time.perf_counter() - t0) / 10 * 1e3)
+        del outs
+    t = np.array(times)
+    print(f"{name:17s} world={world}: per-rank step ms {np.round(t, 3).tolist()}  max {t.max():.3f}  mean {t.mean():.3f}  "
+          f"efficiency bound mean/max = {t.mean() / t.max():.3f}", flush=True)
