@@ -166,8 +166,9 @@ def _device_neighbours_and_inside(lam_points: np.ndarray, global_points: np.ndar
     return np.sqrt(d2.cpu().numpy()), inside.cpu().numpy().astype(bool)
 
 
-def thinning_mask(lats, lons, global_lats, global_lons, cropping_distance: float = 2.0) -> np.ndarray:
-    """Indices of the LAM points closest to each global point of the surrounding box (R: spatial.py:443-503)."""
+def thinning_mask(lats, lons, global_lats, global_lons, cropping_distance: float = 2.0, device: bool = False) -> np.ndarray:
+    """Indices of the LAM points closest to each global point of the surrounding box (R: spatial.py:443-503).
+    ``device=True``: the k = 1 search runs on the GPU (``atx_knn_*``; equidistant candidates resolve to the lower index)."""
     from scipy.spatial import cKDTree
 
     _check_latlon_arrays(lats, lons, global_lats, global_lons)
@@ -177,6 +178,10 @@ def thinning_mask(lats, lons, global_lats, global_lons, cropping_distance: float
         np.max([-90.0, south - cropping_distance]), east + cropping_distance,
     )
     global_points = unit_sphere_xyz(global_lats[mask], global_lons[mask])
+    if device:
+        from .interp import nearest_grid_points_device
+
+        return nearest_grid_points_device(lats, lons, global_lats[mask], global_lons[mask])
     _, indices = cKDTree(unit_sphere_xyz(lats, lons)).query(global_points, k=1)
     return indices
 

@@ -129,3 +129,16 @@ def test_device_mask_builders_equal_the_host_ones(dev):
     a = spatial.global_on_lam_mask(lam_lats, lam_lons, glob["latitudes"], glob["longitudes"], distance_km=40.0, device=True)
     b = spatial.global_on_lam_mask(lam_lats, lam_lons, glob["latitudes"], glob["longitudes"], distance_km=40.0)
     assert np.array_equal(a, b) and len(a) > 100
+    # thinning_mask (R: spatial.py:443-503): nearest LAM point of every global point of the surrounding box.
+    # Longitudes in one convention (the box test of cropping_mask does not wrap); the jittered LAM latitudes make ties unlikely
+    glob_lons = np.where(glob["longitudes"] > 180.0, glob["longitudes"] - 360.0, glob["longitudes"])
+    a = spatial.thinning_mask(lam_lats, lam_lons, glob["latitudes"], glob_lons, device=True)
+    b = spatial.thinning_mask(lam_lats, lam_lons, glob["latitudes"], glob_lons)
+    assert a.shape == b.shape and len(a) > 100
+    same = a == b
+    xyz = spatial.unit_sphere_xyz(lam_lats, lam_lons)
+    assert same.mean() > 0.99  # any difference is an exact tie ...
+    box = spatial.cropping_mask(glob["latitudes"], glob_lons, lam_lats.max() + 2.0, lam_lons.min() - 2.0, lam_lats.min() - 2.0, lam_lons.max() + 2.0)
+    g = spatial.unit_sphere_xyz(glob["latitudes"][box], glob_lons[box])
+    da, db = ((g - xyz[a]) ** 2).sum(axis=1), ((g - xyz[b]) ** 2).sum(axis=1)
+    assert np.array_equal(da, db)  # ... i.e. the chosen neighbours are equally near
