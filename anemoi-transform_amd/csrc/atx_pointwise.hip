@@ -317,11 +317,19 @@ __global__ void reduce_init_kernel(double* result, int red) {
 
 template <typename T>
 __global__ void __launch_bounds__(kBlock)
-reduce_kernel(const T* __restrict__ x, int64_t n, int red, double* result) {
+reduce_kernel(const T* __restrict__ x, int64_t n_rows, int64_t row_len, int64_t pitch, int red, double* result) {
     double acc = red == ATX_RED_MIN ? INFINITY : (red == ATX_RED_MAX ? -INFINITY : 0.0);
     bool saw_nan = false;
-    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
-        const double v = (double)x[i];
+    // rows of `row_len` elements `pitch` apart; (row, col) advances by the grid stride without a division per element
+    const int64_t first = (int64_t)blockIdx.x * kBlock + threadIdx.x, stride = (int64_t)gridDim.x * kBlock;
+    const int64_t d_row = stride / row_len, d_col = stride - d_row * row_len;
+    int64_t row = first / row_len, col = first - row * row_len;
+    for (; row < n_rows; row += d_row, col += d_col) {
+        if (col >= row_len) {
+            col -= row_len;
+            if (++row >= n_rows) break;
+        }
+        const double v = (double)x[row * pitch + col];
         if (v != v) {
             saw_nan = true;
             if (red == ATX_RED_NANCOUNT) acc += 1.0;
@@ -476,19 +484,33 @@ extern "C" int atx_mask_to_index(const uint8_t* mask, int64_t n, int32_t* index,
     return ATX_OK;
 }
 
-extern "C" int atx_reduce(const void* x, int64_t n, int red, double* result, int dtype, void* stream) {
-    ATX_REQUIRE(x && result, ATX_EINVAL, "atx_reduce: null pointer");
-    ATX_REQUIRE(n >= 0, ATX_EINVAL, "atx_reduce: negative n");
-    ATX_REQUIRE(red >= ATX_RED_MIN && red <= ATX_RED_NANCOUNT, ATX_EINVAL, "atx_reduce: bad reduction %d", red);
-    ATX_REQUIRE(dtype == ATX_F32 || dtype == ATX_F64, ATX_EINVAL, "atx_reduce: bad dtype %d", dtype);
+static int reduce_rows(const void* x, int64_t n_rows, int64_t row_len, int64_t pitch, int red, double* result, int dtype,
+                       void* stream, const char* who) {
+    ATX_REQUIRE(x && result, ATX_EINVAL, "%s: null pointer", who);
+    ATX_REQUIRE(n_rows >= 0 && row_len >= 0, ATX_EINVAL, "%s: negative size", who);
+    ATX_REQUIRE(pitch >= row_len, ATX_ESHAPE, "%s: pitch %lld shorter than a row of %lld", who, (long long)pitch, (long long)row_len);
+    ATX_REQUIRE(red >= ATX_RED_MIN && red <= ATX_RED_NANCOUNT, ATX_EINVAL, "%s: bad reduction %d", who, red);
+    ATX_REQUIRE(dtype == ATX_F32 || dtype == ATX_F64, ATX_EINVAL, "%s: bad dtype %d", who, dtype);
     hipStream_t s = static_cast<hipStream_t>(stream);
     hipLaunchKernelGGL(reduce_init_kernel, dim3(1), dim3(1), 0, s, result, red);
     ATX_LAUNCH_CHECK("reduce_init");
-    if (n == 0) return ATX_OK;
+    if (n_rows == 0 || row_len == 0) return ATX_OK;
+    const unsigned grid = grid_for(n_rows * row_len);
     if (dtype == ATX_F32)
-        hipLaunchKernelGGL(reduce_kernel<float>, dim3(grid_for(n)), dim3(kBlock), 0, s, static_cast<const float*>(x), n, red, result);
+        hipLaunchKernelGGL(reduce_kernel<float>, dim3(grid), dim3(kBlock), 0, s, static_cast<const float*>(x), n_rows, row_len, pitch, red, result);
     else
-        hipLaunchKernelGGL(reduce_kernel<double>, dim3(grid_for(n)), dim3(kBlock), 0, s, static_cast<const double*>(x), n, red, result);
+        hipLaunchKernelGGL(reduce_kernel<double>, dim3(grid), dim3(kBlock), 0, s, static_cast<const double*>(x), n_rows, row_len, pitch, red, result);
     ATX_LAUNCH_CHECK("reduce");
     return ATX_OK;
+}
+
+extern "C" int atx_reduce(const void* x, int64_t n, int red, double* result, int dtype, void* stream) {
+    return reduce_rows(x, 1, n, n, red, result, dtype, stream, "atx_reduce");
+}
+
+extern "C" int atx_reduce_stack(const void* x, int64_t n_pts, int64_t n_lev, int64_t pitch, int red, double* result,
+                                int dtype, int layout, void* stream) {
+    ATX_REQUIRE(layout == ATX_COLUMNS || layout == ATX_FIELDS, ATX_EINVAL, "atx_reduce_stack: bad layout %d", layout);
+    if (layout == ATX_COLUMNS) return reduce_rows(x, n_pts, n_lev, pitch, red, result, dtype, stream, "atx_reduce_stack");
+    return reduce_rows(x, n_lev, n_pts, pitch, red, result, dtype, stream, "atx_reduce_stack");
 }

@@ -94,9 +94,91 @@ static int relayout_typed(const void* src_, void* dst_, int64_t n_pts, int n_lev
     return ATX_OK;
 }
 
+// ---- level selection: dst level j = src level map[j] -------------------------------------------------
+// The map of one launch travels by value in the kernel arguments (no device allocation, validated on the host).
+constexpr int kSelChunk = 256;
+struct LevelMap {
+    int32_t src_level[kSelChunk];
+};
+
+// columns: a workgroup copies `tp` points x `nj` destination levels; consecutive lanes write consecutive levels
+template <typename T>
+__global__ void __launch_bounds__(kBlock)
+select_cols_kernel(const T* __restrict__ src, T* __restrict__ dst, LevelMap map, int j0, int nj, int64_t n_pts,
+                   int64_t src_pitch, int64_t dst_pitch, int tp) {
+    __shared__ int32_t lm[kSelChunk];
+    for (int i = threadIdx.x; i < nj; i += kBlock) lm[i] = map.src_level[i];
+    __syncthreads();
+    const int64_t p0 = (int64_t)blockIdx.x * tp;
+    const int np = (int)min((int64_t)tp, n_pts - p0);
+    for (int i = threadIdx.x; i < np * nj; i += kBlock) {
+        const int p = i / nj, j = i - p * nj;
+        const int32_t l = lm[j];
+        if (l >= 0) dst[(p0 + p) * dst_pitch + j0 + j] = src[(p0 + p) * src_pitch + l];
+    }
+}
+
+// fields: grid.y = destination level, every level one contiguous row
+template <typename T>
+__global__ void __launch_bounds__(kBlock)
+select_fields_kernel(const T* __restrict__ src, T* __restrict__ dst, LevelMap map, int j0, int64_t n_pts,
+                     int64_t src_pitch, int64_t dst_pitch) {
+    const int32_t l = map.src_level[blockIdx.y];
+    if (l < 0) return;
+    const T* s = src + (int64_t)l * src_pitch;
+    T* d = dst + (int64_t)(j0 + blockIdx.y) * dst_pitch;
+    for (int64_t p = (int64_t)blockIdx.x * kBlock + threadIdx.x; p < n_pts; p += (int64_t)gridDim.x * kBlock) d[p] = s[p];
+}
+
+template <typename T>
+static int select_typed(const void* src_, void* dst_, const int32_t* level_map, int n_map, int64_t n_pts, int64_t sp,
+                        int64_t dp, int layout, hipStream_t st) {
+    const T* src = static_cast<const T*>(src_);
+    T* dst = static_cast<T*>(dst_);
+    for (int j0 = 0; j0 < n_map; j0 += kSelChunk) {
+        const int nj = n_map - j0 < kSelChunk ? n_map - j0 : kSelChunk;
+        LevelMap map;
+        bool any = false;
+        for (int j = 0; j < kSelChunk; ++j) {
+            map.src_level[j] = j < nj ? level_map[j0 + j] : -1;
+            any = any || map.src_level[j] >= 0;
+        }
+        if (!any) continue;
+        if (layout == ATX_COLUMNS) {
+            int tp = 4096 / nj;  // ~16 items per lane
+            tp = tp < 1 ? 1 : tp;
+            const unsigned gx = (unsigned)((n_pts + tp - 1) / tp);
+            hipLaunchKernelGGL(select_cols_kernel<T>, dim3(gx), dim3(kBlock), 0, st, src, dst, map, j0, nj, n_pts, sp, dp, tp);
+        } else {
+            int64_t gx = (n_pts + (int64_t)kBlock * 8 - 1) / ((int64_t)kBlock * 8);
+            gx = gx < 1 ? 1 : (gx > 4096 ? 4096 : gx);
+            hipLaunchKernelGGL(select_fields_kernel<T>, dim3((unsigned)gx, (unsigned)nj), dim3(kBlock), 0, st, src, dst, map, j0, n_pts, sp, dp);
+        }
+        ATX_LAUNCH_CHECK("select_levels");
+    }
+    return ATX_OK;
+}
+
 }  // namespace atx
 
 using namespace atx;
+
+extern "C" int atx_select_levels(const void* src, void* dst, const int32_t* level_map, int32_t n_map, int64_t n_pts,
+                                 int64_t n_src_lev, int64_t src_pitch, int64_t dst_pitch, int dtype, int layout, void* stream) {
+    ATX_REQUIRE(src && dst && (level_map || n_map == 0), ATX_EINVAL, "atx_select_levels: null pointer");
+    ATX_REQUIRE(dtype == ATX_F32 || dtype == ATX_F64, ATX_EINVAL, "atx_select_levels: bad dtype %d", dtype);
+    ATX_REQUIRE(layout == ATX_COLUMNS || layout == ATX_FIELDS, ATX_EINVAL, "atx_select_levels: bad layout %d", layout);
+    ATX_REQUIRE(n_pts >= 0 && n_map >= 0 && n_src_lev > 0, ATX_EINVAL, "atx_select_levels: bad sizes");
+    ATX_REQUIRE(src_pitch >= (layout == ATX_COLUMNS ? n_src_lev : n_pts), ATX_ESHAPE, "atx_select_levels: src pitch %lld too small", (long long)src_pitch);
+    ATX_REQUIRE(dst_pitch >= (layout == ATX_COLUMNS ? (int64_t)n_map : n_pts), ATX_ESHAPE, "atx_select_levels: dst pitch %lld too small", (long long)dst_pitch);
+    for (int32_t j = 0; j < n_map; ++j)
+        ATX_REQUIRE(level_map[j] < n_src_lev, ATX_EINVAL, "atx_select_levels: level_map[%d] = %d but the source has %lld levels",
+                    j, level_map[j], (long long)n_src_lev);
+    if (n_pts == 0 || n_map == 0) return ATX_OK;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (dtype == ATX_F32) return select_typed<float>(src, dst, level_map, n_map, n_pts, src_pitch, dst_pitch, layout, s);
+    return select_typed<double>(src, dst, level_map, n_map, n_pts, src_pitch, dst_pitch, layout, s);
+}
 
 extern "C" int atx_relayout(const void* src, void* dst, int64_t n_pts, int64_t n_lev, int64_t src_pitch,
                             int64_t dst_pitch, int src_layout, int dst_layout, int dtype, void* stream) {

@@ -31,6 +31,7 @@ from typing import Any, Iterable, Iterator
 import numpy as np
 import torch
 
+from . import native
 from . import stack as _stack
 from .stack import COLUMNS, Stack
 
@@ -501,15 +502,12 @@ def _host_dtype(arrays: list[np.ndarray]) -> torch.dtype:
 
 
 def select_levels(stack: Stack, levels: list[int]) -> Stack:
-    """A new stack holding the given levels of ``stack`` (device-side copy)."""
+    """A new stack holding the given levels of ``stack`` (device-side level gather, ``atx_select_levels``)."""
     if levels == list(range(stack.n_lev)):
         return stack
     out = Stack.empty(stack.n_pts, len(levels), stack.dtype, stack.device, stack.layout, zero=True)
-    index = torch.tensor(levels, dtype=torch.long, device=stack.device)
-    if stack.layout == COLUMNS:
-        out.data[:, : len(levels)] = stack.data.index_select(1, index)
-    else:
-        out.data[: len(levels), : stack.n_pts] = stack.data.index_select(0, index)[:, : stack.n_pts]
+    native.select_levels(stack.data, out.data, levels, n_pts=stack.n_pts, n_src_lev=stack.n_lev, src_pitch=stack.pitch,
+                         dst_pitch=out.pitch, layout=stack.layout)
     return out
 
 
@@ -554,28 +552,39 @@ def group_into_stacks(fields: Iterable[Any], positions: list[int] | None = None,
 def fields_to_stack(fields: list[Any]) -> Stack:
     """One HBM stack whose level ``i`` is ``fields[i]`` (all on the same grid), in that order.
 
-    Fields that already are levels of one stack are selected on the device; anything else
-    (host fields, levels of different stacks) is gathered column by column.
+    Fields that already are levels of one stack are selected on the device (``atx_select_levels``); host fields
+    are uploaded as one staged stack; levels of several stacks are gathered stack by stack.
     """
     refs = [f.stack_ref() if isinstance(f, Field) else None for f in fields]
     if all(r is not None for r in refs) and all(r[0] is refs[0][0] for r in refs):
         return select_levels(refs[0][0], [r[1] for r in refs])
+    # mixed origins: host fields go up as one staged stack, every device stack contributes its levels by one level gather
     dev = _stack.device()
-    columns = []
-    for f, r in zip(fields, refs):
-        if r is not None:
-            columns.append(r[0].level_view(r[1]))
-        else:
-            host = np.ascontiguousarray(f.to_numpy(flatten=True))
-            if host.dtype not in (np.float32, np.float64):
-                host = host.astype(np.float64)
-            columns.append(torch.from_numpy(host).to(dev))
+    host_pos = [i for i, r in enumerate(refs) if r is None]
+    host_arrays = [np.ascontiguousarray(fields[i].to_numpy(flatten=True)) for i in host_pos]
+    host_arrays = [a if a.dtype in (np.float32, np.float64) else a.astype(np.float64) for a in host_arrays]
+    device_stacks: dict[int, Stack] = {id(r[0]): r[0] for r in refs if r is not None}
     if _upload_dtype is not None:
         dtype = _upload_dtype
     else:
-        dtype = torch.float32 if all(c.dtype == torch.float32 for c in columns) else torch.float64
-    n_pts = columns[0].numel()
-    assert all(c.numel() == n_pts for c in columns), "fields of one stack must share a grid"
-    out = Stack.empty(n_pts, len(columns), dtype, dev, COLUMNS, zero=True)
-    out.data[:, : len(columns)] = torch.stack([c.to(dtype) for c in columns], dim=1)
+        all_f32 = all(a.dtype == np.float32 for a in host_arrays) and all(st.dtype == torch.float32 for st in device_stacks.values())
+        dtype = torch.float32 if all_f32 else torch.float64
+    sizes = {a.size for a in host_arrays} | {st.n_pts for st in device_stacks.values()}
+    assert len(sizes) == 1, "fields of one stack must share a grid"
+    n_pts = sizes.pop()
+    if not device_stacks:
+        return Stack.from_fields(host_arrays, dtype=dtype, dev=dev)
+    out = Stack.empty(n_pts, len(fields), dtype, dev, COLUMNS, zero=True)
+    sources: list[tuple[Stack, dict[int, int]]] = []  # (stack, {destination level: source level})
+    if host_pos:
+        staged = Stack.from_fields(host_arrays, dtype=dtype, dev=dev)
+        sources.append((staged, {pos: j for j, pos in enumerate(host_pos)}))
+    for key, st in device_stacks.items():
+        if st.dtype != dtype:  # mixed precision across stacks: widen the narrower one (a cast, not arithmetic)
+            st = Stack(st.data.to(dtype), st.n_pts, st.n_lev, st.layout)
+        sources.append((st.to_layout(COLUMNS), {i: r[1] for i, r in enumerate(refs) if r is not None and id(r[0]) == key}))
+    for st, wanted in sources:
+        level_map = [wanted.get(j, -1) for j in range(len(fields))]
+        native.select_levels(st.data, out.data, level_map, n_pts=n_pts, n_src_lev=st.n_lev, src_pitch=st.pitch,
+                             dst_pitch=out.pitch, layout=COLUMNS)
     return out

@@ -84,6 +84,8 @@ SIGNATURES: dict[str, tuple[Any, list[Any]]] = {
     "atx_cutout_inside": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int32, c_void_p, c_void_p]),
     "atx_reduce": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_int, c_void_p]),
     "atx_relayout": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int64, c_int, c_int, c_int, c_void_p]),
+    "atx_reduce_stack": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_int, c_void_p, c_int, c_int, c_void_p]),
+    "atx_select_levels": (c_int, [c_void_p, c_void_p, c_void_p, c_int32, c_int64, c_int64, c_int64, c_int64, c_int, c_int, c_void_p]),
 }
 
 _lib: ctypes.CDLL | None = None
@@ -300,6 +302,21 @@ def reduce(x, red: int, n: int | None = None) -> float:
     result = torch.zeros(1, dtype=torch.float64, device=x.device)
     _call("atx_reduce", _ptr(x), n, red, _ptr(result), dtype_code(x.dtype), _stream())
     return float(result.item())
+
+
+def reduce_stack(x, red: int, *, n_pts: int, n_lev: int, pitch: int, layout: int) -> float:
+    """``atx_reduce`` over the elements of a pitched stack (padding excluded)."""
+    result = torch.zeros(1, dtype=torch.float64, device=x.device)
+    _call("atx_reduce_stack", _ptr(x), n_pts, n_lev, pitch, red, _ptr(result), dtype_code(x.dtype), layout, _stream())
+    return float(result.item())
+
+
+def select_levels(src, dst, level_map, *, n_pts, n_src_lev, src_pitch, dst_pitch, layout) -> None:
+    """dst level j = src level ``level_map[j]`` (negative: leave dst level j alone); ``level_map`` is a host sequence."""
+    assert src.dtype == dst.dtype
+    lm = (ctypes.c_int32 * len(level_map))(*[int(l) for l in level_map])
+    _call("atx_select_levels", _ptr(src), _ptr(dst), ctypes.cast(lm, c_void_p), len(level_map), n_pts, n_src_lev,
+          src_pitch, dst_pitch, dtype_code(src.dtype), layout, _stream())
 
 
 def relayout(src, dst, *, n_pts, n_lev, src_pitch, dst_pitch, src_layout, dst_layout) -> None:

@@ -126,9 +126,14 @@ class Stack:
 
     def level_numpy(self, level: int) -> np.ndarray:
         """One field as a flat host array — the reference's ``to_numpy(flatten=True)`` (implies D2H)."""
-        return self.level_view(level).contiguous().cpu().numpy()
+        if self.layout == FIELDS:
+            return self.data[level, : self.n_pts].cpu().numpy()
+        row = torch.empty((1, self.n_pts), dtype=self.dtype, device=self.device)
+        native.relayout(self.data[:, level : level + 1], row, n_pts=self.n_pts, n_lev=1, src_pitch=self.pitch,
+                        dst_pitch=self.n_pts, src_layout=COLUMNS, dst_layout=FIELDS)
+        return row[0].cpu().numpy()
 
     def numpy(self) -> np.ndarray:
         """All fields, field-major ``[n_lev, n_pts]``, on the host."""
         fm = self.to_layout(FIELDS)
-        return fm.data[:, : self.n_pts].contiguous().cpu().numpy()
+        return fm.data[:, : self.n_pts].cpu().numpy()  # a FIELDS stack has pitch n_pts: already contiguous

@@ -232,6 +232,9 @@ typedef enum { ATX_RED_MIN = 0, ATX_RED_MAX = 1, ATX_RED_NANCOUNT = 2 } atx_red;
  *   R: filters/fields/cos_sin_from_rad.py:73-76 `data.min()/max()`;
  *      tests/field_filters/test_apply_mask.py:106 `np.sum(np.isnan(result))` */
 int atx_reduce(const void* x, int64_t n, int red, double* result, int dtype, void* stream);
+/* the same over the n_pts x n_lev elements of a (pitched) stack, padding excluded */
+int atx_reduce_stack(const void* x, int64_t n_pts, int64_t n_lev, int64_t pitch, int red, double* result,
+                     int dtype, int layout, void* stream);
 
 /* ---- k-nearest-neighbour index build ---------------------------------------- */
 /* Exact k-NN on the unit sphere by chord distance — device counterpart of
@@ -264,6 +267,13 @@ int atx_cutout_inside(const double* global_xyz, int64_t n, const double* lam_xyz
 int atx_relayout(const void* src, void* dst, int64_t n_pts, int64_t n_lev,
                  int64_t src_pitch, int64_t dst_pitch, int src_layout, int dst_layout,
                  int dtype, void* stream);
+
+/* dst level j = src level level_map[j] for j in [0, n_map); a negative entry leaves dst level j untouched.
+ * Both stacks in `layout`; level_map is a HOST array (validated before launch, passed to the kernel by value).
+ *   R: filter.py:188-196 / fields.py:35-48 — the reference re-lists fields freely (a FieldList is a Python
+ *      list of independent arrays); on a stack, re-listing is this level gather. */
+int atx_select_levels(const void* src, void* dst, const int32_t* level_map, int32_t n_map, int64_t n_pts,
+                      int64_t n_src_lev, int64_t src_pitch, int64_t dst_pitch, int dtype, int layout, void* stream);
 
 #ifdef __cplusplus
 }

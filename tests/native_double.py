@@ -178,8 +178,25 @@ def relayout(src, dst, *, n_pts, n_lev, src_pitch, dst_pitch, src_layout, dst_la
     _levels(dst, n_pts, n_lev, dst_layout)[...] = _levels(src, n_pts, n_lev, src_layout)
 
 
+def reduce_stack(x, red, *, n_pts, n_lev, pitch, layout):
+    a = _levels(x, n_pts, n_lev, layout)
+    if red == native.RED_MIN:
+        return float(a.min())
+    if red == native.RED_MAX:
+        return float(a.max())
+    return float(np.isnan(a).sum())
+
+
+def select_levels(src, dst, level_map, *, n_pts, n_src_lev, src_pitch, dst_pitch, layout):
+    s, d = _levels(src, n_pts, n_src_lev, layout), _levels(dst, n_pts, len(level_map), layout)
+    for j, l in enumerate(level_map):
+        assert l < n_src_lev
+        if l >= 0:
+            d[j] = s[l]
+
+
 PATCHED = ["regrid_ell", "regrid_csr", "check_indices", "pointwise_stack", "combine_stack", "mask_build", "mask_count", "mask_to_index",
-           "reduce", "relayout"]
+           "reduce", "relayout", "reduce_stack", "select_levels"]
 
 
 def install(monkeypatch) -> None:

@@ -347,6 +347,42 @@ def test_relayout_round_trip(dev, tdtype, np_dtype, n_lev, n_pts):
 
 @pytest.mark.parametrize("tdtype,np_dtype", DTYPES)
 @pytest.mark.parametrize("layout", LAYOUTS)
+@pytest.mark.parametrize("n_lev,n_pts,n_out", [(1, 1, 1), (7, 1000, 3), (137, 5003, 137), (300, 700, 290)])
+def test_select_levels_and_stack_reductions(dev, tdtype, np_dtype, layout, n_lev, n_pts, n_out):
+    """Level gather (re-listing fields of a stack) is a bit copy; untouched levels keep their content;
+    reductions over a pitched stack ignore the padding."""
+    rng = np.random.default_rng(23)
+    x = make_fields(rng, n_lev, n_pts, np_dtype, nan_frac=0.01)
+    st = Stack.from_fields(x, dev=dev, layout=layout)
+    itype = np.uint32 if np_dtype == np.float32 else np.uint64
+    level_map = rng.integers(0, n_lev, n_out).tolist()  # repeats allowed
+    if n_out > 2:
+        level_map[1] = -1
+    out = Stack.empty(n_pts, n_out, tdtype, dev, layout)
+    out.data.fill_(7.0)
+    native.select_levels(st.data, out.data, level_map, n_pts=n_pts, n_src_lev=n_lev, src_pitch=st.pitch, dst_pitch=out.pitch, layout=layout)
+    got = out.numpy()
+    want = np.stack([x[l] if l >= 0 else np.full(n_pts, 7.0, np_dtype) for l in level_map])
+    assert np.array_equal(got.view(itype), want.view(itype))
+    with pytest.raises(ValueError):
+        native.select_levels(st.data, out.data, [n_lev] * n_out, n_pts=n_pts, n_src_lev=n_lev, src_pitch=st.pitch, dst_pitch=out.pitch, layout=layout)
+    # pitched reductions: poison the padding of a columns stack, it must not be seen
+    if layout == COLUMNS and st.pitch > n_lev:
+        st.data[:, n_lev:] = float("nan")
+    kw = dict(n_pts=n_pts, n_lev=n_lev, pitch=st.pitch, layout=layout)
+    assert native.reduce_stack(st.data, native.RED_NANCOUNT, **kw) == float(np.isnan(x).sum())
+    clean = np.nan_to_num(x, nan=0.5)
+    sc = Stack.from_fields(clean, dev=dev, layout=layout)
+    if layout == COLUMNS and sc.pitch > n_lev:
+        sc.data[:, n_lev:] = 1e30
+    assert native.reduce_stack(sc.data, native.RED_MIN, **kw) == float(clean.min())
+    if layout == COLUMNS and sc.pitch > n_lev:
+        sc.data[:, n_lev:] = 1e30
+    assert native.reduce_stack(sc.data, native.RED_MAX, **kw) == float(clean.max())
+
+
+@pytest.mark.parametrize("tdtype,np_dtype", DTYPES)
+@pytest.mark.parametrize("layout", LAYOUTS)
 def test_padded_ragged_rows_run_on_the_fixed_k_kernel(dev, tdtype, np_dtype, layout):
     """Short ragged CSR rows (0..4 entries, like MIR's matrices) become fixed-k rows padded with index -1;
     absent entries are skipped, not multiplied by zero: inf / NaN in the source behave as in scipy."""
