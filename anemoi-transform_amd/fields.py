@@ -339,21 +339,32 @@ _HOST_CACHE_ATTR = "_host_fields"
 
 
 def host_level(stack: Stack, level: int) -> np.ndarray:
-    """One level of a stack as a fresh host array.
+    """One level of a stack as a fresh host array (``to_numpy`` returns a copy, R: fields.py:198-199).
 
-    The first access brings the whole stack over in ONE device-to-host copy
-    (field-major, through the relayout kernel); later accesses are slices of it.
-    Stacks are immutable once published to a FieldList, so the copy cannot go stale.
+    The first access brings the whole stack over in ONE device-to-host copy (field-major, through the
+    relayout kernel, into pinned memory) and splits it into one private array per level with a few
+    threads; each of those is handed out once, later accesses of the same level copy from the pinned image.
+    Stacks are immutable once published to a FieldList, so the image cannot go stale.
     """
     cached = _host_cache.get(id(stack))
     if cached is None or cached[0] is not stack:
-        cached = (stack, stack.numpy())
+        image = stack.numpy()
+        if image.nbytes >= _stack._PINNED_MIN_BYTES and image.nbytes <= _SPLIT_MAX_BYTES:
+            handouts = list(_stack.copy_pool().map(np.copy, image))
+        else:
+            handouts = [None] * len(image)
+        cached = (stack, image, handouts)
         _host_cache.clear()  # keep at most one stack on the host
         _host_cache[id(stack)] = cached
+    ready = cached[2][level]
+    if ready is not None:
+        cached[2][level] = None
+        return ready
     return cached[1][level].copy()
 
 
-_host_cache: dict[int, tuple[Stack, np.ndarray]] = {}
+_SPLIT_MAX_BYTES = 8 << 30
+_host_cache: dict[int, tuple[Stack, np.ndarray, list]] = {}
 
 
 # ---- reference factory functions --------------------------------------------------------
@@ -501,6 +512,14 @@ def _host_dtype(arrays: list[np.ndarray]) -> torch.dtype:
     return torch.float32 if all(a.dtype == np.float32 for a in arrays) else torch.float64
 
 
+def host_values(field: Any) -> np.ndarray:
+    """The flattened values of a host field for upload — without the copy ``to_numpy(flatten=True)`` makes
+    (R: fields.py:198-199) when the field is one of ours; the array is only read."""
+    if isinstance(field, ArrayField):
+        return field._values.reshape(-1)
+    return np.asarray(field.to_numpy(flatten=True))
+
+
 def select_levels(stack: Stack, levels: list[int]) -> Stack:
     """A new stack holding the given levels of ``stack`` (device-side level gather, ``atx_select_levels``)."""
     if levels == list(range(stack.n_lev)):
@@ -543,7 +562,7 @@ def group_into_stacks(fields: Iterable[Any], positions: list[int] | None = None,
             else:
                 groups.append(StackGroup(select_levels(stack, levels), members, group_fields))
         else:
-            arrays = [f.to_numpy(flatten=True) for f in group_fields]
+            arrays = [host_values(f) for f in group_fields]
             dtype = _host_dtype(arrays)
             groups.append(StackGroup(Stack.from_fields(arrays, dtype=dtype, dev=_stack.device()), members, group_fields))
     return groups
@@ -561,7 +580,7 @@ def fields_to_stack(fields: list[Any]) -> Stack:
     # mixed origins: host fields go up as one staged stack, every device stack contributes its levels by one level gather
     dev = _stack.device()
     host_pos = [i for i, r in enumerate(refs) if r is None]
-    host_arrays = [np.ascontiguousarray(fields[i].to_numpy(flatten=True)) for i in host_pos]
+    host_arrays = [host_values(fields[i]) for i in host_pos]
     host_arrays = [a if a.dtype in (np.float32, np.float64) else a.astype(np.float64) for a in host_arrays]
     device_stacks: dict[int, Stack] = {id(r[0]): r[0] for r in refs if r is not None}
     if _upload_dtype is not None:

@@ -41,6 +41,61 @@ def column_pitch(n_lev: int, dtype: torch.dtype) -> int:
     return (n_lev + per16 - 1) // per16 * per16
 
 
+# ---- host <-> HBM staging ------------------------------------------------------------------
+_PINNED_MIN_BYTES = 8 << 20    # below this a plain copy is as fast
+_STAGE_BYTES = 256 << 20       # size of one pinned staging chunk (two are in flight)
+_COPY_THREADS = max(1, min(8, (os.cpu_count() or 2) // 2))
+_copy_pool = None
+_copy_streams: dict[int, torch.cuda.Stream] = {}
+
+
+def copy_pool():
+    """Threads for host-side staging copies (numpy releases the GIL for large copies)."""
+    global _copy_pool
+    if _copy_pool is None:
+        from concurrent.futures import ThreadPoolExecutor
+
+        _copy_pool = ThreadPoolExecutor(max_workers=_COPY_THREADS, thread_name_prefix="atx-stage")
+    return _copy_pool
+
+
+def _upload_rows(rows: list[np.ndarray], dst: torch.Tensor) -> None:
+    """``dst[l, :] = rows[l]`` for a device tensor ``dst`` ``[n_lev, n_pts]`` (values cast to its dtype)."""
+    n_lev, n_pts = dst.shape
+    row_bytes = n_pts * dst.element_size()
+    if not dst.is_cuda or n_lev * row_bytes < _PINNED_MIN_BYTES:
+        np_dtype = np.float32 if dst.dtype == torch.float32 else np.float64
+        host = np.empty((n_lev, n_pts), dtype=np_dtype)
+        for l, r in enumerate(rows):
+            host[l] = r
+        dst.copy_(torch.from_numpy(host))
+        return
+    pool = copy_pool()
+    stream = _copy_streams.get(dst.device.index)
+    if stream is None:
+        stream = _copy_streams[dst.device.index] = torch.cuda.Stream(dst.device)
+    per_chunk = max(1, min(n_lev, _STAGE_BYTES // row_bytes))
+    stages = [torch.empty((per_chunk, n_pts), dtype=dst.dtype, pin_memory=True) for _ in range(2 if n_lev > per_chunk else 1)]
+    in_flight: list[torch.cuda.Event | None] = [None] * len(stages)
+    stream.wait_stream(torch.cuda.current_stream(dst.device))  # dst may still be in use by earlier work
+    for c, l0 in enumerate(range(0, n_lev, per_chunk)):
+        l1 = min(n_lev, l0 + per_chunk)
+        slot = c % len(stages)
+        if in_flight[slot] is not None:
+            in_flight[slot].synchronize()  # the DMA that last read this chunk has finished
+        view = stages[slot].numpy()
+        # numpy releases the GIL for large copies: the threads run at memory bandwidth
+        list(pool.map(lambda l: np.copyto(view[l - l0], rows[l], casting="unsafe"), range(l0, l1)))
+        with torch.cuda.stream(stream):
+            dst[l0:l1].copy_(stages[slot][: l1 - l0], non_blocking=True)
+            in_flight[slot] = torch.cuda.Event()
+            in_flight[slot].record()
+    torch.cuda.current_stream(dst.device).wait_stream(stream)
+    for ev in in_flight:  # the staging chunks go back to the host allocator only once the DMA engine is done with them
+        if ev is not None:
+            ev.synchronize()
+
+
 class Stack:
     """``n_lev`` fields on one grid of ``n_pts`` points, in HBM."""
 
@@ -89,15 +144,19 @@ class Stack:
     def from_fields(cls, arrays, dtype: torch.dtype | None = None, dev=None, layout: int = COLUMNS) -> "Stack":
         """Upload ``n_lev`` flattened host fields (each ``[n_pts]``) as one stack.
 
-        The host array is field-major (the reference's unit); it is copied to HBM
-        once and re-laid out on the device by ``atx_relayout``.
+        The host side is field-major (the reference's unit: one array per field).  Fields are copied by
+        a few threads into pinned staging chunks, each chunk goes to HBM by an asynchronous DMA on a
+        copy stream while the next one is being filled, and the stack is re-laid out on the device by
+        ``atx_relayout``.
         """
         dev = device() if dev is None else dev
-        host = np.ascontiguousarray(np.stack([np.asarray(a).reshape(-1) for a in arrays], axis=0))
-        t = torch.from_numpy(host)
-        if dtype is not None:
-            t = t.to(dtype)
-        staged = cls(t.to(dev), host.shape[1], host.shape[0], FIELDS)
+        rows = [np.asarray(a).reshape(-1) for a in arrays]
+        if dtype is None:
+            dtype = torch.float32 if all(r.dtype == np.float32 for r in rows) else torch.float64
+        n_pts = rows[0].size
+        assert all(r.size == n_pts for r in rows), "fields of one stack must share a grid"
+        staged = cls(torch.empty((len(rows), n_pts), dtype=dtype, device=dev), n_pts, len(rows), FIELDS)
+        _upload_rows(rows, staged.data)
         return staged if layout == FIELDS else staged.to_layout(COLUMNS)
 
     # ---- layout ----------------------------------------------------------------------
@@ -136,4 +195,9 @@ class Stack:
     def numpy(self) -> np.ndarray:
         """All fields, field-major ``[n_lev, n_pts]``, on the host."""
         fm = self.to_layout(FIELDS)
+        if fm.data.is_cuda and fm.data.numel() * fm.data.element_size() >= _PINNED_MIN_BYTES:
+            host = torch.empty((self.n_lev, self.n_pts), dtype=self.dtype, pin_memory=True)  # DMA at PCIe rate, one copy
+            host.copy_(fm.data[:, : self.n_pts], non_blocking=True)
+            torch.cuda.current_stream(fm.device).synchronize()
+            return host.numpy()
         return fm.data[:, : self.n_pts].cpu().numpy()  # a FIELDS stack has pitch n_pts: already contiguous
