@@ -10,8 +10,8 @@ single-process loop.  The partitioning follows SURVEY.md §8e:
   to each other;
 * every rank needs the source stack: it is broadcast ONCE (``broadcast_stack``,
   one RCCL broadcast of the contiguous stack tensor) — or, better, each rank only
-  loads the band of source columns its slice references (``source_band``): in the
-  column layout that band is one contiguous slab;
+  receives the band of source columns its slice references (``source_band``,
+  ``exchange_source_bands``): in the column layout that band is one contiguous slab;
 * outputs stay sharded (``FieldList`` per rank); ``gather_target_shards``
   assembles the full field on every rank for callers that need it.
 """
@@ -83,6 +83,37 @@ def rebase_plan(plan: GatherPlan, lo: int, hi: int) -> GatherPlan:
         index = plan.index.astype(np.int64)
         return GatherPlan(hi - lo, plan.n_tgt, index=np.where(index >= 0, index - lo, -1), weights=plan.weights, padded=plan.padded)
     return GatherPlan(hi - lo, plan.n_tgt, csr=(plan.data, plan.indices.astype(np.int64) - lo, plan.indptr))
+
+
+def exchange_source_bands(mine: Stack, plan: GatherPlan) -> tuple[list[Stack], GatherPlan]:
+    """Band-limited source exchange: every rank contributes one source stack and receives, from every
+    rank, only the slab of source columns its own target slice references.
+
+    Returns ``(bands, local_plan)``: ``bands[r]`` is rank ``r``'s stack restricted to this rank's band and
+    ``local_plan`` is this rank's shard of ``plan`` rebased onto that band, so
+    ``local_plan.apply(bands[r])`` equals ``plan.shard(rank, world).apply(<rank r's full stack>)`` bit for bit.
+    Point-to-point (RCCL send/recv over xGMI): ``world - 1`` slabs out and in per rank, each about
+    ``1/world`` of a stack plus the stencil margin, instead of ``world - 1`` whole stacks with a broadcast.
+    """
+    assert mine.layout == COLUMNS, "a band is a contiguous row range of a column stack"
+    rank, world = dist.get_rank(), dist.get_world_size()
+    ranges = [source_band(plan.shard(r, world)) for r in range(world)]  # same on every rank: the plan is replicated
+    lo, hi = ranges[rank]
+    bands = [Stack.empty(hi - lo, mine.n_lev, mine.dtype, mine.device, COLUMNS) for _ in range(world)]
+    bands[rank].data.copy_(mine.data[lo:hi])
+    ops = []
+    for r in range(world):
+        if r == rank:
+            continue
+        r_lo, r_hi = ranges[r]
+        if r_hi > r_lo:
+            ops.append(dist.P2POp(dist.isend, mine.data[r_lo:r_hi], r))
+        if hi > lo:
+            ops.append(dist.P2POp(dist.irecv, bands[r].data, r))
+    if ops:
+        for work in dist.batch_isend_irecv(ops):
+            work.wait()
+    return bands, rebase_plan(plan.shard(rank, world), lo, hi)
 
 
 def sharded_regrid(plan: GatherPlan, src: Stack, rank: int | None = None, world: int | None = None) -> Stack:

@@ -61,6 +61,9 @@ def parse_args():
     ap.add_argument("--no-extras", action="store_true", help="skip the secondary k=1 / f64 / field-major lines")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline sample")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="collective backend for N > 1 (nccl = RCCL)")
+    ap.add_argument("--exchange", default="broadcast", choices=["broadcast", "bands"],
+                    help="N > 1 source exchange before timing: whole stacks by RCCL broadcast, or only the band of source columns "
+                         "each rank's target slice references by send/recv (distributed.exchange_source_bands)")
     ap.add_argument("--share-device", action="store_true",
                     help="REHEARSAL ONLY: all ranks use cuda:0 (exercises the N > 1 code path on a 1-GPU box; needs --backend gloo)")
     return ap.parse_args()
@@ -159,33 +162,42 @@ def main():
     # shards of a lat-lon target are 1.8x apart in cost (polar targets share their source columns)
     from anemoi_transform_amd.gather import GatherPlan
 
-    bounds = GatherPlan(n_src, n_tgt, index=idx64, weights=w64).bounds(world)
+    plan = GatherPlan(n_src, n_tgt, index=idx64, weights=w64)
+    bounds = plan.bounds(world)
     lo, hi = bounds[rank], bounds[rank + 1]
-    idx_d = torch.from_numpy(idx64[lo:hi].astype(np.int32)).to(dev)
-    w_d = torch.from_numpy(w64[lo:hi].astype(np_dtype)).to(dev)
-    assert native.check_indices(idx_d, n_src) == 0
-
     # ---- sources resident in HBM before the timed region
     mine = synth_stack(src_grid, args.levels, tdtype, dev, rank, layout)
     stacks = [mine]
     exchange_ms = None
+    band_lo, n_src_local = 0, n_src
     if world > 1:
         torch.cuda.synchronize()
         dist.barrier()
         t0 = time.perf_counter()
-        stacks = []
-        for r in range(world):
-            buf = mine if r == rank else Stack.empty(n_src, args.levels, tdtype, dev, layout)
-            dist.broadcast(buf.data, src=r)  # the one-off source exchange (RCCL)
-            stacks.append(buf)
+        if args.exchange == "bands":
+            from anemoi_transform_amd.distributed import exchange_source_bands, source_band
+
+            stacks, _ = exchange_source_bands(mine, plan)
+            band_lo, band_hi = source_band(plan.shard(rank, world))
+            n_src_local = band_hi - band_lo
+            del mine
+        else:
+            stacks = []
+            for r in range(world):
+                buf = mine if r == rank else Stack.empty(n_src, args.levels, tdtype, dev, layout)
+                dist.broadcast(buf.data, src=r)  # the one-off source exchange (RCCL)
+                stacks.append(buf)
         torch.cuda.synchronize()
         dist.barrier()
         exchange_ms = (time.perf_counter() - t0) * 1e3
+    idx_d = torch.from_numpy((idx64[lo:hi] - band_lo).astype(np.int32)).to(dev)
+    w_d = torch.from_numpy(w64[lo:hi].astype(np_dtype)).to(dev)
+    assert native.check_indices(idx_d, n_src_local) == 0
     outs = [Stack.empty(hi - lo, args.levels, tdtype, dev, layout) for _ in stacks]
     weighted = args.k > 1
 
     def launch(src, out, idx=idx_d, w=w_d, k=args.k, n_t=hi - lo):
-        native.regrid_ell(src.data, out.data, idx, w if weighted or k > 1 else None, n_src=n_src, n_tgt=n_t, k=k,
+        native.regrid_ell(src.data, out.data, idx, w if weighted or k > 1 else None, n_src=n_src_local, n_tgt=n_t, k=k,
                           n_lev=src.n_lev, src_pitch=src.pitch, out_pitch=out.pitch, layout=src.layout)
 
     def step():
@@ -245,8 +257,8 @@ def main():
                         f"k={args.k} inverse-distance regrid x {args.levels} levels per stack",
             "layout": args.layout,
             "stacks_per_step": world,
-            "sharding": "target points over ranks (contiguous, traffic-balanced); sources exchanged once by RCCL broadcast before timing"
-                        if world > 1 else "single GPU",
+            "sharding": ("target points over ranks (contiguous, traffic-balanced); sources exchanged once before timing by "
+                         + ("RCCL broadcast" if args.exchange == "broadcast" else "band-limited send/recv")) if world > 1 else "single GPU",
             "launches_per_step_per_gpu": world,
             **({"rehearsal": "ranks share one GPU over gloo; not a scaling measurement"} if args.share_device else {}),
         },
@@ -267,6 +279,8 @@ def main():
     }
     if exchange_ms is not None:
         result["source_exchange_ms"] = exchange_ms
+        result["source_exchange"] = args.exchange
+        result["source_bytes_held_per_gpu"] = sum(s.data.numel() * s.data.element_size() for s in stacks)
 
     if rank == 0 and world == 1:
         # ---- parity spot check + CPU baseline on a bounded sample of the same workload

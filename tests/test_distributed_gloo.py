@@ -87,6 +87,15 @@ def _worker(rank: int, world: int, port: int, kind: str, tmpdir: str) -> None:
     assert np.array_equal(got, shard.apply(mine).numpy())
     assert hi - lo < n_src  # a latitude band, not the whole grid
 
+    # 3. band-limited exchange: every rank receives only its band of every other rank's stack (send / recv)
+    bands, local_plan = atxd.exchange_source_bands(mine, plan)
+    assert len(bands) == world and all(b.n_pts == hi - lo for b in bands)
+    for r, band_stack in enumerate(bands):
+        full_r = 280.0 + np.random.default_rng(100 + r).standard_normal((n_lev, n_src))
+        assert np.array_equal(band_stack.numpy(), full_r[:, lo:hi])
+        want = shard.apply(Stack.from_fields(full_r, dev=torch.device("cpu"))).numpy()
+        assert np.array_equal(local_plan.apply(band_stack).numpy(), want)
+
     dist.barrier()
     with open(os.path.join(tmpdir, f"ok{rank}"), "w") as f:
         f.write("ok")
