@@ -102,6 +102,9 @@ class _MetadataView:
         return [(k, self.get(k)) for k in self.keys()]
 
 
+_TYPED_KEY = {"i": int, "l": int, "int": int, "d": float, "float": float, "s": str, "str": str}
+
+
 class Field:
     """Common surface of host and device fields."""
 
@@ -155,6 +158,12 @@ class Field:
 
         def one(key: str) -> Any:
             value = self._lookup(key)
+            if value is MISSING and ":" in key:  # eccodes typed access "levelist:d" (R: rename.py:113-115)
+                base, kind = key.rsplit(":", 1)
+                cast = _TYPED_KEY.get(kind)
+                value = self._lookup(base) if cast is not None else MISSING
+                if value is not MISSING:
+                    return cast(value)
             if value is MISSING:
                 if default is not MISSING:
                     return default
@@ -174,8 +183,11 @@ class Field:
                 out[key] = value
         return out
 
-    def clone(self, **metadata: Any) -> "DerivedField":
-        # R: fields.py:131-144 / 600-641: new metadata, same data
+    def clone(self, *, values: Any = None, **metadata: Any) -> "DerivedField":
+        # R: fields.py:131-144 / 600-641: new metadata, same data; earthkit's ``clone(values=...)`` replaces the data
+        # (used by user functions of the lambda filter, R: tests/field_filters/test_lambda.py:37)
+        if values is not None:
+            return DerivedField(self, data=np.asarray(values).reshape(self.shape), metadata=metadata)
         return DerivedField(self, metadata=metadata)
 
     def __iter__(self):
@@ -381,6 +393,27 @@ def new_field_from_latitudes_longitudes(template: Field, latitudes: np.ndarray, 
 def new_field_with_metadata(template: Field, **metadata: Any) -> DerivedField:
     """R: fields.py:683-698."""
     return DerivedField(template, metadata=metadata)
+
+
+def to_datetime(value: Any) -> "datetime.datetime":
+    """ISO string / date / datetime -> datetime (what ``earthkit.data.utils.dates.to_datetime`` is used for here)."""
+    import datetime
+
+    if isinstance(value, datetime.datetime):
+        return value
+    if isinstance(value, datetime.date):
+        return datetime.datetime(value.year, value.month, value.day)
+    text = str(value)
+    if text.endswith("Z"):
+        text = text[:-1] + "+00:00"
+    return datetime.datetime.fromisoformat(text)
+
+
+def new_field_with_valid_datetime(template: Field, date: Any) -> DerivedField:
+    """R: fields.py:580-597, 665-680 — the field re-dated to ``date`` with ``step`` 0."""
+    date = to_datetime(date)
+    return DerivedField(template, metadata=dict(date=int(date.strftime("%Y%m%d")), time=int(date.strftime("%H%M")), step=0,
+                                                 valid_datetime=date.isoformat()))
 
 
 def new_field_from_stack(stack: Stack, level: int, *, template: Field, latitudes=None, longitudes=None,

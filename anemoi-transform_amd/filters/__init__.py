@@ -5,10 +5,12 @@ Registered names:
                   orog_to_z_fields, z_to_orog_fields, clip_fields, impute_nans_fields,
                   lnsp_to_sp, sp_to_lnsp, glacier_mask, noop,
                   snow_depth_m, snow_cover, cos_sin_from_rad, cos_sin_mean_wave_direction,
-                  w_to_wz, wz_to_w, sum   (multi-input, filters/multi.py)
+                  w_to_wz, wz_to_w, sum, accum_to_interval   (multi-input, filters/multi.py)
+                  rename_fields, clear_step, repeat_members, earthkitfieldlambda, empty,
+                  icon_refinement_level   (re-labelling / re-listing, filters/metadata.py)
   dispatchers     mask (alias apply_mask), remove_nans (alias drop_nans),
                   geopotential_to_height (alias orog_to_z), height_to_geopotential (alias z_to_orog),
-                  clip (alias clipper), impute_nans (alias replace_nans)
+                  clip (alias clipper), impute_nans (alias replace_nans), rename
 
 The dispatchers pick the field filter from the configuration keys exactly as the
 reference does; configurations that select the reference's *tabular* (pandas)
@@ -24,6 +26,7 @@ from ..core import DispatchingFilter, Filter, filter_registry
 
 # importing the modules registers the field filters
 from . import masks as _masks  # noqa: E402
+from . import metadata as _metadata  # noqa: E402
 from . import multi as _multi  # noqa: E402
 from . import pointwise as _pointwise  # noqa: E402
 from . import regrid as _regrid  # noqa: E402

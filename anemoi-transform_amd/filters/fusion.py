@@ -27,6 +27,7 @@ from ..core import Pipeline, ReversedTransform
 from ..fields import DerivedField, FieldList, group_into_stacks, new_field_from_stack
 from .engine import LevelOp, PointMask
 from .masks import MaskVariable
+from .metadata import Rename
 from .pointwise import StackFieldFilter
 from .regrid import RegridFilter
 
@@ -55,6 +56,11 @@ def as_stage(f: Any, backward: bool = False) -> Stage | None:
                 return None  # not reversible: let the ordinary path raise
             return Stage(f._backward_selection.match, f.backward_level_op, f.backward_metadata, f.point_mask)
         return Stage(f._forward_selection.match, f.forward_level_op, f.forward_metadata, f.point_mask)
+    if isinstance(f, Rename):
+        if backward:
+            return None
+        # metadata only: a COPY stage, so a rename between two per-point filters does not end the fused run
+        return Stage(lambda field: bool(f.fused_metadata(field)), lambda field: COPY, f.fused_metadata, lambda: None)
     if isinstance(f, MaskVariable):
         if backward or f.mask_param is not None:
             return None
@@ -104,7 +110,7 @@ def _run_segment(data: Any, head: RegridFilter | None, stages: list[Stage]) -> F
             if st.select(proxies[i]):
                 op = st.level_op(proxies[i])
                 proxies[i] = DerivedField(proxies[i], metadata=st.new_metadata(proxies[i]))
-                touched[i] = True
+                touched[i] = touched[i] or op is not COPY  # a pure relabelling needs no launch
                 if op[1]:
                     m = st.mask()
                     assert mask is None or mask is m, "one point mask per fused launch"
@@ -114,7 +120,7 @@ def _run_segment(data: Any, head: RegridFilter | None, stages: list[Stage]) -> F
             row.append(op)
         ops.append(row)
 
-    out: list[Any] = list(fields)
+    out: list[Any] = list(proxies)  # untouched fields: the original, or its relabelled view (same data, same stack level)
     if head is None:
         positions = [i for i in range(n) if touched[i]]
         if not positions:
