@@ -94,9 +94,19 @@ __device__ __forceinline__ T load_once(const T* p) {
 // ---------------------------------------------------------------------------------
 // ATX_COLUMNS, fixed k (ELL).  K > 0: compile-time k; K == 0: runtime k.
 // ---------------------------------------------------------------------------------
+// Up to kMaxBatch stacks of identical shape share one launch (several variables or time steps on the same grid
+// pair, or the N source stacks of a target-sharded multi-GPU step): blockIdx.y selects the stack, so the launch gaps
+// and per-launch tails of a stack-by-stack loop disappear.  The pointers travel by value in the kernel arguments.
+constexpr int kMaxBatch = 16;
+struct EllBatch {
+    const void* src[kMaxBatch];
+    void* out[kMaxBatch];
+    int n;
+};
+
 template <typename T, int VEC, int K, bool WEIGHTED, bool EPI, bool PAD>
 __global__ void __launch_bounds__(kEllBlock)
-regrid_cols_ell_kernel(const T* __restrict__ src, T* __restrict__ out,
+regrid_cols_ell_kernel(EllBatch batch,
                        const int32_t* __restrict__ idx, const T* __restrict__ w,
                        int64_t n_tgt, int k_rt, int n_lev, int C,
                        int64_t src_pitch, int64_t out_pitch, int tile, unsigned n_tiles,
@@ -134,91 +144,107 @@ regrid_cols_ell_kernel(const T* __restrict__ src, T* __restrict__ out,
     const int items = nt * C;
     const int dt = kEllBlock / C;
     const int dc = kEllBlock - dt * C;
-    int t = tid / C;
-    int c = tid - t * C;
 
-    for (int q = tid; q < items; q += kEllBlock * kU) {
-        int tt[kU], cc[kU];
-        bool ok[kU];
-#pragma unroll
-        for (int u = 0; u < kU; ++u) {
-            ok[u] = (q + u * kEllBlock) < items;
-            tt[u] = ok[u] ? t : 0;
-            cc[u] = ok[u] ? c : 0;
-            t += dt;
-            c += dc;
-            if (c >= C) { c -= C; ++t; }
-        }
+    // stacks of a batch: grid.y (default) keeps workgroups short — measured 0.45 ms per 8-stack step on a 1/8 target shard
+    // against 0.51 ms for a loop over the stacks inside the workgroup (which stages the tile once but runs 8x longer) and
+    // 0.50-0.52 ms for 8 separate launches (profiles/r01_shard_balance.log)
+#ifndef ATX_BATCH_LOOP
+#define ATX_BATCH_LOOP 0
+#endif
+#if ATX_BATCH_LOOP
+    for (int stack = 0; stack < batch.n; ++stack) {
+#else
+    {
+        const int stack = blockIdx.y;
+#endif
+        const T* __restrict__ src = static_cast<const T*>(batch.src[stack]);
+        T* __restrict__ out = static_cast<T*>(batch.out[stack]);
+        int t = tid / C;
+        int c = tid - t * C;
 
-        V acc[kU];
-        if (K > 0) {
-            // all K*kU loads are independent: issue them before any arithmetic
-            V v[kU][K > 0 ? K : 1];
+        for (int q = tid; q < items; q += kEllBlock * kU) {
+            int tt[kU], cc[kU];
+            bool ok[kU];
 #pragma unroll
             for (int u = 0; u < kU; ++u) {
-#pragma unroll
-                for (int j = 0; j < (K > 0 ? K : 1); ++j) {
-                    int64_t p = idx_s[tt[u] * K + j];
-                    if (PAD && p < 0) p = 0;  // absent entry of a padded row: load anything valid, skipped below
-                    v[u][j] = load_src<T, VEC>(src + p * src_pitch + (int64_t)cc[u] * VEC);
-                }
+                ok[u] = (q + u * kEllBlock) < items;
+                tt[u] = ok[u] ? t : 0;
+                cc[u] = ok[u] ? c : 0;
+                t += dt;
+                c += dc;
+                if (c >= C) { c -= C; ++t; }
             }
+
+            V acc[kU];
+            if (K > 0) {
+                // all K*kU loads are independent: issue them before any arithmetic
+                V v[kU][K > 0 ? K : 1];
 #pragma unroll
-            for (int u = 0; u < kU; ++u) {
-                if (WEIGHTED) {
-#pragma unroll
-                    for (int e = 0; e < VEC; ++e) acc[u].v[e] = T(0);
+                for (int u = 0; u < kU; ++u) {
 #pragma unroll
                     for (int j = 0; j < (K > 0 ? K : 1); ++j) {
-                        const T wj = w_s[tt[u] * K + j];
-                        if (!PAD || idx_s[tt[u] * K + j] >= 0) {
+                        int64_t p = idx_s[tt[u] * K + j];
+                        if (PAD && p < 0) p = 0;  // absent entry of a padded row: load anything valid, skipped below
+                        v[u][j] = load_src<T, VEC>(src + p * src_pitch + (int64_t)cc[u] * VEC);
+                    }
+                }
 #pragma unroll
-                            for (int e = 0; e < VEC; ++e) acc[u].v[e] = acc[u].v[e] + wj * v[u][j].v[e];
+                for (int u = 0; u < kU; ++u) {
+                    if (WEIGHTED) {
+#pragma unroll
+                        for (int e = 0; e < VEC; ++e) acc[u].v[e] = T(0);
+#pragma unroll
+                        for (int j = 0; j < (K > 0 ? K : 1); ++j) {
+                            const T wj = w_s[tt[u] * K + j];
+                            if (!PAD || idx_s[tt[u] * K + j] >= 0) {
+#pragma unroll
+                                for (int e = 0; e < VEC; ++e) acc[u].v[e] = acc[u].v[e] + wj * v[u][j].v[e];
+                            }
+                        }
+                    } else {
+                        acc[u] = v[u][0];
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int u = 0; u < kU; ++u) {
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) acc[u].v[e] = T(0);
+                    const int base = tt[u] * k;
+                    int j = 0;
+                    for (; j + 2 <= k; j += 2) {
+                        const int64_t pa = idx_s[base + j], pb = idx_s[base + j + 1];
+                        const V va = *reinterpret_cast<const V*>(src + ((PAD && pa < 0) ? 0 : pa) * src_pitch + (int64_t)cc[u] * VEC);
+                        const V vb = *reinterpret_cast<const V*>(src + ((PAD && pb < 0) ? 0 : pb) * src_pitch + (int64_t)cc[u] * VEC);
+                        const T wa = WEIGHTED ? w_s[base + j] : T(1), wb = WEIGHTED ? w_s[base + j + 1] : T(1);
+#pragma unroll
+                        for (int e = 0; e < VEC; ++e) {
+                            if (!PAD || pa >= 0) acc[u].v[e] = acc[u].v[e] + wa * va.v[e];
+                            if (!PAD || pb >= 0) acc[u].v[e] = acc[u].v[e] + wb * vb.v[e];
                         }
                     }
-                } else {
-                    acc[u] = v[u][0];
-                }
-            }
-        } else {
+                    if (j < k) {
+                        const int64_t pa = idx_s[base + j];
+                        const V va = *reinterpret_cast<const V*>(src + ((PAD && pa < 0) ? 0 : pa) * src_pitch + (int64_t)cc[u] * VEC);
+                        const T wa = WEIGHTED ? w_s[base + j] : T(1);
 #pragma unroll
-            for (int u = 0; u < kU; ++u) {
-#pragma unroll
-                for (int e = 0; e < VEC; ++e) acc[u].v[e] = T(0);
-                const int base = tt[u] * k;
-                int j = 0;
-                for (; j + 2 <= k; j += 2) {
-                    const int64_t pa = idx_s[base + j], pb = idx_s[base + j + 1];
-                    const V va = *reinterpret_cast<const V*>(src + ((PAD && pa < 0) ? 0 : pa) * src_pitch + (int64_t)cc[u] * VEC);
-                    const V vb = *reinterpret_cast<const V*>(src + ((PAD && pb < 0) ? 0 : pb) * src_pitch + (int64_t)cc[u] * VEC);
-                    const T wa = WEIGHTED ? w_s[base + j] : T(1), wb = WEIGHTED ? w_s[base + j + 1] : T(1);
-#pragma unroll
-                    for (int e = 0; e < VEC; ++e) {
-                        if (!PAD || pa >= 0) acc[u].v[e] = acc[u].v[e] + wa * va.v[e];
-                        if (!PAD || pb >= 0) acc[u].v[e] = acc[u].v[e] + wb * vb.v[e];
+                        for (int e = 0; e < VEC; ++e)
+                            if (!PAD || pa >= 0) acc[u].v[e] = acc[u].v[e] + wa * va.v[e];
                     }
                 }
-                if (j < k) {
-                    const int64_t pa = idx_s[base + j];
-                    const V va = *reinterpret_cast<const V*>(src + ((PAD && pa < 0) ? 0 : pa) * src_pitch + (int64_t)cc[u] * VEC);
-                    const T wa = WEIGHTED ? w_s[base + j] : T(1);
-#pragma unroll
-                    for (int e = 0; e < VEC; ++e)
-                        if (!PAD || pa >= 0) acc[u].v[e] = acc[u].v[e] + wa * va.v[e];
-                }
             }
-        }
 
 #pragma unroll
-        for (int u = 0; u < kU; ++u) {
-            if (!ok[u]) continue;
-            if (EPI) {
-                const bool masked = tgt_mask ? (tgt_mask[t0 + tt[u]] != 0) : false;
-                apply_program_vec<T, VEC>(vops_s, prog, n_stage, n_lev, C, cc[u], acc[u], masked);
+            for (int u = 0; u < kU; ++u) {
+                if (!ok[u]) continue;
+                if (EPI) {
+                    const bool masked = tgt_mask ? (tgt_mask[t0 + tt[u]] != 0) : false;
+                    apply_program_vec<T, VEC>(vops_s, prog, n_stage, n_lev, C, cc[u], acc[u], masked);
+                }
+                store_out(reinterpret_cast<V*>(out + (t0 + tt[u]) * out_pitch + (int64_t)cc[u] * VEC), acc[u]);
             }
-            store_out(reinterpret_cast<V*>(out + (t0 + tt[u]) * out_pitch + (int64_t)cc[u] * VEC), acc[u]);
         }
-    }
+    }  // stacks of the batch
 }
 
 // ---------------------------------------------------------------------------------
@@ -435,7 +461,7 @@ static int pick_tile(int64_t n_tgt, int C) {
 static int g_tile_override = 0;  // tuning hook (atx_set_tuning)
 
 template <typename T, int VEC, int K, bool WEIGHTED, bool PAD = false>
-static int launch_cols_ell(const T* src, T* out, const int32_t* idx, const T* w, int64_t n_tgt, int k,
+static int launch_cols_ell(const EllBatch& batch, const int32_t* idx, const T* w, int64_t n_tgt, int k,
                            int n_lev, int64_t src_pitch, int64_t out_pitch, const atx_level_op* prog,
                            int n_stage, const uint8_t* tgt_mask, hipStream_t stream) {
     const int C = (n_lev + VEC - 1) / VEC;
@@ -447,34 +473,34 @@ static int launch_cols_ell(const T* src, T* out, const int32_t* idx, const T* w,
     if (prog) lds += (size_t)n_stage * C * sizeof(LevelOp<T>);
     ATX_REQUIRE(lds <= 64 * 1024, ATX_ENOTIMPL, "regrid_ell: tile needs %zu B of LDS (k=%d, n_lev=%d, stages=%d)", lds, k, n_lev, n_stage);
     if (prog) {
-        hipLaunchKernelGGL((regrid_cols_ell_kernel<T, VEC, K, WEIGHTED, true, PAD>), dim3(n_tiles), dim3(kEllBlock), lds, stream,
-                           src, out, idx, w, n_tgt, k, n_lev, C, src_pitch, out_pitch, tile, n_tiles, prog, n_stage, tgt_mask);
+        hipLaunchKernelGGL((regrid_cols_ell_kernel<T, VEC, K, WEIGHTED, true, PAD>), dim3(n_tiles, ATX_BATCH_LOOP ? 1 : batch.n), dim3(kEllBlock), lds, stream,
+                           batch, idx, w, n_tgt, k, n_lev, C, src_pitch, out_pitch, tile, n_tiles, prog, n_stage, tgt_mask);
     } else {
-        hipLaunchKernelGGL((regrid_cols_ell_kernel<T, VEC, K, WEIGHTED, false, PAD>), dim3(n_tiles), dim3(kEllBlock), lds, stream,
-                           src, out, idx, w, n_tgt, k, n_lev, C, src_pitch, out_pitch, tile, n_tiles, prog, n_stage, tgt_mask);
+        hipLaunchKernelGGL((regrid_cols_ell_kernel<T, VEC, K, WEIGHTED, false, PAD>), dim3(n_tiles, ATX_BATCH_LOOP ? 1 : batch.n), dim3(kEllBlock), lds, stream,
+                           batch, idx, w, n_tgt, k, n_lev, C, src_pitch, out_pitch, tile, n_tiles, prog, n_stage, tgt_mask);
     }
     ATX_LAUNCH_CHECK("regrid_cols_ell");
     return ATX_OK;
 }
 
 template <typename T, int VEC>
-static int dispatch_cols_ell(const T* src, T* out, const int32_t* idx, const T* w, int64_t n_tgt, int k,
+static int dispatch_cols_ell(const EllBatch& batch, const int32_t* idx, const T* w, int64_t n_tgt, int k,
                              int n_lev, int64_t sp, int64_t op, bool pad, const atx_level_op* prog, int n_stage,
                              const uint8_t* m, hipStream_t st) {
-    if (!w) return launch_cols_ell<T, VEC, 1, false>(src, out, idx, w, n_tgt, k, n_lev, sp, op, prog, n_stage, m, st);
+    if (!w) return launch_cols_ell<T, VEC, 1, false>(batch, idx, w, n_tgt, k, n_lev, sp, op, prog, n_stage, m, st);
     if (pad) {  // padded ragged rows: the common widths compile-time, the rest runtime
         switch (k) {
-            case 3: return launch_cols_ell<T, VEC, 3, true, true>(src, out, idx, w, n_tgt, k, n_lev, sp, op, prog, n_stage, m, st);
-            case 4: return launch_cols_ell<T, VEC, 4, true, true>(src, out, idx, w, n_tgt, k, n_lev, sp, op, prog, n_stage, m, st);
-            default: return launch_cols_ell<T, VEC, 0, true, true>(src, out, idx, w, n_tgt, k, n_lev, sp, op, prog, n_stage, m, st);
+            case 3: return launch_cols_ell<T, VEC, 3, true, true>(batch, idx, w, n_tgt, k, n_lev, sp, op, prog, n_stage, m, st);
+            case 4: return launch_cols_ell<T, VEC, 4, true, true>(batch, idx, w, n_tgt, k, n_lev, sp, op, prog, n_stage, m, st);
+            default: return launch_cols_ell<T, VEC, 0, true, true>(batch, idx, w, n_tgt, k, n_lev, sp, op, prog, n_stage, m, st);
         }
     }
     switch (k) {
-        case 1: return launch_cols_ell<T, VEC, 1, true>(src, out, idx, w, n_tgt, k, n_lev, sp, op, prog, n_stage, m, st);
-        case 2: return launch_cols_ell<T, VEC, 2, true>(src, out, idx, w, n_tgt, k, n_lev, sp, op, prog, n_stage, m, st);
-        case 3: return launch_cols_ell<T, VEC, 3, true>(src, out, idx, w, n_tgt, k, n_lev, sp, op, prog, n_stage, m, st);
-        case 4: return launch_cols_ell<T, VEC, 4, true>(src, out, idx, w, n_tgt, k, n_lev, sp, op, prog, n_stage, m, st);
-        default: return launch_cols_ell<T, VEC, 0, true>(src, out, idx, w, n_tgt, k, n_lev, sp, op, prog, n_stage, m, st);
+        case 1: return launch_cols_ell<T, VEC, 1, true>(batch, idx, w, n_tgt, k, n_lev, sp, op, prog, n_stage, m, st);
+        case 2: return launch_cols_ell<T, VEC, 2, true>(batch, idx, w, n_tgt, k, n_lev, sp, op, prog, n_stage, m, st);
+        case 3: return launch_cols_ell<T, VEC, 3, true>(batch, idx, w, n_tgt, k, n_lev, sp, op, prog, n_stage, m, st);
+        case 4: return launch_cols_ell<T, VEC, 4, true>(batch, idx, w, n_tgt, k, n_lev, sp, op, prog, n_stage, m, st);
+        default: return launch_cols_ell<T, VEC, 0, true>(batch, idx, w, n_tgt, k, n_lev, sp, op, prog, n_stage, m, st);
     }
 }
 
@@ -531,22 +557,26 @@ static bool cols_vector_ok(const void* src, const void* out, int64_t sp, int64_t
 }
 
 template <typename T>
-static int regrid_ell_typed(const void* src_, void* out_, const int32_t* idx, const void* w_, int64_t n_tgt, int k,
+static int regrid_ell_typed(const EllBatch& batch, const int32_t* idx, const void* w_, int64_t n_tgt, int k,
                             int n_lev, int64_t sp, int64_t op, int layout, bool pad, const atx_level_op* prog, int n_stage,
                             const uint8_t* m, hipStream_t st) {
-    const T* src = static_cast<const T*>(src_);
-    T* out = static_cast<T*>(out_);
     const T* w = static_cast<const T*>(w_);
     if (layout == ATX_COLUMNS) {
         constexpr int VEC = Vec16<T>::N;
         // the vector path needs every row start 16-byte aligned and room for the
         // last (partial) vector inside the pitch
         const int64_t covered = ((int64_t)(n_lev + VEC - 1) / VEC) * VEC;
-        if (cols_vector_ok<T>(src_, out_, sp, op) && covered <= sp && covered <= op)
-            return dispatch_cols_ell<T, VEC>(src, out, idx, w, n_tgt, k, n_lev, sp, op, pad, prog, n_stage, m, st);
-        return dispatch_cols_ell<T, 1>(src, out, idx, w, n_tgt, k, n_lev, sp, op, pad, prog, n_stage, m, st);
+        bool vector_ok = covered <= sp && covered <= op;
+        for (int i = 0; i < batch.n; ++i) vector_ok = vector_ok && cols_vector_ok<T>(batch.src[i], batch.out[i], sp, op);
+        if (vector_ok) return dispatch_cols_ell<T, VEC>(batch, idx, w, n_tgt, k, n_lev, sp, op, pad, prog, n_stage, m, st);
+        return dispatch_cols_ell<T, 1>(batch, idx, w, n_tgt, k, n_lev, sp, op, pad, prog, n_stage, m, st);
     }
-    return dispatch_fields_ell<T>(src, out, idx, w, n_tgt, k, n_lev, sp, op, pad, prog, n_stage, m, st);
+    for (int i = 0; i < batch.n; ++i) {  // field-major stacks: lanes keep indices / weights in registers, one launch per stack
+        const int rc = dispatch_fields_ell<T>(static_cast<const T*>(batch.src[i]), static_cast<T*>(batch.out[i]), idx, w, n_tgt, k,
+                                              n_lev, sp, op, pad, prog, n_stage, m, st);
+        if (rc != ATX_OK) return rc;
+    }
+    return ATX_OK;
 }
 
 template <typename T, int VEC>
@@ -634,25 +664,54 @@ extern "C" int atx_set_tuning(int tile) {
     return ATX_OK;
 }
 
+static int regrid_ell_common(const char* fn, const void* const* srcs, void* const* outs, int32_t n_stack, const int32_t* idx,
+                             const void* w, int64_t n_src, int64_t n_tgt, int32_t k, int64_t n_lev, int64_t src_pitch,
+                             int64_t out_pitch, int dtype, int layout, int32_t flags, const atx_level_op* prog,
+                             int32_t n_stage, const uint8_t* tgt_mask, void* stream) {
+    ATX_REQUIRE(srcs && outs && n_stack >= 1, ATX_EINVAL, "%s: needs at least one stack", fn);
+    for (int32_t i = 0; i < n_stack; ++i) {
+        int st = check_stack_args(fn, srcs[i], outs[i], n_src, n_tgt, n_lev, src_pitch, out_pitch, dtype, layout);
+        if (st != ATX_OK) return st;
+    }
+    ATX_REQUIRE(idx, ATX_EINVAL, "%s: null idx", fn);
+    ATX_REQUIRE(k >= 1 && k <= 64, ATX_EINVAL, "%s: k=%d outside [1, 64]", fn, k);
+    ATX_REQUIRE(w || k == 1, ATX_EINVAL, "%s: a pure gather (w == NULL) needs k == 1, got %d", fn, k);
+    ATX_REQUIRE((flags & ~ATX_ELL_PADDED) == 0, ATX_EINVAL, "%s: unknown flags 0x%x", fn, flags);
+    ATX_REQUIRE(!(flags & ATX_ELL_PADDED) || w, ATX_EINVAL, "%s: ATX_ELL_PADDED needs weights", fn);
+    const bool pad = (flags & ATX_ELL_PADDED) != 0;
+    ATX_REQUIRE((prog == nullptr) == (n_stage == 0) && n_stage >= 0 && n_stage <= 8, ATX_EINVAL,
+                "%s: prog/n_stage mismatch (n_stage=%d)", fn, n_stage);
+    if (n_tgt == 0) return ATX_OK;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    for (int32_t first = 0; first < n_stack; first += kMaxBatch) {
+        EllBatch batch;
+        batch.n = n_stack - first < kMaxBatch ? n_stack - first : kMaxBatch;
+        for (int i = 0; i < kMaxBatch; ++i) {
+            batch.src[i] = i < batch.n ? srcs[first + i] : nullptr;
+            batch.out[i] = i < batch.n ? outs[first + i] : nullptr;
+        }
+        const int rc = dtype == ATX_F32
+            ? regrid_ell_typed<float>(batch, idx, w, n_tgt, k, (int)n_lev, src_pitch, out_pitch, layout, pad, prog, n_stage, tgt_mask, s)
+            : regrid_ell_typed<double>(batch, idx, w, n_tgt, k, (int)n_lev, src_pitch, out_pitch, layout, pad, prog, n_stage, tgt_mask, s);
+        if (rc != ATX_OK) return rc;
+    }
+    return ATX_OK;
+}
+
 extern "C" int atx_regrid_ell(const void* src, void* out, const int32_t* idx, const void* w, int64_t n_src,
                               int64_t n_tgt, int32_t k, int64_t n_lev, int64_t src_pitch, int64_t out_pitch,
                               int dtype, int layout, int32_t flags, const atx_level_op* prog, int32_t n_stage,
                               const uint8_t* tgt_mask, void* stream) {
-    int st = check_stack_args("atx_regrid_ell", src, out, n_src, n_tgt, n_lev, src_pitch, out_pitch, dtype, layout);
-    if (st != ATX_OK) return st;
-    ATX_REQUIRE(idx, ATX_EINVAL, "atx_regrid_ell: null idx");
-    ATX_REQUIRE(k >= 1 && k <= 64, ATX_EINVAL, "atx_regrid_ell: k=%d outside [1, 64]", k);
-    ATX_REQUIRE(w || k == 1, ATX_EINVAL, "atx_regrid_ell: a pure gather (w == NULL) needs k == 1, got %d", k);
-    ATX_REQUIRE((flags & ~ATX_ELL_PADDED) == 0, ATX_EINVAL, "atx_regrid_ell: unknown flags 0x%x", flags);
-    ATX_REQUIRE(!(flags & ATX_ELL_PADDED) || w, ATX_EINVAL, "atx_regrid_ell: ATX_ELL_PADDED needs weights");
-    const bool pad = (flags & ATX_ELL_PADDED) != 0;
-    ATX_REQUIRE((prog == nullptr) == (n_stage == 0) && n_stage >= 0 && n_stage <= 8, ATX_EINVAL,
-                "atx_regrid_ell: prog/n_stage mismatch (n_stage=%d)", n_stage);
-    if (n_tgt == 0) return ATX_OK;
-    hipStream_t s = static_cast<hipStream_t>(stream);
-    if (dtype == ATX_F32)
-        return regrid_ell_typed<float>(src, out, idx, w, n_tgt, k, (int)n_lev, src_pitch, out_pitch, layout, pad, prog, n_stage, tgt_mask, s);
-    return regrid_ell_typed<double>(src, out, idx, w, n_tgt, k, (int)n_lev, src_pitch, out_pitch, layout, pad, prog, n_stage, tgt_mask, s);
+    return regrid_ell_common("atx_regrid_ell", &src, &out, 1, idx, w, n_src, n_tgt, k, n_lev, src_pitch, out_pitch, dtype,
+                             layout, flags, prog, n_stage, tgt_mask, stream);
+}
+
+extern "C" int atx_regrid_ell_batch(const void* const* srcs, void* const* outs, int32_t n_stack, const int32_t* idx,
+                                    const void* w, int64_t n_src, int64_t n_tgt, int32_t k, int64_t n_lev,
+                                    int64_t src_pitch, int64_t out_pitch, int dtype, int layout, int32_t flags,
+                                    const atx_level_op* prog, int32_t n_stage, const uint8_t* tgt_mask, void* stream) {
+    return regrid_ell_common("atx_regrid_ell_batch", srcs, outs, n_stack, idx, w, n_src, n_tgt, k, n_lev, src_pitch, out_pitch,
+                             dtype, layout, flags, prog, n_stage, tgt_mask, stream);
 }
 
 extern "C" int atx_regrid_csr(const void* src, void* out, const int32_t* indptr, const int32_t* indices,

@@ -59,15 +59,19 @@ class _Interpolator:
     def regrid_fieldlist(self, data: Any, *, shard: tuple[int, int] | None = None) -> FieldList:
         fields = list(data)
         out: list[Any] = [None] * len(fields)
+        # stacks that share a plan (several variables / time steps on one grid pair) go through ONE batched launch
+        batches: dict[int, tuple[GatherPlan, np.ndarray, np.ndarray, list[Any]]] = {}
         for group in group_into_stacks(fields):
             plan = self.plan_for(group.fields[0])
             lat, lon = self.out_latlon(group.fields[0])
             if shard is not None:
                 lo, hi = plan.shard_range(*shard)
                 plan, lat, lon = self._sharded(plan, shard), lat[lo:hi], lon[lo:hi]
-            regridded = plan.apply(group.stack)
-            for level, (pos, f) in enumerate(zip(group.positions, group.fields)):
-                out[pos] = new_field_from_stack(regridded, level, template=f, latitudes=lat, longitudes=lon)
+            batches.setdefault(id(plan), (plan, lat, lon, []))[3].append(group)
+        for plan, lat, lon, groups in batches.values():
+            for group, regridded in zip(groups, plan.apply_many([g.stack for g in groups])):
+                for level, (pos, f) in enumerate(zip(group.positions, group.fields)):
+                    out[pos] = new_field_from_stack(regridded, level, template=f, latitudes=lat, longitudes=lon)
         return FieldList(out)
 
     def _sharded(self, plan: GatherPlan, shard: tuple[int, int]) -> GatherPlan:

@@ -26,10 +26,11 @@ from . import native
 from .stack import Stack
 
 
-# Cost of one target column relative to one first-touched source column in ``GatherPlan.bounds``: the stored column plus
-# its k table entries are 1.06 column-equivalents at 137 f32 levels; a least-squares fit of measured per-shard times
-# on MI355X (O1280 -> 0.25 degree, 8 shards, equal-count and balanced cuts) gives 1.10.
-TARGET_COST = 1.1
+# Cost of one target column relative to one first-touched source column in ``GatherPlan.bounds``.  By bytes alone the stored
+# column plus its k table entries are 1.06 column-equivalents at 137 f32 levels; least-squares fits of measured per-shard
+# times on MI355X (O1280 -> 0.25 degree, 4 and 8 shards; tools/shard_efficiency.py) give 1.1 for one launch per stack and
+# 1.4 for the batched launch the multi-GPU step uses (polar shards: many targets on few source columns).
+TARGET_COST = 1.4
 
 
 class GatherPlan:
@@ -230,7 +231,27 @@ class GatherPlan:
             )
         return out
 
+    def apply_many(self, stacks: list[Stack]) -> list[Stack]:
+        """The gather over several source stacks of identical shape (variables / time steps on one grid) — fixed-k
+        plans on column stacks run them in ONE launch (``atx_regrid_ell_batch``, grid.y = stack); anything else falls back to one launch per stack."""
+        if not stacks:
+            return []
+        first = stacks[0]
+        same = all((s.n_pts, s.n_lev, s.dtype, s.layout, s.pitch) == (first.n_pts, first.n_lev, first.dtype, first.layout, first.pitch)
+                   for s in stacks)
+        if self.kind != "ell" or not same or self.n_tgt == 0 or len(stacks) == 1:
+            return [self.apply(s) for s in stacks]
+        assert first.n_pts == self.n_src, (first.n_pts, self.n_src)
+        outs = [first.new_like(n_pts=self.n_tgt, zero=False) for _ in stacks]
+        idx, w = self._tensors(first.device, first.dtype)
+        native.regrid_ell_batch(
+            [s.data for s in stacks], [o.data for o in outs], idx, w, n_src=self.n_src, n_tgt=self.n_tgt, k=self.k,
+            n_lev=first.n_lev, src_pitch=first.pitch, out_pitch=outs[0].pitch, layout=first.layout, padded=self.padded,
+        )
+        return outs
 
-def shard_bounds(n: int, rank: int, world: int) -> tuple[int, int]:
-    """Balanced contiguous partition of ``range(n)`` into ``world`` slices."""
+
+def equal_count_bounds(n: int, rank: int, world: int) -> tuple[int, int]:
+    """Contiguous partition of ``range(n)`` into ``world`` slices of (almost) equal length — for per-point work,
+    whose cost is uniform; gathers use ``GatherPlan.bounds`` (balanced by traffic) instead."""
     return (n * rank) // world, (n * (rank + 1)) // world

@@ -59,6 +59,11 @@ SIGNATURES: dict[str, tuple[Any, list[Any]]] = {
         [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int32, c_int64, c_int64, c_int64, c_int, c_int, c_int32,
          c_void_p, c_int32, c_void_p, c_void_p],
     ),
+    "atx_regrid_ell_batch": (
+        c_int,
+        [c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_int64, c_int64, c_int32, c_int64, c_int64, c_int64, c_int, c_int,
+         c_int32, c_void_p, c_int32, c_void_p, c_void_p],
+    ),
     "atx_regrid_csr": (
         c_int,
         [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int64, c_int64, c_int64, c_int,
@@ -187,6 +192,24 @@ def regrid_ell(src, out, idx, w, *, n_src, n_tgt, k, n_lev, src_pitch, out_pitch
     _call(
         "atx_regrid_ell", _ptr(src), _ptr(out), _ptr(idx), _ptr(w), n_src, n_tgt, k, n_lev, src_pitch, out_pitch,
         dtype_code(src.dtype), layout, ELL_PADDED if padded else 0, _ptr(prog), n_stage, _ptr(tgt_mask), _stream(),
+    )
+
+
+def regrid_ell_batch(srcs, outs, idx, w, *, n_src, n_tgt, k, n_lev, src_pitch, out_pitch, layout, prog=None, n_stage=0,
+                     tgt_mask=None, padded: bool = False) -> None:
+    """``regrid_ell`` over several stacks of identical shape in one launch (``atx_regrid_ell_batch``): ``srcs`` / ``outs``
+    are sequences of device tensors."""
+    assert len(srcs) == len(outs) >= 1
+    assert idx.dtype == torch.int32
+    dtype = srcs[0].dtype
+    assert all(t.dtype == dtype for t in srcs) and all(t.dtype == dtype for t in outs) and (w is None or w.dtype == dtype)
+    n = len(srcs)
+    src_ptrs = (c_void_p * n)(*[_ptr(t) for t in srcs])
+    out_ptrs = (c_void_p * n)(*[_ptr(t) for t in outs])
+    _call(
+        "atx_regrid_ell_batch", ctypes.cast(src_ptrs, c_void_p), ctypes.cast(out_ptrs, c_void_p), n, _ptr(idx), _ptr(w), n_src,
+        n_tgt, k, n_lev, src_pitch, out_pitch, dtype_code(dtype), layout, ELL_PADDED if padded else 0, _ptr(prog), n_stage,
+        _ptr(tgt_mask), _stream(),
     )
 
 

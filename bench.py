@@ -200,9 +200,12 @@ def main():
         native.regrid_ell(src.data, out.data, idx, w if weighted or k > 1 else None, n_src=n_src_local, n_tgt=n_t, k=k,
                           n_lev=src.n_lev, src_pitch=src.pitch, out_pitch=out.pitch, layout=src.layout)
 
-    def step():
-        for s, o in zip(stacks, outs):
-            launch(s, o)
+    def step():  # one launch over all stacks of the step (atx_regrid_ell_batch: grid.y = stack)
+        if len(stacks) == 1:
+            launch(stacks[0], outs[0])
+        else:
+            native.regrid_ell_batch([s.data for s in stacks], [o.data for o in outs], idx_d, w_d, n_src=n_src_local, n_tgt=hi - lo,
+                                    k=args.k, n_lev=args.levels, src_pitch=stacks[0].pitch, out_pitch=outs[0].pitch, layout=layout)
 
     # ---- timed region: W warm-up steps, then exactly K steps between barriers
     for _ in range(args.warmup):
@@ -225,9 +228,11 @@ def main():
     value = units_per_step * args.steps / elapsed
 
     # ---- roofline of the dominant kernel, HIP events around single launches
-    avg_ms, min_ms = time_launches(lambda: launch(stacks[0], outs[0]), max(args.steps, 10), 2)
+    # (N > 1, column stacks: the step IS one batched launch over this rank's shard of all N stacks)
+    one_launch = layout == COLUMNS or len(stacks) == 1
+    avg_ms, min_ms = time_launches(step if one_launch else (lambda: launch(stacks[0], outs[0])), max(args.steps, 10), 2)
     shard_unique = int(np.unique(idx64[lo:hi]).size)
-    alg = algorithmic_bytes(args.levels, itemsize, shard_unique, hi - lo, args.k)
+    alg = algorithmic_bytes(args.levels, itemsize, shard_unique, hi - lo, args.k) * (len(stacks) if one_launch else 1)
     achieved = alg / (avg_ms * 1e-3) / 1e9
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
@@ -259,7 +264,7 @@ def main():
             "stacks_per_step": world,
             "sharding": ("target points over ranks (contiguous, traffic-balanced); sources exchanged once before timing by "
                          + ("RCCL broadcast" if args.exchange == "broadcast" else "band-limited send/recv")) if world > 1 else "single GPU",
-            "launches_per_step_per_gpu": world,
+            "launches_per_step_per_gpu": 1 if layout == COLUMNS else world,
             **({"rehearsal": "ranks share one GPU over gloo; not a scaling measurement"} if args.share_device else {}),
         },
         "roofline": {

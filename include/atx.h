@@ -144,6 +144,16 @@ int atx_regrid_ell(const void* src, void* out, const int32_t* idx, const void* w
                    const atx_level_op* prog, int32_t n_stage, const uint8_t* tgt_mask,
                    void* stream);
 
+/* atx_regrid_ell applied to n_stack source stacks of identical shape, dtype and pitch with ONE launch per 16 stacks
+ * (ATX_COLUMNS: grid.y = stack, no launch gaps or per-launch tails; field-major stacks are launched one after the
+ * other).  srcs / outs are HOST arrays of n_stack device pointers; any n_stack >= 1.
+ *   R: regrid.py:204-208 — the per-field loop, when the FieldList holds several variables / time steps on one grid
+ *      pair (BASELINE config 4), or the N source stacks of a target-sharded multi-GPU step. */
+int atx_regrid_ell_batch(const void* const* srcs, void* const* outs, int32_t n_stack, const int32_t* idx, const void* w,
+                         int64_t n_src, int64_t n_tgt, int32_t k, int64_t n_lev, int64_t src_pitch, int64_t out_pitch,
+                         int dtype, int layout, int32_t flags, const atx_level_op* prog, int32_t n_stage,
+                         const uint8_t* tgt_mask, void* stream);
+
 /*
  * General CSR interpolation: out[t, l] = sum_{jj in [indptr[t], indptr[t+1])} data[jj] * src[indices[jj], l]
  * accumulated from 0 in jj order — scipy's csr_matvec.

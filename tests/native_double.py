@@ -89,6 +89,11 @@ def regrid_ell(src, out, idx, w, *, n_src, n_tgt, k, n_lev, src_pitch, out_pitch
     _epilogue(y, prog, n_stage, tgt_mask, n_lev)
 
 
+def regrid_ell_batch(srcs, outs, idx, w, **kw):
+    for src, out in zip(srcs, outs):
+        regrid_ell(src, out, idx, w, **kw)
+
+
 def regrid_csr(src, out, indptr, indices, data, *, n_src, n_tgt, nnz, n_lev, src_pitch, out_pitch, layout, prog=None,
                n_stage=0, tgt_mask=None):
     x = _levels(src, n_src, n_lev, layout)
@@ -195,7 +200,7 @@ def select_levels(src, dst, level_map, *, n_pts, n_src_lev, src_pitch, dst_pitch
             d[j] = s[l]
 
 
-PATCHED = ["regrid_ell", "regrid_csr", "check_indices", "pointwise_stack", "combine_stack", "mask_build", "mask_count", "mask_to_index",
+PATCHED = ["regrid_ell", "regrid_ell_batch", "regrid_csr", "check_indices", "pointwise_stack", "combine_stack", "mask_build", "mask_count", "mask_to_index",
            "reduce", "relayout", "reduce_stack", "select_levels"]
 
 

@@ -20,7 +20,7 @@ import pytest
 import torch
 
 from anemoi_transform_amd import native
-from anemoi_transform_amd.gather import GatherPlan
+from anemoi_transform_amd.gather import TARGET_COST, GatherPlan
 from anemoi_transform_amd.grids import lookup
 from anemoi_transform_amd.interp import knn_inverse_distance
 from anemoi_transform_amd.stack import COLUMNS, FIELDS, Stack
@@ -96,7 +96,7 @@ def test_shards_concatenate_bit_exact(case):
     # shard boundaries are balanced by traffic: polar shards of the lat-lon target hold more targets
     sizes = [p.shape[0] for p in parts]
     assert sizes[0] > 1.3 * sizes[3] and sizes[7] > 1.3 * sizes[4] and sum(sizes) == case["n_tgt"]
-    cost = [np.unique(case["idx"][b0:b1]).size + 1.1 * (b1 - b0) for b0, b1 in zip(case["plan"].bounds(8)[:-1], case["plan"].bounds(8)[1:])]
+    cost = [np.unique(case["idx"][b0:b1]).size + TARGET_COST * (b1 - b0) for b0, b1 in zip(case["plan"].bounds(8)[:-1], case["plan"].bounds(8)[1:])]
     assert max(cost) < 1.1 * min(cost)
 
 

@@ -347,6 +347,35 @@ def test_relayout_round_trip(dev, tdtype, np_dtype, n_lev, n_pts):
 
 @pytest.mark.parametrize("tdtype,np_dtype", DTYPES)
 @pytest.mark.parametrize("layout", LAYOUTS)
+@pytest.mark.parametrize("k,n_stack", [(1, 3), (4, 1), (4, 5), (4, 19)])
+def test_batched_regrid_equals_one_launch_per_stack(dev, tdtype, np_dtype, layout, k, n_stack):
+    """atx_regrid_ell_batch: several stacks through one launch (more than 16 are split internally), bit for bit the
+    single-stack results; mismatched shapes fall back to single launches in GatherPlan.apply_many."""
+    from anemoi_transform_amd.gather import GatherPlan
+
+    rng = np.random.default_rng(41)
+    n_src, n_tgt, n_lev = 4000, 2777, 13
+    idx = rng.integers(0, n_src, (n_tgt, k))
+    w = None if k == 1 else rng.random((n_tgt, k))
+    plan = GatherPlan(n_src, n_tgt, index=idx, weights=w)
+    stacks = [Stack.from_fields(make_fields(rng, n_lev, n_src, np_dtype, nan_frac=0.01), dev=dev, layout=layout) for _ in range(n_stack)]
+    many = plan.apply_many(stacks)
+    itype = torch.int32 if np_dtype == np.float32 else torch.int64
+    for st, got in zip(stacks, many):
+        want = plan.apply(st)
+        assert got.layout == layout and got.n_pts == n_tgt
+        cut = (slice(None), slice(0, n_lev)) if layout == COLUMNS else (slice(None), slice(0, n_tgt))
+        assert torch.equal(got.data[cut].contiguous().view(itype), want.data[cut].contiguous().view(itype))
+    odd = Stack.from_fields(make_fields(rng, n_lev + 2, n_src, np_dtype), dev=dev, layout=layout)
+    mixed = plan.apply_many([stacks[0], odd])
+    assert mixed[1].n_lev == n_lev + 2 and np.array_equal(mixed[1].numpy(), plan.apply(odd).numpy(), equal_nan=True)
+    with pytest.raises(ValueError):
+        native.regrid_ell_batch([stacks[0].data], [many[0].data], plan._tensors(dev, tdtype)[0], plan._tensors(dev, tdtype)[1],
+                                n_src=n_src, n_tgt=n_tgt, k=65, n_lev=n_lev, src_pitch=stacks[0].pitch, out_pitch=many[0].pitch, layout=layout)
+
+
+@pytest.mark.parametrize("tdtype,np_dtype", DTYPES)
+@pytest.mark.parametrize("layout", LAYOUTS)
 @pytest.mark.parametrize("n_lev,n_pts,n_out", [(1, 1, 1), (7, 1000, 3), (137, 5003, 137), (300, 700, 290)])
 def test_select_levels_and_stack_reductions(dev, tdtype, np_dtype, layout, n_lev, n_pts, n_out):
     """Level gather (re-listing fields of a stack) is a bit copy; untouched levels keep their content;

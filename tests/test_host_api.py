@@ -31,7 +31,7 @@ from anemoi_transform_amd.fields import (
     new_field_from_latitudes_longitudes,
     new_field_from_numpy,
 )
-from anemoi_transform_amd.gather import GatherPlan, shard_bounds
+from anemoi_transform_amd.gather import GatherPlan, equal_count_bounds
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 GOLDEN = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "reference_vectors.json")))
@@ -126,7 +126,7 @@ def test_gather_plan_validation_and_sharding():
     assert s.n_tgt == csr.bounds(2)[2] - csr.bounds(2)[1] and s.indptr[0] == 0 and s.indptr[-1] == len(s.indices)
     both = [csr.shard(r, 2) for r in range(2)]
     assert np.array_equal(np.concatenate([p.indices for p in both]), csr.indices)
-    assert [shard_bounds(10, r, 4) for r in range(4)] == [(0, 2), (2, 5), (5, 7), (7, 10)]
+    assert [equal_count_bounds(10, r, 4) for r in range(4)] == [(0, 2), (2, 5), (5, 7), (7, 10)]
     m = GatherPlan.from_mask(np.array([True, False, True, True]))
     assert m.k == 1 and np.array_equal(m.index[:, 0], [0, 2, 3])
 

@@ -19,16 +19,19 @@ idx, w = interp.knn_inverse_distance(src, tgt, k=4, device=True)
 plan = GatherPlan(n_src, n_tgt, index=idx, weights=w)
 world = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 stacks = [bench.synth_stack(src, L, torch.float32, dev, s, COLUMNS) for s in range(world)]
-for name, bounds in (("equal-count", [(n_tgt * r) // world for r in range(world + 1)]),
-                     ("traffic-balanced", plan.bounds(world))):
-    if bounds is None:
-        continue
+for name, bounds, batched in (("equal-count", [(n_tgt * r) // world for r in range(world + 1)], False),
+                              ("traffic-balanced", plan.bounds(world), False),
+                              ("balanced+batched", plan.bounds(world), True)):
     times = []
     for r in range(world):
         lo, hi = bounds[r], bounds[r + 1]
         idx_d = torch.from_numpy(idx[lo:hi].astype(np.int32)).to(dev); w_d = torch.from_numpy(w[lo:hi].astype(np.float32)).to(dev)
         outs = [Stack.empty(hi - lo, L, torch.float32, dev, COLUMNS) for _ in range(world)]
         def step():
+            if batched:  # one launch over the `world` stacks of the step (atx_regrid_ell_batch)
+                native.regrid_ell_batch([s.data for s in stacks], [o.data for o in outs], idx_d, w_d, n_src=n_src, n_tgt=hi - lo, k=4,
+                                        n_lev=L, src_pitch=stacks[0].pitch, out_pitch=outs[0].pitch, layout=COLUMNS)
+                return
             for s, o in zip(stacks, outs):
                 native.regrid_ell(s.data, o.data, idx_d, w_d, n_src=n_src, n_tgt=hi - lo, k=4, n_lev=L, src_pitch=s.pitch, out_pitch=o.pitch, layout=COLUMNS)
         for _ in range(3): step()
