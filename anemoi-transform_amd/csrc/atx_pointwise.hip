@@ -105,6 +105,66 @@ pointwise_cols_kernel(const T* __restrict__ x, T* __restrict__ y, int64_t n_pts,
     }
 }
 
+// ATX_COLUMNS with tight, equal pitches (pitch == C*VEC: what Stack.empty allocates): the stack is ONE contiguous run of
+// n_pts*C vectors.  A workgroup sweeps 16 KB chunks of it (kBlock * kPwUnroll vectors = 128 whole cache lines when the
+// base is line aligned), so no line is shared between workgroups — the row-chunk kernel above fetched 4.4 % and wrote
+// 1.8 % more than the stack holds (boundary lines of its chunks, PMC counters in profiles/traffic.json) and idles
+// kBlock % C lanes.  A lane's column changes from pass to pass; its operators come from the LDS table either way.
+template <typename T, int VEC>
+__global__ void __launch_bounds__(kBlock)
+pointwise_cols_flat_kernel(const T* __restrict__ x, T* __restrict__ y, int64_t n_pts, int n_lev, int C,
+                           const atx_level_op* __restrict__ prog, int n_stage,
+                           const uint8_t* __restrict__ point_mask, int in_place) {
+    using V = Pack<T, VEC>;
+    extern __shared__ __align__(16) unsigned char smem[];
+    LevelOp<T>* vec_ops = reinterpret_cast<LevelOp<T>*>(smem);  // [n_stage][C]
+    uint8_t* active = reinterpret_cast<uint8_t*>(vec_ops + (size_t)n_stage * C);  // [C]: column has a non-COPY stage
+    const int tid = threadIdx.x;
+    build_vector_ops<T, VEC>(prog, vec_ops, n_stage, n_lev, C, tid, kBlock);
+    __syncthreads();
+    for (int c = tid; c < C; c += kBlock) {
+        bool act = false;
+        for (int s = 0; s < n_stage; ++s) {
+            const LevelOp<T> o = vec_ops[s * C + c];
+            act = act || o.op != ATX_OP_COPY || o.use_mask != 0;
+        }
+        active[c] = act ? 1 : 0;
+    }
+    __syncthreads();
+
+    const int64_t n_vec = n_pts * C;
+    constexpr int64_t kChunk = (int64_t)kBlock * kPwUnroll;
+    for (int64_t base = (int64_t)blockIdx.x * kChunk; base < n_vec; base += (int64_t)gridDim.x * kChunk) {
+        const int64_t row_b = base / C;  // uniform: scalar unit
+        const int col_b = (int)(base - row_b * C);
+        V v[kPwUnroll];
+        int64_t row[kPwUnroll];
+        int col[kPwUnroll];
+        bool ok[kPwUnroll], act[kPwUnroll];
+#pragma unroll
+        for (int u = 0; u < kPwUnroll; ++u) {
+            const int off = col_b + u * kBlock + tid;  // < C + kChunk: 32-bit arithmetic
+            const int dr = off / C;
+            col[u] = off - dr * C;
+            row[u] = row_b + dr;
+            const int64_t vi = base + u * kBlock + tid;
+            ok[u] = vi < n_vec;
+            act[u] = active[col[u]] != 0;
+            if (in_place && !act[u]) ok[u] = false;  // untouched levels of an in-place call: nothing to move
+            if (ok[u]) v[u] = pw_load<T, VEC>(x + vi * VEC);
+        }
+#pragma unroll
+        for (int u = 0; u < kPwUnroll; ++u) {
+            if (!ok[u]) continue;
+            if (act[u]) {
+                const bool masked = point_mask ? (point_mask[row[u]] != 0) : false;
+                apply_program_vec<T, VEC>(vec_ops, prog, n_stage, n_lev, C, col[u], v[u], masked);
+            }
+            pw_store<T, VEC>(y + (base + u * kBlock + tid) * VEC, v[u]);
+        }
+    }
+}
+
 // ATX_FIELDS: grid.y = level (operator uniform per workgroup), lanes along points.
 template <typename T, int VEC>
 __global__ void __launch_bounds__(kBlock)
@@ -379,6 +439,19 @@ static int pointwise_typed(const void* x_, void* y_, int64_t n_pts, int n_lev, i
         const int C = wide ? (n_lev + VEC - 1) / VEC : n_lev;
         const size_t lds = (size_t)n_stage * C * sizeof(LevelOp<T>);
         ATX_REQUIRE(lds <= 64 * 1024, ATX_ENOTIMPL, "pointwise: program needs %zu B of LDS", lds);
+#ifndef ATX_PW_FLAT
+#define ATX_PW_FLAT 1
+#endif
+        if (ATX_PW_FLAT && wide && xp == (int64_t)C * VEC && yp == xp) {  // one contiguous run of vectors: line-aligned chunks
+            const int64_t n_vec = n_pts * C;
+            int64_t blocks = (n_vec + (int64_t)kBlock * kPwUnroll - 1) / ((int64_t)kBlock * kPwUnroll);
+            if (blocks > kMaxGrid) blocks = kMaxGrid;
+            const size_t lds_flat = lds + (size_t)C;
+            hipLaunchKernelGGL((pointwise_cols_flat_kernel<T, VEC>), dim3((unsigned)blocks), dim3(kBlock), lds_flat, st, x, y, n_pts, n_lev,
+                               C, prog, n_stage, mask, in_place);
+            ATX_LAUNCH_CHECK("pointwise_stack");
+            return ATX_OK;
+        }
         const int Cg = C < kBlock ? C : kBlock;
         const int64_t chunk = (int64_t)(kBlock / Cg) * kPwUnroll;  // rows one workgroup moves per iteration
         int64_t blocks = (n_pts + chunk - 1) / chunk;

@@ -3,8 +3,8 @@
 
 Runs, on one GPU, with the bench's O1280 -> 0.25 degree k=4 x137 inputs:
   1. a CALIBRATION launch with a known byte count in the same access width as the
-     regrid kernel (16 B per lane): `atx_pointwise_stack` copying the whole source
-     stack out of place  -> reads n_src*pitch*B bytes, writes the same;
+     regrid kernel (16 B per lane): `atx_pointwise_stack` copying a field-major stack of
+     the same size out of place (aligned contiguous rows) -> reads n_src*n_lev*B bytes, writes the same;
   2. `--launches` regrid launches (`regrid_cols_ell_kernel`).
 The counters of (1) give the correction factor MI355X_MICROARCH.md §HBM asks for
 (FETCH_SIZE reads ~1/2 of a wide coalesced stream on gfx950); tools/pmc_summarize.py
@@ -60,14 +60,26 @@ def main():
     out = Stack.empty(n_tgt, args.levels, tdtype, dev, COLUMNS)
     torch.cuda.synchronize()
 
-    # 1. calibration: full-stack copy, 16 B per lane, known bytes
-    copy = src.new_like()
+    # 1. calibration: a copy with a known byte count in the regrid kernel's access width (16 B per lane) over perfectly
+    #    aligned, contiguous rows — the field-major per-point kernel on a [levels, n_src] stack.  (The column-stack
+    #    per-point kernel is launched too: its workgroup chunks are not line aligned, so its own counters show a few %
+    #    of boundary-line refetch; it is reported, not used for calibration.)
+    from anemoi_transform_amd.stack import FIELDS
+
+    flat_src = Stack.empty(n_src, args.levels, tdtype, dev, FIELDS, zero=True)
+    flat_dst = Stack.empty(n_src, args.levels, tdtype, dev, FIELDS)
     prog = native.level_program([[(native.OP_COPY, 0, 0.0, 0.0)] * args.levels], dev)
+    native.pointwise_stack(flat_src.data, flat_dst.data, n_pts=n_src, n_lev=args.levels, x_pitch=flat_src.pitch, y_pitch=flat_dst.pitch,
+                           layout=FIELDS, prog=prog, n_stage=1)
+    torch.cuda.synchronize()
+    calib_bytes = n_src * args.levels * itemsize
+    del flat_src, flat_dst
+    copy = src.new_like()
     native.pointwise_stack(src.data, copy.data, n_pts=n_src, n_lev=args.levels, x_pitch=src.pitch, y_pitch=copy.pitch,
                            layout=COLUMNS, prog=prog, n_stage=1)
     torch.cuda.synchronize()
     covered = (args.levels + (16 // itemsize) - 1) // (16 // itemsize) * (16 // itemsize)
-    calib_bytes = n_src * covered * itemsize
+    cols_copy_bytes = n_src * covered * itemsize
 
     # 2. the regrid launches
     for _ in range(args.launches):
@@ -77,7 +89,8 @@ def main():
 
     meta = {
         "config": f"o1280->0.25 k={args.k} L={args.levels} {args.dtype} columns gpus=1",
-        "calibration_kernel": "pointwise_cols_kernel",
+        "calibration_kernel": "pointwise_fields_kernel",
+        "cols_copy_bytes": cols_copy_bytes,
         "calibration_read_bytes": calib_bytes,
         "calibration_write_bytes": calib_bytes,
         "regrid_kernel": "regrid_cols_ell_kernel",

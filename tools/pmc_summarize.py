@@ -29,7 +29,7 @@ def counters(directory: str, counter: str) -> dict[str, list[float]]:
                 if row["Counter_Name"] != counter:
                     continue
                 name = row["Kernel_Name"]
-                for key in ("pointwise_cols_kernel", "regrid_cols_ell_kernel", "regrid_fields_ell_kernel"):
+                for key in ("pointwise_cols_kernel", "pointwise_fields_kernel", "regrid_cols_ell_kernel", "regrid_fields_ell_kernel"):
                     if key in name:
                         out.setdefault(key, []).append(float(row["Counter_Value"]))
     return out
@@ -47,8 +47,8 @@ def main():
     meta = json.load(open(args.meta))
     fetch = counters(args.fetch_dir, "FETCH_SIZE")
     write = counters(args.write_dir, "WRITE_SIZE")
-    cal_f = fetch["pointwise_cols_kernel"][0] * 1024
-    cal_w = write["pointwise_cols_kernel"][0] * 1024
+    cal_f = fetch[meta["calibration_kernel"]][0] * 1024
+    cal_w = write[meta["calibration_kernel"]][0] * 1024
     read_corr = meta["calibration_read_bytes"] / cal_f
     write_corr = meta["calibration_write_bytes"] / cal_w
     kern = meta["regrid_kernel"]
@@ -76,6 +76,12 @@ def main():
         "algorithmic_bytes_per_launch": meta["algorithmic_bytes_per_launch"],
     }
     rec["traffic_over_algorithmic"] = rec["hbm_bytes_per_launch"] / rec["algorithmic_bytes_per_launch"]
+    if "pointwise_cols_kernel" in fetch and "cols_copy_bytes" in meta:  # the column-stack per-point copy, same correction
+        rec["pointwise_cols_copy"] = {
+            "known_bytes_each_way": meta["cols_copy_bytes"],
+            "fetch_over_known": fetch["pointwise_cols_kernel"][0] * 1024 * read_corr / meta["cols_copy_bytes"],
+            "write_over_known": write["pointwise_cols_kernel"][0] * 1024 * write_corr / meta["cols_copy_bytes"],
+        }
     table = {}
     if os.path.exists(args.out):
         table = json.load(open(args.out))
