@@ -227,3 +227,51 @@ def test_csr_and_gather_statements():
     m = rng.random(50) < 0.5
     assert np.array_equal(oracle.masked_subset(x, m), x[m])
     assert np.array_equal(oracle.masked_subset(x, np.flatnonzero(m)), x[m])
+
+
+# ---- multi-input statements (R: tests/field_filters/test_cos_sin_*.py, test_sum.py, test_snow_depth_m.py, test_glacier_mask.py,
+#      test_accum_to_interval.py) -------------------------------------------------------------------------------------------
+def test_cos_sin_vectors():
+    g = GOLDEN["cos_sin_from_rad"]
+    cos, sin = oracle.cos_sin(arr(g["rad"]))
+    np.testing.assert_allclose(cos, arr(g["cos"]))  # the reference's tolerance: assert_allclose defaults (rtol 1e-7)
+    np.testing.assert_allclose(sin, arr(g["sin"]))
+    np.testing.assert_allclose(oracle.direction_from_cos_sin(arr(g["cos"]), arr(g["sin"])), arr(g["rad"]))
+    d = GOLDEN["cos_sin_mean_wave_direction"]
+    cos, sin = oracle.cos_sin(arr(d["mwd"]), degrees=True)
+    np.testing.assert_allclose(cos, arr(d["cos"]))
+    np.testing.assert_allclose(sin, arr(d["sin"]))
+    np.testing.assert_allclose(oracle.direction_from_cos_sin(arr(d["cos"]), arr(d["sin"]), degrees=True), arr(d["mwd"]))
+
+
+def test_sum_vectors():
+    g = GOLDEN["sum"]
+    t, r = arr(g["t"]), arr(g["r"])
+    assert np.allclose(oracle.sum_fields([r.copy(), t.copy()]), (r + t).flatten())
+    assert np.allclose(oracle.sum_fields([t.copy(), t - 15.0]), (t * 2.0 - 15.0).flatten())
+    assert oracle.sum_fields([r.copy(), t.copy()]).shape == (6,)  # arrays are flattened in sum
+
+
+def test_snow_depth_and_glacier_vectors():
+    g = GOLDEN["snow_depth_m"]
+    sd, rsn = arr(g["snow_depth"]), arr(g["snow_density"])
+    np.testing.assert_allclose(oracle.snow_depth_m(sd, rsn), 1000.0 * sd / rsn)
+    k = g["known"]
+    np.testing.assert_allclose(oracle.snow_depth_m(arr(k["snow_depth"]), arr(k["snow_density"])), arr(k["expected"]))
+    m = GOLDEN["glacier_mask"]
+    values, mask = arr(m["snow_depth"]), arr(m["glacier_mask"]).astype(bool)
+    expected = np.ma.array(values, mask=mask).filled(np.nan)  # the reference test's own expectation (test_glacier_mask.py:54)
+    assert np.allclose(oracle.apply_mask_values(values.flatten(), mask.flatten()).reshape(values.shape), expected, equal_nan=True)
+
+
+@pytest.mark.parametrize("case,zero_left", [("zero_left_true", True), ("zero_left_false", False)])
+def test_accum_to_interval_vectors(case, zero_left):
+    g = GOLDEN["accum_to_interval"]
+    base, c = arr(g["base"]), g[case]
+    fields = [dict(param="tp", values=base * c["accumulated_multiples_of_base"][i], valid_datetime=g["times"][i]) for i in c["given_order"]]
+    fields.append(dict(param="t", values=base + 10, valid_datetime=g["times"][0]))
+    out = oracle.filter_accum_to_interval(fields, variables=["tp"], zero_left=zero_left)
+    tp = sorted((f for f in out if f["param"] == "tp"), key=lambda f: f["valid_datetime"])
+    for f, mult in zip(tp, c["expected_multiples"]):
+        assert np.allclose(f["values"], base * mult)
+    assert [f for f in out if f["param"] == "t"][0]["values"] is fields[-1]["values"]  # non-target variables pass through
