@@ -184,7 +184,9 @@ regrid_cols_ell_kernel(EllBatch batch,
 #pragma unroll
                     for (int j = 0; j < (K > 0 ? K : 1); ++j) {
                         int64_t p = idx_s[tt[u] * K + j];
-                        if (PAD && p < 0) p = 0;  // absent entry of a padded row: load anything valid, skipped below
+                        // absent entry of a padded row: load anything valid, skipped below (predicating the load instead was
+                        // measured 20 % slower: the branch breaks up the batch of independent loads)
+                        if (PAD && p < 0) p = 0;
                         v[u][j] = load_src<T, VEC>(src + p * src_pitch + (int64_t)cc[u] * VEC);
                     }
                 }
@@ -445,13 +447,17 @@ check_indices_kernel(const int32_t* __restrict__ idx, int64_t n, int64_t n_src, 
 // ---------------------------------------------------------------------------------
 // host-side launchers
 // ---------------------------------------------------------------------------------
-static int pick_tile(int64_t n_tgt, int C) {
+static int pick_tile(int64_t n_tgt, int C, bool epilogue) {
     // Small tiles win: ~560 (target, vector) items per 256-lane workgroup, i.e. 16 targets of
     // 137 f32 levels, rounded up to a multiple of 4 targets (measured on O1280 -> 0.25 deg:
     // tiles of 12 / 16 beat 10, 14, 18-32; 64/128/512-lane workgroups reach the same plateau at
     // the same items-per-lane ratio — profiles/r01_ab_variants.log, r01_ab_block_sizes.log).  More, shorter
     // workgroups keep more of them in different phases (index staging / gather / store).
-    int tile = (560 / C + 2) / 4 * 4;  // nearest multiple of 4 targets: 16 for 137 f32 levels, 8 for 137 f64 levels
+    // With an epilogue every workgroup first builds its operator table (a second global-load latency before the
+    // barrier): tiles 2.5x larger amortise it — 137 levels f32: 0.491 ms at 16 targets, 0.469 at 32-48; f64: 0.985 ms at 8,
+    // 0.878 at 24 (profiles/r01_ab_epilogue.log).
+    const int items = epilogue ? 1400 : 560;
+    int tile = (items / C + 2) / 4 * 4;  // nearest multiple of 4 targets: 16 (40 with epilogue) for 137 f32 levels, 8 (20) for f64
     if (tile < 8) tile = 8;
     if (tile > 256) tile = 256;
     if ((int64_t)tile > n_tgt) tile = (int)n_tgt;
@@ -465,7 +471,7 @@ static int launch_cols_ell(const EllBatch& batch, const int32_t* idx, const T* w
                            int n_lev, int64_t src_pitch, int64_t out_pitch, const atx_level_op* prog,
                            int n_stage, const uint8_t* tgt_mask, hipStream_t stream) {
     const int C = (n_lev + VEC - 1) / VEC;
-    int tile = g_tile_override > 0 ? g_tile_override : pick_tile(n_tgt, C);
+    int tile = g_tile_override > 0 ? g_tile_override : pick_tile(n_tgt, C, prog != nullptr);
     if ((int64_t)tile > n_tgt) tile = (int)n_tgt;
     const unsigned n_tiles = (unsigned)((n_tgt + tile - 1) / tile);
     size_t lds = (size_t)tile * k * (sizeof(int32_t) + (WEIGHTED ? sizeof(T) : 0));
@@ -584,7 +590,7 @@ static int launch_cols_csr(const T* src, T* out, const int32_t* indptr, const in
                            int64_t n_tgt, int64_t nnz, int n_lev, int64_t sp, int64_t op,
                            const atx_level_op* prog, int n_stage, const uint8_t* m, hipStream_t st) {
     const int C = (n_lev + VEC - 1) / VEC;
-    int tile = g_tile_override > 0 ? g_tile_override : pick_tile(n_tgt, C);
+    int tile = g_tile_override > 0 ? g_tile_override : pick_tile(n_tgt, C, prog != nullptr);
     if ((int64_t)tile > n_tgt) tile = (int)n_tgt;
     const unsigned n_tiles = (unsigned)((n_tgt + tile - 1) / tile);
     // LDS room for ~2x the mean entries of a tile (tiles above it read CSR from L2)

@@ -63,7 +63,7 @@ def main():
     results = {}
     for case in args.cases:
         k = int(case[1])
-        f64 = case.endswith("f64")
+        f64 = "f64" in case
         tdt, npdt, isz = (torch.float64, np.float64, 8) if f64 else (torch.float32, np.float32, 4)
         src = bench.synth_stack(src_grid, args.levels, tdt, dev, 0, COLUMNS)
         out = Stack.empty(n_tgt, args.levels, tdt, dev, COLUMNS)
@@ -71,10 +71,16 @@ def main():
         w = torch.from_numpy(w64.astype(npdt)).to(dev) if k > 1 else None
         alg = bench.algorithmic_bytes(args.levels, isz, int(np.unique(idx64[:, :k]).size), n_tgt, k)
 
+        # "...e": with the 2-stage epilogue of config 5 (x * g, then x - 273.15)
+        prog = native.level_program([[(native.OP_MUL, 0, 9.80665, 0.0)] * args.levels, [(native.OP_AFFINE, 0, 1.0, -273.15)] * args.levels],
+                                    dev) if "e" in case[2:] else None
+        f64 = "f64" in case
+
         def run(h, tile):
             h.atx_set_tuning(tile)
             rc = h.atx_regrid_ell(src.data.data_ptr(), out.data.data_ptr(), idx.data_ptr(), None if w is None else w.data_ptr(),
-                                  n_src, n_tgt, k, args.levels, src.pitch, out.pitch, 1 if f64 else 0, 0, 0, None, 0, None, stream)
+                                  n_src, n_tgt, k, args.levels, src.pitch, out.pitch, 1 if f64 else 0, 0, 0,
+                                  None if prog is None else prog.data_ptr(), 0 if prog is None else 2, None, stream)
             assert rc == 0, h.atx_last_error()
 
         combos = [(name, tile) for name in libs for tile in args.tiles]
