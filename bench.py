@@ -368,6 +368,18 @@ def main():
                                 "achieved_GBs": a / (ms * 1e-3) / 1e9, "frac": a / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
                 del s, o, wd
                 torch.cuda.empty_cache()
+            # the CPU's best case (SURVEY.md §8d baseline B): the same statement on 16 worker processes, run as a child
+            # process that never touches the GPU; reported next to the one-thread "as the reference runs" baseline
+            if not args.no_cpu_baseline:
+                import subprocess
+
+                try:
+                    child = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "cpu_all_cores.py"), "--seconds", "8",
+                                            "--src-grid", args.src_grid, "--tgt-grid", args.tgt_grid, "--k", str(args.k)],
+                                           capture_output=True, text=True, timeout=180)
+                    extras["cpu_all_cores"] = json.loads(child.stdout.strip().splitlines()[-1])
+                except Exception as e:  # a baseline must never take the bench line down
+                    extras["cpu_all_cores"] = {"error": f"{type(e).__name__}: {e}"}
             result["extras"] = extras
 
     if rank == 0:
