@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Headline benchmark: grid-points/s regridded, O1280 -> 0.25 degree x 137 levels.
 
-    python bench.py --gpus 1 --steps 20 --warmup 5
+    python bench.py --gpus 1 --steps 200 --warmup 20
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
@@ -48,8 +48,8 @@ SEED = 20260630
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--src-grid", default="o1280")
     ap.add_argument("--tgt-grid", default="0.25")
     ap.add_argument("--levels", type=int, default=137)
@@ -230,7 +230,7 @@ def main():
     # ---- roofline of the dominant kernel, HIP events around single launches
     # (N > 1, column stacks: the step IS one batched launch over this rank's shard of all N stacks)
     one_launch = layout == COLUMNS or len(stacks) == 1
-    avg_ms, min_ms = time_launches(step if one_launch else (lambda: launch(stacks[0], outs[0])), max(args.steps, 10), 2)
+    avg_ms, min_ms = time_launches(step if one_launch else (lambda: launch(stacks[0], outs[0])), min(max(args.steps, 10), 200), 2)
     shard_unique = int(np.unique(idx64[lo:hi]).size)
     alg = algorithmic_bytes(args.levels, itemsize, shard_unique, hi - lo, args.k) * (len(stacks) if one_launch else 1)
     achieved = alg / (avg_ms * 1e-3) / 1e9
