@@ -127,6 +127,12 @@ class Field:
         """``(stack, level)`` if the data lives in HBM, else ``None``."""
         return None
 
+    def target_range(self) -> tuple[int, int, int] | None:
+        """``(lo, hi, n_total)`` if the field holds points ``[lo, hi)`` of a grid of ``n_total`` points — the output of
+        a target-sharded ``regrid`` on one rank — else ``None``.  Per-point filters that bring a
+        full-grid point mask (``apply_mask(path=...)``, ``glacier_mask``) use its window ``[lo, hi)``."""
+        return None
+
     # ---- reference surface -----------------------------------------------------------
     def to_numpy(self, flatten: bool = False, dtype: Any = None, index: Any = None) -> np.ndarray:
         # R: fields.py:178-202 — astype, flatten, index, in that order; always a copy here
@@ -265,8 +271,10 @@ class DerivedField(Field):
         latitudes: np.ndarray | None = None,
         longitudes: np.ndarray | None = None,
         metadata: dict[str, Any] | None = None,
+        target_range: tuple[int, int, int] | None = None,
     ) -> None:
         # metadata overrides travel as a dict: keys such as "level" or "data" are legal metadata names
+        self._target_range = target_range
         assert data is None or stack_level is None
         stack, level = stack_level if stack_level is not None else (None, None)
         self._template = template
@@ -293,6 +301,15 @@ class DerivedField(Field):
             return self._stack, self._level
         if self._data is None:
             return self._template.stack_ref()
+        return None
+
+    def target_range(self) -> tuple[int, int, int] | None:
+        if self._target_range is not None:
+            return self._target_range
+        if self._latitudes is None and isinstance(self._template, Field):  # same grid as the template: same window
+            inherited = self._template.target_range()
+            if inherited is not None and inherited[1] - inherited[0] == int(np.prod(self.shape)):
+                return inherited
         return None
 
     def _flat(self) -> np.ndarray:
@@ -417,9 +434,10 @@ def new_field_with_valid_datetime(template: Field, date: Any) -> DerivedField:
 
 
 def new_field_from_stack(stack: Stack, level: int, *, template: Field, latitudes=None, longitudes=None,
-                         metadata: dict[str, Any] | None = None) -> DerivedField:
+                         metadata: dict[str, Any] | None = None, target_range: tuple[int, int, int] | None = None) -> DerivedField:
     """Engine-side factory: the field is level ``level`` of an HBM stack."""
-    return DerivedField(template, stack_level=(stack, level), latitudes=latitudes, longitudes=longitudes, metadata=metadata)
+    return DerivedField(template, stack_level=(stack, level), latitudes=latitudes, longitudes=longitudes, metadata=metadata,
+                        target_range=target_range)
 
 
 class FieldList:

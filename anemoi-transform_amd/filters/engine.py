@@ -35,6 +35,24 @@ class PointMask:
         native.mask_build(values, tensor, n=n_points, stride=stride, cmp=cmp, threshold=threshold)
         return cls(tensor, n_points)
 
+    def window(self, lo: int, hi: int) -> "PointMask":
+        """The mask of points ``[lo, hi)`` (a view): what a rank of a target-sharded job applies to its slice."""
+        assert 0 <= lo <= hi <= self.n_points
+        return PointMask(self.tensor[lo:], hi - lo)
+
+    def for_fields(self, fields: list[Any], n_pts: int) -> "PointMask":
+        """This mask as it applies to ``fields`` of ``n_pts`` points each: itself, or — for the slices a target-sharded
+        regrid produced (``Field.target_range``) — its window; a mask of any other length is an error
+        (R: apply_mask.py:185 would raise IndexError)."""
+        if self.n_points == n_pts:
+            return self
+        ranges = {f.target_range() if hasattr(f, "target_range") else None for f in fields}
+        if len(ranges) == 1:
+            r = ranges.pop()
+            if r is not None and r[2] == self.n_points and r[1] - r[0] == n_pts:
+                return self.window(r[0], r[1])
+        raise IndexError(f"boolean index did not match indexed array: mask has {self.n_points} points, field has {n_pts}")
+
     def count(self) -> int:
         return native.mask_count(self.tensor, self.n_points)
 
@@ -65,13 +83,7 @@ def run_level_ops(
 
     for group in group_into_stacks(fields, positions, sparse_ok=True):
         src = group.stack
-        if point_mask is not None:
-            # R: apply_mask.py:185 would raise IndexError on a mask of the wrong length
-            if point_mask.n_points != src.n_pts:
-                raise IndexError(
-                    f"boolean index did not match indexed array: mask has {point_mask.n_points} points, "
-                    f"field has {src.n_pts}"
-                )
+        mask = None if point_mask is None else point_mask.for_fields(group.fields, src.n_pts)
         dst = src.new_like()
         stage: list[LevelOp] = [(native.OP_COPY, 0, 0.0, 0.0)] * src.n_lev  # levels outside the group: untouched
         for level, f in zip(group.levels, group.fields):
@@ -80,7 +92,7 @@ def run_level_ops(
         native.pointwise_stack(
             src.data, dst.data, n_pts=src.n_pts, n_lev=src.n_lev, x_pitch=src.pitch, y_pitch=dst.pitch,
             layout=src.layout, prog=prog, n_stage=1,
-            point_mask=None if point_mask is None else point_mask.tensor,
+            point_mask=None if mask is None else mask.tensor,
         )
         for level, pos, f in zip(group.levels, group.positions, group.fields):
             out[pos] = new_field_from_stack(dst, level, template=f, metadata=new_metadata(f))

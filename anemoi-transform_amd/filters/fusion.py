@@ -127,8 +127,7 @@ def _run_segment(data: Any, head: RegridFilter | None, stages: list[Stage]) -> F
             return FieldList(out)
         for group in group_into_stacks(fields, positions, sparse_ok=True):
             src = group.stack
-            if mask is not None and mask.n_points != src.n_pts:
-                raise IndexError(f"boolean index did not match indexed array: mask has {mask.n_points} points, field has {src.n_pts}")
+            group_mask = None if mask is None else mask.for_fields(group.fields, src.n_pts)
             dst = src.new_like()
             stages = []
             for row in ops:
@@ -139,7 +138,7 @@ def _run_segment(data: Any, head: RegridFilter | None, stages: list[Stage]) -> F
             prog = native.level_program(stages, src.device)
             native.pointwise_stack(src.data, dst.data, n_pts=src.n_pts, n_lev=src.n_lev, x_pitch=src.pitch, y_pitch=dst.pitch,
                                    layout=src.layout, prog=prog, n_stage=len(ops),
-                                   point_mask=None if mask is None else mask.tensor)
+                                   point_mask=None if group_mask is None else group_mask.tensor)
             for level, pos in zip(group.levels, group.positions):
                 out[pos] = new_field_from_stack(dst, level, template=proxies[pos])
         return FieldList(out)
@@ -148,18 +147,24 @@ def _run_segment(data: Any, head: RegridFilter | None, stages: list[Stage]) -> F
     for group in group_into_stacks(fields):
         plan = interp.plan_for(group.fields[0])
         lat, lon = interp.out_latlon(group.fields[0])
+        window = None
+        full_targets = plan.n_tgt
         if head.shard is not None:
             lo, hi = plan.shard_range(*head.shard)
+            window = (lo, hi, full_targets)
             plan, lat, lon = interp._sharded(plan, head.shard), lat[lo:hi], lon[lo:hi]
         kwargs = {}
         if any(touched[p] for p in group.positions):
+            tgt_mask = mask
             if mask is not None and mask.n_points != plan.n_tgt:
-                raise IndexError(f"boolean index did not match indexed array: mask has {mask.n_points} points, field has {plan.n_tgt}")
+                if window is None or mask.n_points != full_targets:
+                    raise IndexError(f"boolean index did not match indexed array: mask has {mask.n_points} points, field has {plan.n_tgt}")
+                tgt_mask = mask.window(window[0], window[1])  # a full-grid mask on this rank's slice of the targets
             kwargs = dict(prog=native.level_program([[row[p] for p in group.positions] for row in ops], group.stack.device),
-                          n_stage=len(ops), tgt_mask=None if mask is None else mask.tensor)
+                          n_stage=len(ops), tgt_mask=None if tgt_mask is None else tgt_mask.tensor)
         regridded = plan.apply(group.stack, **kwargs)
         for level, pos in enumerate(group.positions):
-            out[pos] = new_field_from_stack(regridded, level, template=proxies[pos], latitudes=lat, longitudes=lon)
+            out[pos] = new_field_from_stack(regridded, level, template=proxies[pos], latitudes=lat, longitudes=lon, target_range=window)
     return FieldList(out)
 
 

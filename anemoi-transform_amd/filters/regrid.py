@@ -60,18 +60,20 @@ class _Interpolator:
         fields = list(data)
         out: list[Any] = [None] * len(fields)
         # stacks that share a plan (several variables / time steps on one grid pair) go through ONE batched launch
-        batches: dict[int, tuple[GatherPlan, np.ndarray, np.ndarray, list[Any]]] = {}
+        batches: dict[int, tuple[GatherPlan, np.ndarray, np.ndarray, Any, list[Any]]] = {}
         for group in group_into_stacks(fields):
             plan = self.plan_for(group.fields[0])
             lat, lon = self.out_latlon(group.fields[0])
+            window = None
             if shard is not None:
                 lo, hi = plan.shard_range(*shard)
+                window = (lo, hi, plan.n_tgt)  # the output fields know which points of the target grid they hold
                 plan, lat, lon = self._sharded(plan, shard), lat[lo:hi], lon[lo:hi]
-            batches.setdefault(id(plan), (plan, lat, lon, []))[3].append(group)
-        for plan, lat, lon, groups in batches.values():
+            batches.setdefault(id(plan), (plan, lat, lon, window, []))[4].append(group)
+        for plan, lat, lon, window, groups in batches.values():
             for group, regridded in zip(groups, plan.apply_many([g.stack for g in groups])):
                 for level, (pos, f) in enumerate(zip(group.positions, group.fields)):
-                    out[pos] = new_field_from_stack(regridded, level, template=f, latitudes=lat, longitudes=lon)
+                    out[pos] = new_field_from_stack(regridded, level, template=f, latitudes=lat, longitudes=lon, target_range=window)
         return FieldList(out)
 
     def _sharded(self, plan: GatherPlan, shard: tuple[int, int]) -> GatherPlan:

@@ -104,6 +104,43 @@ def test_regrid_chain_fused_equals_unfused_and_oracle(engine, launches, tmp_path
     assert fused[0].metadata("units") == "degC"
 
 
+@pytest.mark.parametrize("fuse", [True, False])
+def test_target_sharded_pipeline_with_a_full_grid_mask(engine, tmp_path, monkeypatch, fuse):
+    """Every rank of a target-sharded job runs `regrid(shard=(r, world)) | ... | apply_mask(path=<full-grid mask>)` on
+    its own slice: the slices know which target points they hold and the mask is windowed accordingly; the slices
+    concatenate to the unsharded result (fused and filter by filter)."""
+    specs, matrix, mask_path, mask = setup_case(tmp_path)
+    if not fuse:
+        monkeypatch.setenv("ATX_NO_FUSION", "1")
+
+    def run(shard):
+        pipeline = test_source(specs)
+        filters = config5_pipeline(matrix, mask_path)
+        filters[0] = create_filter_by_name("regrid", matrix=matrix, shard=shard)
+        for f in filters:
+            pipeline = pipeline | f
+        return list(pipeline)
+
+    whole = run(None)
+    world = 3
+    parts = [run((r, world)) for r in range(world)]
+    n_tgt = len(matrix["out_latitudes"])
+    for i, w in enumerate(whole):
+        assert w.target_range() is None
+        ranges = [p[i].target_range() for p in parts]
+        assert ranges[0][0] == 0 and ranges[-1][1] == n_tgt and all(r[2] == n_tgt for r in ranges)
+        assert all(a[1] == b[0] for a, b in zip(ranges, ranges[1:]))
+        joined = np.concatenate([p[i].to_numpy(flatten=True) for p in parts])
+        assert np.array_equal(joined, w.to_numpy(flatten=True), equal_nan=True)
+        assert np.array_equal(np.concatenate([p[i].grid_points()[0] for p in parts]), w.grid_points()[0])
+        assert [p[i].metadata("param") for p in parts] == [w.metadata("param")] * world
+    # a mask that is neither the slice's nor the whole grid's length is still an error
+    np.save(str(tmp_path / "short.npy"), np.zeros(n_tgt - 1))
+    bad = create_filter_by_name("apply_mask", path=str(tmp_path / "short.npy"), mask_value=1)
+    with pytest.raises(IndexError):
+        list(test_source(specs) | create_filter_by_name("regrid", matrix=matrix, shard=(0, world)) | bad)
+
+
 def test_pointwise_run_without_regrid_is_one_launch(engine, launches):
     src = lookup("o16")
     specs = synthetic_fields(src, 4)
