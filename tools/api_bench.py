@@ -50,8 +50,15 @@ def main():
     regrid = create_filter_by_name("regrid", matrix=matrix)
     chain = regrid | create_filter_by_name("orog_to_z") | create_filter_by_name("convert", unit_in="K", unit_out="degC", param="t")
     rescale = create_filter_by_name("rescale", scale=1.0, offset=-273.15, param="t")
+    # config-4 shape: several variables x 137 levels on the same grid pair -> one batched launch (atx_regrid_ell_batch)
+    more = [bench.synth_stack(src, L, torch.float32, dev, s, COLUMNS) for s in (1, 2)]
+    many = FieldList(list(fields) + [
+        new_field_from_stack(st, l, template=template, latitudes=src["latitudes"], longitudes=src["longitudes"],
+                             metadata={"param": name, "levelist": l + 1})
+        for st, name in zip(more, ("u", "v")) for l in range(L)])
     res = {
         "regrid.forward (137 fields, one stack)": wall(lambda: regrid.forward(fields)),
+        "regrid.forward (411 fields, three stacks, one batched launch)": wall(lambda: regrid.forward(many)),
         "fused pipeline regrid|orog_to_z|convert": wall(lambda: chain.forward(fields)),
         "rescale.forward on 136 of 137 source fields": wall(lambda: rescale.forward(fields)),
     }
