@@ -350,6 +350,14 @@ class DerivedField(Field):
                 base[key] = self._overrides[key]
         return base
 
+    def __getattr__(self, name: str) -> Any:
+        # R: fields.py:69-109 — attributes this wrapper does not define are forwarded to the wrapped field, with a warning;
+        # `copy` is refused (and so is `clone` there: here every field defines it)
+        if name.startswith("_") or name in ("clone", "copy"):
+            raise AttributeError(f"{type(self).__name__}: forwarding of `{name}` is not supported")
+        LOG.warning("%s: forwarding `%s`", type(self).__name__, name)
+        return getattr(self._template, name)
+
     def __repr__(self) -> str:
         where = f"hbm level {self._level}" if self._stack is not None else ("host array" if self._data is not None else "template data")
         return f"DerivedField({self._template!r}, {where}, metadata={self._overrides})"

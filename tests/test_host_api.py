@@ -461,3 +461,23 @@ def test_cli_writes_the_reference_file_formats(tmp_path, capsys):
     assert mask.dtype.kind == "i" and np.all(np.diff(mask) > 0) and len(mask) > 0
     assert main(["filters", "list"]) == 0
     assert "regrid" in capsys.readouterr().out
+
+
+def test_derived_field_forwards_unknown_attributes(caplog):
+    """R: fields.py:69-109 (WrappedField.__getattr__): unknown attributes come from the wrapped field, with a warning;
+    `copy` is refused."""
+    import logging
+
+    from anemoi_transform_amd.fields import ArrayField, new_field_with_metadata
+
+    base = ArrayField(np.arange(6.0).reshape(3, 2), {"param": "t"}, np.zeros(6), np.zeros(6))
+    base.origin = "unit-test"
+    derived = new_field_with_metadata(new_field_with_metadata(base, param="u"), levelist=5)
+    with caplog.at_level(logging.WARNING):
+        assert derived.origin == "unit-test"
+    assert "forwarding `origin`" in caplog.text
+    with pytest.raises(AttributeError, match="forwarding of `copy` is not supported"):
+        derived.copy
+    with pytest.raises(AttributeError):
+        derived.no_such_attribute
+    assert derived.clone(param="v").metadata("param") == "v"
