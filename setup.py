@@ -4,7 +4,6 @@
 """
 
 import os
-import subprocess
 import sys
 
 from setuptools import setup
