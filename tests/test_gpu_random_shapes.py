@@ -1,0 +1,212 @@
+"""Randomised differential test of the regrid / per-point / level-gather kernels against the oracle.
+
+Seeded, so every run draws the same cases: odd sizes around the vector width, the tile sizes and the workgroup size;
+loose pitches (padding poisoned with NaN, which must neither be read into a result nor overwritten); both layouts, both
+dtypes; fixed-k, padded ragged and general CSR operators; epilogue programs with point masks; batches.  Float64
+results must equal numpy / scipy bit for bit, float32 within the 1e-6 relative tolerance of BASELINE.json.
+"""
+
+from __future__ import annotations
+
+import numpy as np
+import pytest
+import torch
+
+from anemoi_transform_amd import native
+from anemoi_transform_amd.stack import COLUMNS, FIELDS
+from oracle import oracle
+
+pytestmark = pytest.mark.gpu
+
+POISON = float("nan")
+
+
+class Loose:
+    """A stack with an arbitrary pitch whose padding is poisoned."""
+
+    def __init__(self, values: np.ndarray, layout: int, pad: int, dev, align16: bool):
+        n_lev, n_pts = values.shape
+        tdt = torch.float32 if values.dtype == np.float32 else torch.float64
+        per16 = 16 // values.itemsize
+        rows, row_len = (n_pts, n_lev) if layout == COLUMNS else (n_lev, n_pts)
+        pitch = row_len + pad
+        if align16:
+            pitch = (pitch + per16 - 1) // per16 * per16
+        self.data = torch.full((rows, pitch), POISON, dtype=tdt, device=dev)
+        block = torch.from_numpy(np.ascontiguousarray(values.T if layout == COLUMNS else values)).to(dev)
+        self.data[:, :row_len] = block
+        self.n_lev, self.n_pts, self.layout, self.pitch, self.row_len = n_lev, n_pts, layout, pitch, row_len
+
+    def values(self) -> np.ndarray:
+        a = self.data[:, : self.row_len].cpu().numpy()
+        return a.T.copy() if self.layout == COLUMNS else a
+
+    def padding_untouched(self) -> bool:
+        # column stacks: the 16-byte vector kernels own the padding levels up to the next vector boundary (atx.h: the
+        # content of the padding is unspecified); everything beyond that, and all padding of field-major rows, stays
+        start = self.row_len
+        if self.layout == COLUMNS:
+            per16 = 16 // self.data.element_size()
+            start = (self.row_len + per16 - 1) // per16 * per16
+        pad = self.data[:, start:]
+        return bool(torch.isnan(pad).all().item()) if pad.numel() else True
+
+
+def random_program(rng, n_stage, n_lev):
+    ops = []
+    for _ in range(n_stage):
+        stage = []
+        uniform = rng.random() < 0.5
+        base = None
+        for l in range(n_lev):
+            if uniform and base is not None:
+                stage.append(base)
+                continue
+            kind = rng.integers(0, 7)
+            use_mask = int(rng.random() < 0.3)
+            entry = [(native.OP_COPY, use_mask, 0.0, 0.0), (native.OP_AFFINE, use_mask, 1.5, -3.0), (native.OP_AFFINE_INV, use_mask, 2.0, 1.0),
+                     (native.OP_MUL, use_mask, 9.80665, 0.0), (native.OP_DIV, use_mask, 9.80665, 0.0),
+                     (native.OP_CLIP, use_mask, 270.0, 300.0), (native.OP_IMPUTE_NAN, use_mask, -1.0, 0.0)][kind]
+            stage.append(entry)
+            base = entry
+        ops.append(stage)
+    return ops
+
+
+def apply_program_host(levels: np.ndarray, ops, mask: np.ndarray | None) -> np.ndarray:
+    out = levels.copy()
+    dt = levels.dtype.type
+    for stage in ops:
+        for l, (op, use_mask, p0, p1) in enumerate(stage):
+            x = out[l]
+            p0, p1 = dt(p0), dt(p1)
+            if op == native.OP_AFFINE:
+                x = oracle.rescale_forward(x, p0, p1)
+            elif op == native.OP_AFFINE_INV:
+                x = oracle.rescale_backward(x, p0, p1)
+            elif op == native.OP_MUL:
+                x = x * p0
+            elif op == native.OP_DIV:
+                x = x / p0
+            elif op == native.OP_CLIP:
+                x = oracle.clip(x, p0, p1)
+            elif op == native.OP_IMPUTE_NAN:
+                x = oracle.impute_nans(x.copy(), p0)
+            if use_mask and mask is not None:
+                x = oracle.apply_mask_values(x.copy(), mask)
+            out[l] = x
+    return out
+
+
+def check(got: np.ndarray, want: np.ndarray, what: str):
+    if got.dtype == np.float64:
+        assert np.array_equal(got, want, equal_nan=True), what
+    else:
+        np.testing.assert_allclose(got, want, rtol=1e-6, atol=1e-4, err_msg=what)
+
+
+@pytest.mark.parametrize("seed", range(30))
+def test_random_regrid_cases(dev, seed):
+    rng = np.random.default_rng(1000 + seed)
+    for case in range(10):
+        np_dtype = [np.float32, np.float64][rng.integers(0, 2)]
+        layout = [COLUMNS, FIELDS][rng.integers(0, 2)]
+        n_lev = int(rng.choice([1, 2, 3, 4, 5, 7, 8, 9, 15, 16, 17, 33, 63, 137, 140, 257]))
+        n_src = int(rng.integers(1, 3000))
+        n_tgt = int(rng.choice([1, 2, 7, 8, 15, 16, 17, 31, 255, 256, 257, 1000, 2049]))
+        pad = int(rng.choice([0, 0, 1, 3, 4, 5]))
+        align16 = bool(rng.integers(0, 2))
+        kind = rng.choice(["gather", "ell", "padded", "csr"])
+        x = (280 + 30 * rng.standard_normal((n_lev, n_src))).astype(np_dtype)
+        x[rng.random(x.shape) < 0.02] = np.nan
+        src = Loose(x, layout, pad, dev, align16)
+        out = Loose(np.zeros((n_lev, n_tgt), np_dtype), layout, int(rng.choice([0, 2, 4])), dev, align16)
+        with_prog = rng.random() < 0.4
+        ops = random_program(rng, int(rng.integers(1, 4)), n_lev) if with_prog else None
+        prog = native.level_program(ops, dev) if with_prog else None
+        mask_host = (rng.random(n_tgt) < 0.3) if with_prog else None
+        mask_dev = None
+        if with_prog:
+            mask_dev = torch.zeros(n_tgt + 8, dtype=torch.uint8, device=dev)
+            mask_dev[:n_tgt] = torch.from_numpy(mask_host.astype(np.uint8)).to(dev)
+        kw = dict(n_src=n_src, n_tgt=n_tgt, n_lev=n_lev, src_pitch=src.pitch, out_pitch=out.pitch, layout=layout,
+                  prog=prog, n_stage=len(ops) if with_prog else 0, tgt_mask=mask_dev)
+        what = f"seed {seed} case {case}: {kind} {np_dtype.__name__} layout {layout} L={n_lev} Ns={n_src} Nt={n_tgt} pitches {src.pitch}/{out.pitch} prog={with_prog}"
+        if kind == "gather":
+            idx = rng.integers(0, n_src, n_tgt).astype(np.int32)
+            native.regrid_ell(src.data, out.data, torch.from_numpy(idx).to(dev), None, k=1, **kw)
+            want = oracle.gather_nn(x, idx)
+        elif kind == "ell":
+            k = int(rng.choice([1, 2, 3, 4, 5, 9]))
+            idx = rng.integers(0, n_src, (n_tgt, k)).astype(np.int32)
+            w = rng.random((n_tgt, k)).astype(np_dtype)
+            native.regrid_ell(src.data, out.data, torch.from_numpy(idx).to(dev), torch.from_numpy(w).to(dev), k=k, **kw)
+            indptr = np.arange(n_tgt + 1) * k
+            want = np.stack([oracle.csr_apply(w.reshape(-1), idx.reshape(-1), indptr, (n_tgt, n_src), f) for f in x])
+        elif kind == "padded":
+            k = int(rng.choice([2, 3, 4, 6]))
+            idx = rng.integers(0, n_src, (n_tgt, k)).astype(np.int32)
+            lengths = rng.integers(0, k + 1, n_tgt)
+            present = np.arange(k)[None, :] < lengths[:, None]
+            idx[~present] = -1
+            w = np.where(present, rng.random((n_tgt, k)), 0.0).astype(np_dtype)
+            native.regrid_ell(src.data, out.data, torch.from_numpy(idx).to(dev), torch.from_numpy(w).to(dev), k=k, padded=True, **kw)
+            indptr = np.concatenate([[0], np.cumsum(lengths)])
+            want = np.stack([oracle.csr_apply(w[present], idx[present], indptr, (n_tgt, n_src), f) for f in x])
+        else:
+            lengths = rng.integers(0, int(rng.choice([2, 5, 40])) + 1, n_tgt)
+            indptr = np.concatenate([[0], np.cumsum(lengths)]).astype(np.int32)
+            nnz = int(indptr[-1])
+            indices = rng.integers(0, n_src, nnz).astype(np.int32)
+            data = rng.standard_normal(nnz).astype(np_dtype)
+            kw_csr = {k_: v for k_, v in kw.items()}
+            native.regrid_csr(src.data, out.data, torch.from_numpy(indptr).to(dev), torch.from_numpy(indices).to(dev) if nnz else torch.zeros(1, dtype=torch.int32, device=dev),
+                              torch.from_numpy(data).to(dev) if nnz else torch.zeros(1, dtype=src.data.dtype, device=dev), nnz=nnz, **kw_csr)
+            want = np.stack([oracle.csr_apply(data, indices, indptr, (n_tgt, n_src), f) for f in x])
+        if with_prog:
+            want = apply_program_host(want.astype(np_dtype), ops, mask_host)
+        check(out.values(), want.astype(np_dtype), what)
+        assert out.padding_untouched(), what + " (padding of the output written)"
+
+
+@pytest.mark.parametrize("seed", range(15))
+def test_random_pointwise_and_level_gather_cases(dev, seed):
+    rng = np.random.default_rng(2000 + seed)
+    for case in range(10):
+        np_dtype = [np.float32, np.float64][rng.integers(0, 2)]
+        layout = [COLUMNS, FIELDS][rng.integers(0, 2)]
+        n_lev = int(rng.choice([1, 2, 3, 4, 5, 8, 9, 31, 137, 300]))
+        n_pts = int(rng.choice([1, 3, 4, 5, 63, 64, 65, 255, 257, 1023, 1025, 4099]))
+        pad = int(rng.choice([0, 0, 0, 1, 4, 6]))
+        align16 = bool(rng.integers(0, 2))
+        x = (280 + 30 * rng.standard_normal((n_lev, n_pts))).astype(np_dtype)
+        x[rng.random(x.shape) < 0.03] = np.nan
+        what = f"seed {seed} case {case}: {np_dtype.__name__} layout {layout} L={n_lev} N={n_pts} pad {pad} align16 {align16}"
+        # per-point program, out of place and in place
+        ops = random_program(rng, int(rng.integers(1, 5)), n_lev)
+        prog = native.level_program(ops, dev)
+        mask_host = rng.random(n_pts) < 0.25
+        mask_dev = torch.zeros(n_pts + 8, dtype=torch.uint8, device=dev)
+        mask_dev[:n_pts] = torch.from_numpy(mask_host.astype(np.uint8)).to(dev)
+        src = Loose(x, layout, pad, dev, align16)
+        dst = Loose(np.zeros_like(x), layout, pad, dev, align16)
+        kw = dict(n_pts=n_pts, n_lev=n_lev, layout=layout, prog=prog, n_stage=len(ops), point_mask=mask_dev)
+        native.pointwise_stack(src.data, dst.data, x_pitch=src.pitch, y_pitch=dst.pitch, **kw)
+        want = apply_program_host(x, ops, mask_host)
+        check(dst.values(), want, what + " out of place")
+        assert dst.padding_untouched() and np.array_equal(src.values(), x, equal_nan=True), what
+        native.pointwise_stack(src.data, src.data, x_pitch=src.pitch, y_pitch=src.pitch, **kw)
+        check(src.values(), want, what + " in place")
+        assert src.padding_untouched(), what
+        # level gather
+        n_out = int(rng.integers(1, n_lev + 3))
+        level_map = [int(v) for v in rng.integers(-1, n_lev, n_out)]
+        src2 = Loose(x, layout, pad, dev, align16)
+        out = Loose(np.full((n_out, n_pts), 7.0, np_dtype), layout, int(rng.choice([0, 3])), dev, align16)
+        native.select_levels(src2.data, out.data, level_map, n_pts=n_pts, n_src_lev=n_lev, src_pitch=src2.pitch, dst_pitch=out.pitch, layout=layout)
+        want = np.stack([x[l] if l >= 0 else np.full(n_pts, 7.0, np_dtype) for l in level_map])
+        itype = np.uint32 if np_dtype == np.float32 else np.uint64
+        assert np.array_equal(out.values().view(itype), want.view(itype)), what + " level gather"
+        assert out.padding_untouched(), what
+        # pitched reduction ignores the poisoned padding
+        assert native.reduce_stack(src2.data, native.RED_NANCOUNT, n_pts=n_pts, n_lev=n_lev, pitch=src2.pitch, layout=layout) == float(np.isnan(x).sum())
