@@ -208,5 +208,13 @@ def test_random_pointwise_and_level_gather_cases(dev, seed):
         itype = np.uint32 if np_dtype == np.float32 else np.uint64
         assert np.array_equal(out.values().view(itype), want.view(itype)), what + " level gather"
         assert out.padding_untouched(), what
+        # layout conversion between loose pitches, both directions
+        other = FIELDS if layout == COLUMNS else COLUMNS
+        conv = Loose(np.zeros_like(x), other, int(rng.choice([0, 1, 4])), dev, align16)
+        native.relayout(src2.data, conv.data, n_pts=n_pts, n_lev=n_lev, src_pitch=src2.pitch, dst_pitch=conv.pitch, src_layout=layout, dst_layout=other)
+        assert np.array_equal(conv.values().view(itype), x.view(itype)), what + " relayout"
+        same = Loose(np.zeros_like(x), layout, int(rng.choice([0, 2])), dev, align16)
+        native.relayout(src2.data, same.data, n_pts=n_pts, n_lev=n_lev, src_pitch=src2.pitch, dst_pitch=same.pitch, src_layout=layout, dst_layout=layout)
+        assert np.array_equal(same.values().view(itype), x.view(itype)) and same.padding_untouched(), what + " pitched copy"
         # pitched reduction ignores the poisoned padding
         assert native.reduce_stack(src2.data, native.RED_NANCOUNT, n_pts=n_pts, n_lev=n_lev, pitch=src2.pitch, layout=layout) == float(np.isnan(x).sum())
