@@ -142,3 +142,41 @@ def test_device_mask_builders_equal_the_host_ones(dev):
     g = spatial.unit_sphere_xyz(glob["latitudes"][box], glob_lons[box])
     da, db = ((g - xyz[a]) ** 2).sum(axis=1), ((g - xyz[b]) ** 2).sum(axis=1)
     assert np.array_equal(da, db)  # ... i.e. the chosen neighbours are equally near
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_knn_random_point_sets(dev, seed):
+    """Seeded random cases: tiny and odd-sized source sets (around the 8-point leaves of the box tree), clustered points,
+    exact duplicates, more neighbours asked for than there are sources (cKDTree pads with index n / distance inf)."""
+    rng = np.random.default_rng(500 + seed)
+    for case in range(6):
+        n_src = int(rng.choice([1, 2, 7, 8, 9, 15, 17, 63, 65, 500, 3001]))
+        n_tgt = int(rng.choice([1, 5, 64, 257, 1500]))
+        k = int(rng.choice([1, 2, 3, 4, 8]))
+        style = rng.choice(["uniform", "cluster", "duplicates"])
+        if style == "uniform":
+            lat, lon = np.degrees(np.arcsin(rng.uniform(-1, 1, n_src))), rng.uniform(0, 360, n_src)
+        elif style == "cluster":
+            lat, lon = 45 + rng.normal(0, 0.01, n_src), 10 + rng.normal(0, 0.01, n_src)
+        else:
+            base = max(1, n_src // 3)
+            pick = rng.integers(0, base, n_src)
+            lat, lon = np.degrees(np.arcsin(rng.uniform(-1, 1, base)))[pick], rng.uniform(0, 360, base)[pick]
+        src = dict(latitudes=lat, longitudes=lon)
+        tlat, tlon = np.degrees(np.arcsin(rng.uniform(-1, 1, n_tgt))), rng.uniform(0, 360, n_tgt)
+        if style == "cluster":
+            tlat, tlon = 45 + rng.normal(0, 0.02, n_tgt), 10 + rng.normal(0, 0.02, n_tgt)
+        tgt = dict(latitudes=tlat, longitudes=tlon)
+        want_i, want_d = oracle.nearest_grid_points(lat, lon, tlat, tlon, num_neighbours_to_return=k, return_distances=True)
+        got_i, got_d = interp.nearest_grid_points_device(lat, lon, tlat, tlon, num_neighbours_to_return=k, return_distances=True)
+        what = f"seed {seed} case {case}: {style} n_src={n_src} n_tgt={n_tgt} k={k}"
+        assert got_i.shape == want_i.shape, what
+        assert np.array_equal(got_d, want_d), what + ": distances must be bit-identical to cKDTree's"
+        missing = np.isinf(want_d)
+        assert np.array_equal(got_i[missing], want_i[missing]), what + ": the 'no neighbour' marker is len(source)"
+        # where all candidate distances of a row are distinct the index lists are identical
+        gi, wi, gd = got_i.reshape(n_tgt, -1), want_i.reshape(n_tgt, -1), got_d.reshape(n_tgt, -1)
+        with np.errstate(invalid="ignore"):  # inf - inf between two missing neighbours
+            distinct = (np.diff(gd, axis=1) != 0).all(axis=1) if gd.shape[1] > 1 else np.ones(n_tgt, bool)
+        if style != "duplicates":  # duplicated sources tie at any rank: only the distances are comparable
+            assert np.array_equal(gi[distinct], wi[distinct]), what
