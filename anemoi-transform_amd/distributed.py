@@ -123,6 +123,30 @@ def sharded_regrid(plan: GatherPlan, src: Stack, rank: int | None = None, world:
     return plan.shard(rank, world).apply(src)
 
 
+def pipelined_sharded_regrid(plan: GatherPlan, mine: Stack) -> list[Stack]:
+    """End-to-end form of the target-sharded step: every rank contributes one source stack; the broadcast of stack
+    ``r + 1`` runs (on the collective's own stream) while this rank interpolates its target slice of stack ``r``.
+    Returns this rank's slice of every rank's stack, in rank order.  Two source buffers are alive at a time instead of
+    ``world`` (SURVEY.md §7 "broadcast >> kernel": chunk by 137-level stack and double-buffer)."""
+    rank, world = dist.get_rank(), dist.get_world_size()
+    local = plan.shard(rank, world)
+
+    def incoming(r: int) -> Stack:
+        return mine if r == rank else Stack.empty(mine.n_pts, mine.n_lev, mine.dtype, mine.device, mine.layout)
+
+    outs: list[Stack] = []
+    buf = incoming(0)
+    work = dist.broadcast(buf.data, src=0, async_op=True)
+    for r in range(world):
+        work.wait()  # the compute stream waits for broadcast r; the host does not block on the GPU
+        current = buf
+        if r + 1 < world:
+            buf = incoming(r + 1)
+            work = dist.broadcast(buf.data, src=r + 1, async_op=True)  # overlaps with the launch below
+        outs.append(local.apply(current))
+    return outs
+
+
 def gather_target_shards(local: Stack, plan: GatherPlan) -> Stack:
     """All target slices of ``plan`` on every rank (column layout: each slice is a contiguous row range)."""
     assert local.layout == COLUMNS, "target shards are row ranges of a column stack"

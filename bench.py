@@ -64,6 +64,9 @@ def parse_args():
     ap.add_argument("--exchange", default="broadcast", choices=["broadcast", "bands"],
                     help="N > 1 source exchange before timing: whole stacks by RCCL broadcast, or only the band of source columns "
                          "each rank's target slice references by send/recv (distributed.exchange_source_bands)")
+    ap.add_argument("--end-to-end", action="store_true",
+                    help="N > 1: also time one step INCLUDING the source exchange, broadcasts double-buffered against the launches "
+                         "(distributed.pipelined_sharded_regrid); reported as `end_to_end`, never as `value`")
     ap.add_argument("--share-device", action="store_true",
                     help="REHEARSAL ONLY: all ranks use cuda:0 (exercises the N > 1 code path on a 1-GPU box; needs --backend gloo)")
     return ap.parse_args()
@@ -282,6 +285,22 @@ def main():
         },
         "precompute_s": precompute_s,
     }
+    if world > 1 and args.end_to_end and layout == COLUMNS:
+        from anemoi_transform_amd.distributed import pipelined_sharded_regrid
+
+        del outs
+        torch.cuda.empty_cache()
+        mine_again = synth_stack(src_grid, args.levels, tdtype, dev, rank, layout)
+        pipelined_sharded_regrid(plan, mine_again)  # warm-up (communicator, allocations)
+        torch.cuda.synchronize()
+        dist.barrier()
+        t0 = time.perf_counter()
+        pipelined_sharded_regrid(plan, mine_again)
+        torch.cuda.synchronize()
+        t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        result["end_to_end"] = {"ms_per_step": float(t.item()) * 1e3, "value": units_per_step / float(t.item()), "unit": "grid-points/s",
+                                "note": "one step including the exchange of the N source stacks (broadcast r+1 overlapped with launch r)"}
     if exchange_ms is not None:
         result["source_exchange_ms"] = exchange_ms
         result["source_exchange"] = args.exchange

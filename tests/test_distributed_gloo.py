@@ -96,6 +96,13 @@ def _worker(rank: int, world: int, port: int, kind: str, tmpdir: str) -> None:
         want = shard.apply(Stack.from_fields(full_r, dev=torch.device("cpu"))).numpy()
         assert np.array_equal(local_plan.apply(band_stack).numpy(), want)
 
+    # 4. double-buffered form: broadcast of the next stack overlaps with the interpolation of the current one
+    piped = atxd.pipelined_sharded_regrid(plan, mine)
+    assert len(piped) == world
+    for r, got_r in enumerate(piped):
+        full_r = 280.0 + np.random.default_rng(100 + r).standard_normal((n_lev, n_src))
+        assert np.array_equal(got_r.numpy(), shard.apply(Stack.from_fields(full_r, dev=torch.device("cpu"))).numpy())
+
     dist.barrier()
     with open(os.path.join(tmpdir, f"ok{rank}"), "w") as f:
         f.write("ok")
