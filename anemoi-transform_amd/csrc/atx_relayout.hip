@@ -50,6 +50,75 @@ transpose_kernel(const T* __restrict__ src, T* __restrict__ dst, int64_t n_pts, 
     }
 }
 
+// The same tile with 16-byte accesses on BOTH sides (needs 16-byte aligned bases and pitches that are multiples of a
+// vector on both sides, and whole vectors inside the column pitch): on the fields side a lane moves VEC consecutive
+// points of one level, on the columns side VEC consecutive levels of one point; LDS accesses stay scalar.
+template <typename T, bool TO_COLUMNS>
+__global__ void __launch_bounds__(kBlock)
+transpose_vec_kernel(const T* __restrict__ src, T* __restrict__ dst, int64_t n_pts, int n_lev,
+                     int64_t src_pitch, int64_t dst_pitch, int TP, int LC, int LCpad) {
+    constexpr int VEC = Vec16<T>::N;
+    using V = Pack<T, VEC>;
+    extern __shared__ __align__(16) unsigned char smem[];
+    T* tile = reinterpret_cast<T*>(smem);
+    const int64_t p0 = (int64_t)blockIdx.x * TP;
+    const int l0 = blockIdx.y * LC;
+    const int np = (int)min((int64_t)TP, n_pts - p0);
+    const int nl = min(LC, n_lev - l0);
+    const int tid = threadIdx.x;
+    const int PV = TP / VEC;               // point vectors per level row of the tile
+    const int CV = (nl + VEC - 1) / VEC;   // level vectors per column of the tile (l0 is a multiple of VEC)
+    const T* fields = TO_COLUMNS ? src : dst;
+    const int64_t fields_pitch = TO_COLUMNS ? src_pitch : dst_pitch;
+    const int64_t cols_pitch = TO_COLUMNS ? dst_pitch : src_pitch;
+    (void)fields;
+
+    if (TO_COLUMNS) {
+        for (int i = tid; i < nl * PV; i += kBlock) {
+            const int l = i / PV, pv = i - l * PV;
+            const int p = pv * VEC;
+            if (p + VEC <= np) {
+                const V v = *reinterpret_cast<const V*>(src + (int64_t)(l0 + l) * fields_pitch + p0 + p);
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) tile[(p + e) * LCpad + l] = v.v[e];
+            } else {
+                for (int e = 0; e < VEC; ++e)
+                    if (p + e < np) tile[(p + e) * LCpad + l] = src[(int64_t)(l0 + l) * fields_pitch + p0 + p + e];
+            }
+        }
+        __syncthreads();
+        for (int i = tid; i < np * CV; i += kBlock) {
+            const int p = i / CV, c = i - p * CV;
+            V v;
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) v.v[e] = (c * VEC + e < nl) ? tile[p * LCpad + c * VEC + e] : T(0);
+            *reinterpret_cast<V*>(dst + (p0 + p) * cols_pitch + l0 + c * VEC) = v;
+        }
+    } else {
+        for (int i = tid; i < np * CV; i += kBlock) {
+            const int p = i / CV, c = i - p * CV;
+            const V v = *reinterpret_cast<const V*>(src + (p0 + p) * cols_pitch + l0 + c * VEC);
+#pragma unroll
+            for (int e = 0; e < VEC; ++e)
+                if (c * VEC + e < nl) tile[p * LCpad + c * VEC + e] = v.v[e];
+        }
+        __syncthreads();
+        for (int i = tid; i < nl * PV; i += kBlock) {
+            const int l = i / PV, pv = i - l * PV;
+            const int p = pv * VEC;
+            if (p + VEC <= np) {
+                V v;
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) v.v[e] = tile[(p + e) * LCpad + l];
+                *reinterpret_cast<V*>(dst + (int64_t)(l0 + l) * fields_pitch + p0 + p) = v;
+            } else {
+                for (int e = 0; e < VEC; ++e)
+                    if (p + e < np) dst[(int64_t)(l0 + l) * fields_pitch + p0 + p + e] = tile[(p + e) * LCpad + l];
+            }
+        }
+    }
+}
+
 // same layout on both sides: pitched copy of rows of `row_len` elements
 template <typename T>
 __global__ void __launch_bounds__(kBlock)
@@ -86,6 +155,23 @@ static int relayout_typed(const void* src_, void* dst_, int64_t n_pts, int n_lev
     const unsigned gx = (unsigned)((n_pts + TP - 1) / TP);
     const unsigned gy = (unsigned)((n_lev + LC - 1) / LC);
     ATX_REQUIRE(gy <= 65535, ATX_ENOTIMPL, "atx_relayout: too many level chunks");
+#ifndef ATX_TP_VEC
+#define ATX_TP_VEC 1
+#endif
+    {
+        constexpr int VEC = Vec16<T>::N;
+        const int64_t cols_pitch = dst_layout == ATX_COLUMNS ? dp : sp, fields_pitch = dst_layout == ATX_COLUMNS ? sp : dp;
+        const int64_t covered = ((int64_t)(n_lev + VEC - 1) / VEC) * VEC;
+        const bool vec = ATX_TP_VEC && aligned16(src_) && aligned16(dst_) && cols_pitch % VEC == 0 && fields_pitch % VEC == 0 &&
+                         covered <= cols_pitch && (gy == 1 || LC % VEC == 0) && TP % VEC == 0;
+        // measured (137 levels of O1280): towards columns 2.14 -> 1.44 ms f32, 3.20 -> 2.89 ms f64; towards fields the scalar
+        // kernel is as fast (f32) or faster (f64: 2.69 vs 3.16 ms), so only the columns direction takes the vector kernel
+        if (vec && dst_layout == ATX_COLUMNS) {
+            hipLaunchKernelGGL((transpose_vec_kernel<T, true>), dim3(gx, gy), dim3(kBlock), lds, st, src, dst, n_pts, n_lev, sp, dp, TP, LC, LCpad);
+            ATX_LAUNCH_CHECK("transpose_vec");
+            return ATX_OK;
+        }
+    }
     if (dst_layout == ATX_COLUMNS)
         hipLaunchKernelGGL((transpose_kernel<T, true>), dim3(gx, gy), dim3(kBlock), lds, st, src, dst, n_pts, n_lev, sp, dp, TP, LC, LCpad);
     else
