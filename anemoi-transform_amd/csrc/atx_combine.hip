@@ -70,37 +70,88 @@ __device__ __forceinline__ void combine_one(int op, int flags, const T* x, int n
     }
 }
 
-template <typename T, int VEC>
+// The stacks are contiguous runs of vectors (pitch is a multiple of the vector): a workgroup sweeps line-aligned chunks
+// of kBlock * U vectors, U = kCombUnroll independent loads per operand and lane in flight for up to 3 operands (the n-ary
+// sum keeps one: 8 operands x 4 vectors would not fit the register file).  Non-temporal stores measured no better.
+#ifndef ATX_COMB_UNROLL
+#define ATX_COMB_UNROLL 4  // measured on 137-level O1280 stacks: difference 2->1 f32 2.57 / 2.37 / 2.10 ms at 1 / 2 / 4
+#endif
+#ifndef ATX_COMB_NT
+#define ATX_COMB_NT 0
+#endif
+constexpr int kCombUnroll = ATX_COMB_UNROLL;
+constexpr int comb_unroll(int nin) { return nin <= 3 ? kCombUnroll : 1; }
+
+template <typename T, int N>
+__device__ __forceinline__ void comb_store(T* p, const Pack<T, N>& v) {
+#if ATX_COMB_NT
+    typedef T NV __attribute__((ext_vector_type(N)));
+    __builtin_nontemporal_store(*reinterpret_cast<const NV*>(&v), reinterpret_cast<NV*>(p));
+#else
+    *reinterpret_cast<Pack<T, N>*>(p) = v;
+#endif
+}
+template <typename T>
+__device__ __forceinline__ void comb_store(T* p, const Pack<T, 1>& v) {
+    *p = v.v[0];
+}
+
+// NIN: compile-time bound of the operand count (1, 2, 3 or ATX_COMB_MAX_INPUTS) so the operand registers are exactly as many as needed
+template <typename T, int VEC, int NIN>
 __global__ void __launch_bounds__(kBlock)
 combine_kernel(CombArgs a, int op, int flags, int n_in, int n_out, int64_t n_rows, int64_t row_len, int64_t pitch,
                int layout, int n_lev, const double* __restrict__ level_param) {
     using V = Pack<T, VEC>;
-    const int64_t vec_per_row = pitch / VEC;  // pitch % VEC == 0 on this path (else VEC == 1)
+    const int vec_per_row = (int)(pitch / VEC);  // pitch % VEC == 0 on this path (else VEC == 1)
     const int64_t total = n_rows * vec_per_row;
-    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < total; i += (int64_t)gridDim.x * kBlock) {
-        const int64_t row = i / vec_per_row;
-        const int64_t col = (i - row * vec_per_row) * VEC;
-        V x[ATX_COMB_MAX_INPUTS];
+    constexpr int U = comb_unroll(NIN);
+    constexpr int64_t kChunk = (int64_t)kBlock * U;
+    const bool small_rows = vec_per_row < (1 << 20);  // columns layout: (row, col) from 32-bit arithmetic
+    for (int64_t base = (int64_t)blockIdx.x * kChunk; base < total; base += (int64_t)gridDim.x * kChunk) {
+        const int64_t row_b = base / vec_per_row;  // uniform
+        const int col_b = (int)(base - row_b * vec_per_row);
+        V x[U][NIN];
+        int64_t vi[U];
+        bool ok[U];
 #pragma unroll
-        for (int k = 0; k < ATX_COMB_MAX_INPUTS; ++k)
-            if (k < n_in) x[k] = *reinterpret_cast<const V*>(static_cast<const T*>(a.in[k]) + row * pitch + col);
-        V y0, y1;
+        for (int u = 0; u < U; ++u) {
+            vi[u] = base + u * kBlock + threadIdx.x;
+            ok[u] = vi[u] < total;
 #pragma unroll
-        for (int e = 0; e < VEC; ++e) {
-            T xe[ATX_COMB_MAX_INPUTS];
-#pragma unroll
-            for (int k = 0; k < ATX_COMB_MAX_INPUTS; ++k) xe[k] = (k < n_in) ? x[k].v[e] : T(0);
-            const int64_t level = layout == ATX_COLUMNS ? col + e : row;
-            const bool live = (col + e) < row_len;
-            T lv = T(0);
-            if (level_param && level < n_lev) lv = static_cast<T>(level_param[level]);
-            T r0, r1;
-            combine_one<T>(op, flags, xe, n_in, lv, r0, r1);
-            y0.v[e] = live ? r0 : T(0);  // padding stays zero
-            y1.v[e] = live ? r1 : T(0);
+            for (int k = 0; k < NIN; ++k)
+                if (k < n_in && ok[u]) x[u][k] = *reinterpret_cast<const V*>(static_cast<const T*>(a.in[k]) + vi[u] * VEC);
         }
-        *reinterpret_cast<V*>(static_cast<T*>(a.out[0]) + row * pitch + col) = y0;
-        if (n_out > 1) *reinterpret_cast<V*>(static_cast<T*>(a.out[1]) + row * pitch + col) = y1;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (!ok[u]) continue;
+            int64_t row, col;
+            if (small_rows) {
+                const int off = col_b + u * kBlock + threadIdx.x;
+                const int dr = off / vec_per_row;
+                row = row_b + dr;
+                col = (int64_t)(off - dr * vec_per_row) * VEC;
+            } else {
+                row = vi[u] / vec_per_row;
+                col = (vi[u] - row * vec_per_row) * VEC;
+            }
+            V y0, y1;
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) {
+                T xe[ATX_COMB_MAX_INPUTS];
+#pragma unroll
+                for (int k = 0; k < ATX_COMB_MAX_INPUTS; ++k) xe[k] = (k < NIN && k < n_in) ? x[u][k < NIN ? k : 0].v[e] : T(0);
+                const int64_t level = layout == ATX_COLUMNS ? col + e : row;
+                const bool live = (col + e) < row_len;
+                T lv = T(0);
+                if (level_param && level < n_lev) lv = static_cast<T>(level_param[level]);
+                T r0, r1;
+                combine_one<T>(op, flags, xe, n_in, lv, r0, r1);
+                y0.v[e] = live ? r0 : T(0);  // padding stays zero
+                y1.v[e] = live ? r1 : T(0);
+            }
+            comb_store<T>(static_cast<T*>(a.out[0]) + vi[u] * VEC, y0);
+            if (n_out > 1) comb_store<T>(static_cast<T*>(a.out[1]) + vi[u] * VEC, y1);
+        }
     }
 }
 
@@ -113,15 +164,25 @@ static int combine_typed(const CombArgs& a, int op, int flags, int n_in, int n_o
     for (int k = 0; k < n_out; ++k) vec_ok = vec_ok && aligned16(a.out[k]);
     const int64_t n_rows = layout == ATX_COLUMNS ? n_pts : n_lev;
     const int64_t row_len = layout == ATX_COLUMNS ? n_lev : n_pts;
-    int64_t blocks = (n_rows * (pitch / (vec_ok ? VEC : 1)) + kBlock - 1) / kBlock;
+    const int per_block = kBlock * comb_unroll(n_in <= 3 ? n_in : ATX_COMB_MAX_INPUTS);
+    int64_t blocks = (n_rows * (pitch / (vec_ok ? VEC : 1)) + per_block - 1) / per_block;
     if (blocks > 2048) blocks = 2048;
     if (blocks < 1) blocks = 1;
-    if (vec_ok)
-        hipLaunchKernelGGL((combine_kernel<T, VEC>), dim3((unsigned)blocks), dim3(kBlock), 0, st, a, op, flags, n_in, n_out, n_rows,
-                           row_len, pitch, layout, n_lev, level_param);
-    else
-        hipLaunchKernelGGL((combine_kernel<T, 1>), dim3((unsigned)blocks), dim3(kBlock), 0, st, a, op, flags, n_in, n_out, n_rows,
-                           row_len, pitch, layout, n_lev, level_param);
+#define ATX_COMB_LAUNCH(V_, N_)                                                                                              \
+    hipLaunchKernelGGL((combine_kernel<T, V_, N_>), dim3((unsigned)blocks), dim3(kBlock), 0, st, a, op, flags, n_in, n_out, n_rows, \
+                       row_len, pitch, layout, n_lev, level_param)
+    if (vec_ok) {
+        if (n_in <= 1) ATX_COMB_LAUNCH(VEC, 1);
+        else if (n_in == 2) ATX_COMB_LAUNCH(VEC, 2);
+        else if (n_in == 3) ATX_COMB_LAUNCH(VEC, 3);
+        else ATX_COMB_LAUNCH(VEC, ATX_COMB_MAX_INPUTS);
+    } else {
+        if (n_in <= 1) ATX_COMB_LAUNCH(1, 1);
+        else if (n_in == 2) ATX_COMB_LAUNCH(1, 2);
+        else if (n_in == 3) ATX_COMB_LAUNCH(1, 3);
+        else ATX_COMB_LAUNCH(1, ATX_COMB_MAX_INPUTS);
+    }
+#undef ATX_COMB_LAUNCH
     ATX_LAUNCH_CHECK("combine_stack");
     return ATX_OK;
 }

@@ -100,6 +100,10 @@ def main():
         z = x.new_like()
         record(f"combine snow_cover (2->1) {tag}", timeit(lambda: native.combine_stack(native.COMB_SNOW_COVER, [x.data, y.data], [z.data],
                n_pts=n_src, n_lev=L, pitch=x.pitch, layout=COLUMNS)), 3 * stack_bytes)
+        record(f"combine difference (2->1, accum_to_interval) {tag}", timeit(lambda: native.combine_stack(native.COMB_SUB, [x.data, y.data], [z.data],
+               n_pts=n_src, n_lev=L, pitch=x.pitch, layout=COLUMNS)), 3 * stack_bytes)
+        record(f"combine cos_sin (1->2) {tag}", timeit(lambda: native.combine_stack(native.COMB_COS_SIN, [x.data], [y.data, z.data],
+               n_pts=n_src, n_lev=L, pitch=x.pitch, layout=COLUMNS)), 3 * stack_bytes)
         # ---- layout
         f = Stack.empty(n_src, L, tdt, dev, FIELDS)
         record(f"relayout columns->fields {tag}", timeit(lambda: native.relayout(x.data, f.data, n_pts=n_src, n_lev=L, src_pitch=x.pitch,
