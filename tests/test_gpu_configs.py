@@ -114,3 +114,41 @@ def test_config5_chained_filters_on_o2560(dev):
     for l, fn in ((0, lambda v: oracle.rescale_forward(v, np.float32(1.0), np.float32(-273.15))), (136, lambda v: v * np.float32(oracle.G))):
         base = oracle.csr_apply(w32, idx.reshape(-1), indptr, (n_tgt, n_src), x.level_numpy(l))
         assert np.array_equal(fused.level_numpy(l), fn(base))
+
+
+def test_kernels_on_a_stack_beyond_2_to_31_elements(dev):
+    """O2560 x 137 levels = 3.6e9 elements (14.4 GB f32): every streaming kernel must do its index arithmetic in 64 bits.
+    Checked on samples against torch indexing (bit copies) and against an independent reduction."""
+    from anemoi_transform_amd.stack import FIELDS
+
+    n_pts, n_lev = 26306560, 137
+    assert n_pts * 140 > 2**31
+    x = Stack.empty(n_pts, n_lev, torch.float32, dev, COLUMNS)
+    x.data.copy_((torch.arange(n_pts, device=dev, dtype=torch.float32) % 8191.0).unsqueeze(1) * 0.25)  # exact in f32
+    x.data[:, :n_lev] += torch.arange(n_lev, device=dev, dtype=torch.float32) * 2048.0
+    probe = torch.tensor([0, 1, 12345, n_pts // 2, n_pts - 2, n_pts - 1], device=dev)
+    # per-point program over the whole stack (flat kernel) and its in-place form
+    y = x.new_like()
+    prog = native.level_program([[(native.OP_AFFINE, 0, 2.0, 1.0)] * n_lev], dev)
+    kw = dict(n_pts=n_pts, n_lev=n_lev, x_pitch=x.pitch, y_pitch=y.pitch, layout=COLUMNS, prog=prog, n_stage=1)
+    native.pointwise_stack(x.data, y.data, **kw)
+    assert torch.equal(y.data[probe, :n_lev], x.data[probe, :n_lev] * 2.0 + 1.0)
+    assert torch.equal(y.data[-5:, :n_lev], x.data[-5:, :n_lev] * 2.0 + 1.0)
+    # reduction over the pitched stack
+    assert native.reduce_stack(x.data, native.RED_MAX, n_pts=n_pts, n_lev=n_lev, pitch=x.pitch, layout=COLUMNS) == 8190 * 0.25 + 136 * 2048.0
+    assert native.reduce_stack(x.data, native.RED_NANCOUNT, n_pts=n_pts, n_lev=n_lev, pitch=x.pitch, layout=COLUMNS) == 0.0
+    # level gather of the last levels, then layout conversion both ways
+    sel = Stack.empty(n_pts, 3, torch.float32, dev, COLUMNS)
+    native.select_levels(x.data, sel.data, [136, 0, 68], n_pts=n_pts, n_src_lev=n_lev, src_pitch=x.pitch, dst_pitch=sel.pitch, layout=COLUMNS)
+    assert torch.equal(sel.data[probe, :3], x.data[probe][:, [136, 0, 68]])
+    del y, sel
+    f = x.to_layout(FIELDS)
+    assert torch.equal(f.data[:, probe], x.data[probe, :n_lev].T) and torch.equal(f.data[136, -3:], x.data[-3:, 136])
+    back = f.to_layout(COLUMNS)
+    assert torch.equal(back.data[probe, :n_lev], x.data[probe, :n_lev]) and torch.equal(back.data[-3:, :n_lev], x.data[-3:, :n_lev])
+    del f
+    # multi-input kernel: difference of two stacks
+    z = x.new_like()
+    native.combine_stack(native.COMB_SUB, [back.data, x.data], [z.data], n_pts=n_pts, n_lev=n_lev, pitch=x.pitch, layout=COLUMNS)
+    assert native.reduce_stack(z.data, native.RED_MAX, n_pts=n_pts, n_lev=n_lev, pitch=z.pitch, layout=COLUMNS) == 0.0
+    assert native.reduce_stack(z.data, native.RED_MIN, n_pts=n_pts, n_lev=n_lev, pitch=z.pitch, layout=COLUMNS) == 0.0
