@@ -1,0 +1,55 @@
+"""bench.py's contract (one JSON line with the driver's keys plus `roofline` / `cpu_baseline`) on small grids, and the
+N > 1 code path rehearsed with two ranks sharing the one GPU of the test box over gloo (the real N > 1 runs use RCCL,
+one GPU per rank; this keeps sharding, exchange, batched launch and max-over-ranks timing from rotting)."""
+
+from __future__ import annotations
+
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SMALL = ["--src-grid", "o96", "--tgt-grid", "1.0", "--levels", "7", "--steps", "3", "--warmup", "1"]
+KEYS = {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+        "data", "config", "roofline"}
+
+
+def last_json(stdout: str) -> dict:
+    lines = [l for l in stdout.strip().splitlines() if l.startswith("{")]
+    assert len(lines) == 1, stdout  # exactly ONE JSON line
+    return json.loads(lines[0])
+
+
+def test_single_gpu_line():
+    run = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *SMALL, "--cpu-seconds", "0.5", "--no-extras"],
+                         capture_output=True, text=True, timeout=300, cwd=ROOT)
+    assert run.returncode == 0, run.stderr[-2000:]
+    d = last_json(run.stdout)
+    assert KEYS <= set(d) and d["n_gpus"] == 1 and d["steps"] == 3 and d["warmup"] == 1
+    assert d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None and d["data"] == "synthetic"
+    assert d["unit"] == "grid-points/s" and d["value"] > 0 and d["dtype"] == "f32" and "workload" in d["config"]
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
+    c = d["cpu_baseline"]
+    assert c["kind"] == "port" and c["cores"] == 1 and c["value"] > 0 and "sample" in c
+    assert d["parity_max_rel_err"] <= 1e-6
+
+
+def test_two_ranks_rehearsal_over_gloo():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", *SMALL, "--backend", "gloo", "--share-device"]
+    run = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert run.returncode == 0, run.stderr[-2000:]
+    d = last_json(run.stdout)
+    assert KEYS <= set(d) and d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 0
+    assert d["config"]["stacks_per_step"] == 2 and d["config"]["launches_per_step_per_gpu"] == 1
+    assert d["source_exchange"] == "broadcast" and d["source_exchange_ms"] > 0
+    assert "cpu_baseline" not in d  # rank 0 at N = 1 only
