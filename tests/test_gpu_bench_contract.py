@@ -40,16 +40,19 @@ def test_single_gpu_line():
     assert d["parity_max_rel_err"] <= 1e-6
 
 
-def test_two_ranks_rehearsal_over_gloo():
+@pytest.mark.parametrize("exchange", ["broadcast", "bands"])
+def test_two_ranks_rehearsal_over_gloo(exchange):
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", *SMALL, "--backend", "gloo", "--share-device"]
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", *SMALL, "--backend", "gloo", "--share-device", "--exchange", exchange,
+           "--end-to-end"]
     run = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT)
     assert run.returncode == 0, run.stderr[-2000:]
     d = last_json(run.stdout)
     assert KEYS <= set(d) and d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 0
     assert d["config"]["stacks_per_step"] == 2 and d["config"]["launches_per_step_per_gpu"] == 1
-    assert d["source_exchange"] == "broadcast" and d["source_exchange_ms"] > 0
+    assert d["source_exchange"] == exchange and d["source_exchange_ms"] > 0
+    assert d["end_to_end"]["value"] > 0 and d["end_to_end"]["value"] < d["value"]  # the exchange is inside that one
     assert "cpu_baseline" not in d  # rank 0 at N = 1 only
