@@ -3,8 +3,8 @@
 // engine's native HBM layout).
 //
 // A workgroup moves TP points x LC levels through LDS.  On the FIELDS side a wave
-// touches 128 contiguous bytes of one level (small tiles = many resident workgroups: measured
-// best, 256-B tiles -25 %, 512-B tiles -50 %); on the COLUMNS side the TP columns of
+// touches 256 contiguous bytes of one level (35 KB LDS tiles, 4 workgroups per CU: measured best;
+// 128-B tiles -5 %, 512-B tiles -30 %); on the COLUMNS side the TP columns of
 // the tile form one contiguous TP*pitch run, swept by consecutive lanes.  The LDS
 // tile is [point][level] with an odd row length (in 4-byte words for f32) so both
 // phases are bank-conflict free for f32 and at most 2-way for f64.
@@ -146,8 +146,8 @@ static int relayout_typed(const void* src_, void* dst_, int64_t n_pts, int n_lev
         return ATX_OK;
     }
 #ifndef ATX_TP_BYTES
-#define ATX_TP_BYTES 128
-#endif
+#define ATX_TP_BYTES 256  // re-measured with the vector kernel (137 levels of O1280, ms c->f / f->c): 128 B: 1.65 / 1.47 f32, 2.69 / 2.92 f64;
+#endif                    // 256 B: 1.59-1.66 / 1.32-1.44 f32, 2.52 / 2.66 f64; 384 B and 512 B slower (LDS tiles cut the occupancy)
     const int TP = ATX_TP_BYTES / (int)sizeof(T);  // contiguous bytes per level on the fields side
     int LC = n_lev < 160 ? n_lev : 128;
     const int LCpad = LC | 1;
