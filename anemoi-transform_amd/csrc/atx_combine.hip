@@ -166,7 +166,7 @@ static int combine_typed(const CombArgs& a, int op, int flags, int n_in, int n_o
     const int64_t row_len = layout == ATX_COLUMNS ? n_lev : n_pts;
     const int per_block = kBlock * comb_unroll(n_in <= 3 ? n_in : ATX_COMB_MAX_INPUTS);
     int64_t blocks = (n_rows * (pitch / (vec_ok ? VEC : 1)) + per_block - 1) / per_block;
-    if (blocks > 2048) blocks = 2048;
+    if (blocks > kStreamGrid) blocks = kStreamGrid;
     if (blocks < 1) blocks = 1;
 #define ATX_COMB_LAUNCH(V_, N_)                                                                                              \
     hipLaunchKernelGGL((combine_kernel<T, V_, N_>), dim3((unsigned)blocks), dim3(kBlock), 0, st, a, op, flags, n_in, n_out, n_rows, \

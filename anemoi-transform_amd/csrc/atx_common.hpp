@@ -34,6 +34,14 @@ constexpr int kWave = 64;    // CDNA4 wavefront
 constexpr int kBlock = 256;  // 4 waves: one per SIMD of a CU
 constexpr int kXcds = 8;     // MI355X: 8 XCDs, private 4 MiB L2 each
 
+// Grid cap of the grid-stride streaming kernels.  Measured on MI355X (per-point kernel over a 3.7 GB stack): 2048 workgroups
+// (8 per CU) 1.42 ms, 8192 1.26, 65536 1.20-1.27, 131072 the same, one workgroup per 16 KB chunk (225 k) 1.22-1.26 —
+// many short workgroups keep more requests in different phases in flight than a few long-lived ones.
+#ifndef ATX_MAX_GRID
+#define ATX_MAX_GRID 65536
+#endif
+constexpr int64_t kStreamGrid = ATX_MAX_GRID;
+
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
 // ---- 16-byte vectors ----------------------------------------------------------

@@ -7,14 +7,13 @@
 //   R: filters/fields/clipper.py:69, impute_nans.py:53-54, lnsp_to_sp.py:47,65
 //   R: filters/fields/apply_mask.py:183-185, glacier_mask.py:33  values[mask] = nan
 // by ONE streaming pass over the stack: level l gets prog[s][l] for each stage s.
-// HBM-bound: 16-byte loads/stores, grid capped at 8 workgroups per CU and
-// grid-strided; levels whose program is all-COPY are not touched when the
+// HBM-bound: 16-byte loads/stores, grid-strided over up to kStreamGrid short workgroups; levels whose program is all-COPY are not touched when the
 // operation is in place.
 #include "atx_common.hpp"
 
 namespace atx {
 
-constexpr int kMaxGrid = 256 * 8;  // 256 CUs x 8 workgroups
+constexpr int64_t kMaxGrid = kStreamGrid;
 
 // ATX_COLUMNS.  A workgroup sweeps CONTIGUOUS chunks of rows (points).  Its lanes are laid over
 // (row-in-pass, vector column): lane = r*Cg + c with Cg = min(C, 256) columns per pass and
@@ -378,45 +377,61 @@ __global__ void reduce_init_kernel(double* result, int red) {
     *result = red == ATX_RED_MIN ? INFINITY : (red == ATX_RED_MAX ? -INFINITY : 0.0);
 }
 
+// One partial per lane over a grid-stride sweep (4 independent loads in flight), 64-lane shuffle, one LDS combine per
+// workgroup, ONE atomic per workgroup (a per-wave atomic on a single address serialised 100 k of them on large inputs).
+constexpr int kRedUnroll = 4;
+constexpr int64_t kRedGrid = 8192;
+
+__device__ __forceinline__ double red_combine(double a, double b, int red) {
+    if (red == ATX_RED_NANCOUNT) return a + b;
+    if (a != a || b != b) return NAN;  // np.min / np.max propagate NaN
+    if (red == ATX_RED_MIN) return b < a ? b : a;
+    return b > a ? b : a;
+}
+
 template <typename T>
 __global__ void __launch_bounds__(kBlock)
 reduce_kernel(const T* __restrict__ x, int64_t n_rows, int64_t row_len, int64_t pitch, int red, double* result) {
-    double acc = red == ATX_RED_MIN ? INFINITY : (red == ATX_RED_MAX ? -INFINITY : 0.0);
-    bool saw_nan = false;
+    const double identity = red == ATX_RED_MIN ? INFINITY : (red == ATX_RED_MAX ? -INFINITY : 0.0);
+    double acc = identity;
     // rows of `row_len` elements `pitch` apart; (row, col) advances by the grid stride without a division per element
     const int64_t first = (int64_t)blockIdx.x * kBlock + threadIdx.x, stride = (int64_t)gridDim.x * kBlock;
     const int64_t d_row = stride / row_len, d_col = stride - d_row * row_len;
     int64_t row = first / row_len, col = first - row * row_len;
-    for (; row < n_rows; row += d_row, col += d_col) {
-        if (col >= row_len) {
-            col -= row_len;
-            if (++row >= n_rows) break;
-        }
-        const double v = (double)x[row * pitch + col];
-        if (v != v) {
-            saw_nan = true;
-            if (red == ATX_RED_NANCOUNT) acc += 1.0;
-        } else if (red == ATX_RED_MIN) {
-            acc = v < acc ? v : acc;
-        } else if (red == ATX_RED_MAX) {
-            acc = v > acc ? v : acc;
-        }
-    }
-    if (red != ATX_RED_NANCOUNT && saw_nan) acc = NAN;
-    // 64-lane shuffle reduction
+    while (row < n_rows) {
+        T v[kRedUnroll];
+        bool ok[kRedUnroll];
 #pragma unroll
-    for (int off = kWave / 2; off > 0; off >>= 1) {
-        const double o = __shfl_down(acc, off, kWave);
-        if (red == ATX_RED_NANCOUNT) acc += o;
-        else if (o != o || acc != acc) acc = NAN;
-        else if (red == ATX_RED_MIN) acc = o < acc ? o : acc;
-        else acc = o > acc ? o : acc;
+        for (int u = 0; u < kRedUnroll; ++u) {
+            ok[u] = row < n_rows;
+            v[u] = ok[u] ? x[row * pitch + col] : T(0);
+            row += d_row;
+            col += d_col;
+            if (col >= row_len) {
+                col -= row_len;
+                ++row;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < kRedUnroll; ++u) {
+            if (!ok[u]) continue;
+            const double d = (double)v[u];
+            if (red == ATX_RED_NANCOUNT) acc += (d != d) ? 1.0 : 0.0;
+            else acc = red_combine(acc, d, red);
+        }
     }
-    if ((threadIdx.x & (kWave - 1)) == 0) {
+#pragma unroll
+    for (int off = kWave / 2; off > 0; off >>= 1) acc = red_combine(acc, __shfl_down(acc, off, kWave), red);
+    __shared__ double partial[kBlock / kWave];
+    if ((threadIdx.x & (kWave - 1)) == 0) partial[threadIdx.x / kWave] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double total = partial[0];
+        for (int w = 1; w < kBlock / kWave; ++w) total = red_combine(total, partial[w], red);
         if (red == ATX_RED_NANCOUNT) {
-            if (acc != 0.0) atomicAdd(result, acc);
+            if (total != 0.0) atomicAdd(result, total);
         } else {
-            atomic_minmax(result, acc, red == ATX_RED_MAX);
+            atomic_minmax(result, total, red == ATX_RED_MAX);
         }
     }
 }
@@ -468,7 +483,7 @@ static int pointwise_typed(const void* x_, void* y_, int64_t n_pts, int n_lev, i
     } else {
         ATX_REQUIRE(n_lev <= 65535, ATX_ENOTIMPL, "pointwise: n_lev=%d exceeds grid.y", n_lev);
         unsigned gx = grid_for((n_pts + VEC - 1) / VEC);
-        // keep the whole grid near 8 workgroups per CU
+        // grid.x * n_lev workgroups in all: about kStreamGrid
         const unsigned cap = (unsigned)((kMaxGrid + n_lev - 1) / n_lev);
         if (gx > cap) gx = cap < 1 ? 1 : cap;
         if (vec_ok) {
@@ -530,7 +545,8 @@ extern "C" int atx_mask_count(const uint8_t* mask, int64_t n, int64_t* count, vo
     int st = hip_status(hipMemsetAsync(count, 0, sizeof(int64_t), s), "atx_mask_count memset");
     if (st != ATX_OK) return st;
     if (n == 0) return ATX_OK;
-    hipLaunchKernelGGL(mask_count_kernel, dim3(grid_for(n)), dim3(kBlock), 0, s, mask, n, reinterpret_cast<unsigned long long*>(count));
+    const unsigned count_grid = grid_for(n) > 2048u ? 2048u : grid_for(n);  // one atomic per wave on one address: keep them few
+    hipLaunchKernelGGL(mask_count_kernel, dim3(count_grid), dim3(kBlock), 0, s, mask, n, reinterpret_cast<unsigned long long*>(count));
     ATX_LAUNCH_CHECK("mask_count");
     return ATX_OK;
 }
@@ -571,7 +587,8 @@ static int reduce_rows(const void* x, int64_t n_rows, int64_t row_len, int64_t p
     hipLaunchKernelGGL(reduce_init_kernel, dim3(1), dim3(1), 0, s, result, red);
     ATX_LAUNCH_CHECK("reduce_init");
     if (n_rows == 0 || row_len == 0) return ATX_OK;
-    const unsigned grid = grid_for(n_rows * row_len);
+    int64_t blocks = (n_rows * row_len + (int64_t)kBlock * kRedUnroll - 1) / ((int64_t)kBlock * kRedUnroll);
+    const unsigned grid = (unsigned)(blocks > kRedGrid ? kRedGrid : (blocks < 1 ? 1 : blocks));
     if (dtype == ATX_F32)
         hipLaunchKernelGGL(reduce_kernel<float>, dim3(grid), dim3(kBlock), 0, s, static_cast<const float*>(x), n_rows, row_len, pitch, red, result);
     else

@@ -746,7 +746,7 @@ extern "C" int atx_check_indices(const int32_t* idx, int64_t n, int64_t n_src, i
     if (st != ATX_OK) return st;
     if (n == 0) return ATX_OK;
     int64_t blocks = (n + kBlock - 1) / kBlock;
-    if (blocks > 2048) blocks = 2048;
+    if (blocks > kStreamGrid) blocks = kStreamGrid;
     hipLaunchKernelGGL(check_indices_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, s, idx, n, n_src,
                        reinterpret_cast<unsigned long long*>(n_bad));
     ATX_LAUNCH_CHECK("check_indices");

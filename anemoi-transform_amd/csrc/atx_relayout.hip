@@ -140,7 +140,7 @@ static int relayout_typed(const void* src_, void* dst_, int64_t n_pts, int n_lev
         const int64_t n_rows = src_layout == ATX_COLUMNS ? n_pts : n_lev;
         const int64_t row_len = src_layout == ATX_COLUMNS ? n_lev : n_pts;
         int64_t blocks = (n_rows * row_len + kBlock - 1) / kBlock;
-        if (blocks > 2048) blocks = 2048;
+        if (blocks > kStreamGrid) blocks = kStreamGrid;
         hipLaunchKernelGGL(pitched_copy_kernel<T>, dim3((unsigned)blocks), dim3(kBlock), 0, st, src, dst, n_rows, row_len, sp, dp);
         ATX_LAUNCH_CHECK("pitched_copy");
         return ATX_OK;
@@ -237,7 +237,7 @@ static int select_typed(const void* src_, void* dst_, const int32_t* level_map, 
             hipLaunchKernelGGL(select_cols_kernel<T>, dim3(gx), dim3(kBlock), 0, st, src, dst, map, j0, nj, n_pts, sp, dp, tp);
         } else {
             int64_t gx = (n_pts + (int64_t)kBlock * 8 - 1) / ((int64_t)kBlock * 8);
-            gx = gx < 1 ? 1 : (gx > 4096 ? 4096 : gx);
+            gx = gx < 1 ? 1 : (gx > kStreamGrid ? kStreamGrid : gx);
             hipLaunchKernelGGL(select_fields_kernel<T>, dim3((unsigned)gx, (unsigned)nj), dim3(kBlock), 0, st, src, dst, map, j0, n_pts, sp, dp);
         }
         ATX_LAUNCH_CHECK("select_levels");
