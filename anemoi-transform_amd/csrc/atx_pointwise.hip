@@ -167,6 +167,60 @@ pointwise_cols_flat_kernel(const T* __restrict__ x, T* __restrict__ y, int64_t n
     }
 }
 
+// The same stacks with the per-vector operator table GIVEN (vec_prog, built once on the host by atx_vector_program): no
+// shared memory, no barrier, no loop — one 16-byte vector per lane and one workgroup per 4 KB, the launch shape that
+// streams fastest on MI355X (a plain y = a*x + b over 3.7 GB: 6.17 TB/s in this shape, 5.8 TB/s with 2-8 vectors per
+// lane and / or a grid-stride loop — tools/experiments/stream_shapes.hip).  A lane fetches the operators of its column
+// for all stages from the table (L1 / L2 resident: n_stage * C * 24 B) before its data arrives.
+template <typename T, int VEC>
+__global__ void __launch_bounds__(kBlock)
+pointwise_cols_table_kernel(const T* __restrict__ x, T* __restrict__ y, int64_t n_vec, int n_lev, int C,
+                            const atx_level_op* __restrict__ prog, const atx_level_op* __restrict__ vec_prog, int n_stage,
+                            const uint8_t* __restrict__ point_mask, int in_place) {
+    using V = Pack<T, VEC>;
+    const int64_t vi = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (vi >= n_vec) return;
+    int64_t row;
+    int c;
+    if (n_vec <= 0xffffffffll) {  // uniform: 32-bit division
+        const unsigned r = (unsigned)vi / (unsigned)C;
+        row = r;
+        c = (int)((unsigned)vi - r * (unsigned)C);
+    } else {
+        row = vi / C;
+        c = (int)(vi - row * C);
+    }
+    LevelOp<T> ops[8];
+    bool act = false, need_mask = false;
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+        if (s < n_stage) {
+            ops[s] = load_level_op<T>(vec_prog, (int64_t)s * C + c);
+            act = act || ops[s].op != ATX_OP_COPY || ops[s].use_mask != 0;
+            need_mask = need_mask || ops[s].use_mask != 0;
+        }
+    }
+    if (!act && in_place) return;  // untouched levels of an in-place call: nothing to move
+    V v = pw_load<T, VEC>(x + vi * VEC);
+    if (act) {
+        const bool masked = (need_mask && point_mask) ? (point_mask[row] != 0) : false;
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            if (s >= n_stage) break;
+            if (ops[s].op != kOpMixed) {
+                apply_level_op_vec<T, VEC>(ops[s], v, masked);
+            } else {
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) {
+                    const int l = c * VEC + e;
+                    if (l < n_lev) v.v[e] = apply_level_op(load_level_op<T>(prog, (int64_t)s * n_lev + l), v.v[e], masked);
+                }
+            }
+        }
+    }
+    pw_store<T, VEC>(y + vi * VEC, v);
+}
+
 // ATX_FIELDS: grid.y = level (operator uniform per workgroup), lanes along points.
 template <typename T, int VEC>
 __global__ void __launch_bounds__(kBlock)
@@ -445,7 +499,7 @@ static unsigned grid_for(int64_t items) {
 
 template <typename T>
 static int pointwise_typed(const void* x_, void* y_, int64_t n_pts, int n_lev, int64_t xp, int64_t yp, int layout,
-                           const atx_level_op* prog, int n_stage, const uint8_t* mask, hipStream_t st) {
+                           const atx_level_op* prog, const atx_level_op* vec_prog, int n_stage, const uint8_t* mask, hipStream_t st) {
     const T* x = static_cast<const T*>(x_);
     T* y = static_cast<T*>(y_);
     const int in_place = (x_ == y_ && xp == yp) ? 1 : 0;
@@ -462,6 +516,15 @@ static int pointwise_typed(const void* x_, void* y_, int64_t n_pts, int n_lev, i
 #endif
         if (ATX_PW_FLAT && wide && xp == (int64_t)C * VEC && yp == xp) {  // one contiguous run of vectors: line-aligned chunks
             const int64_t n_vec = n_pts * C;
+            // measured (137 levels of O1280): one stage, f32, out of place: table kernel 1.21 ms (6.1 TB/s) vs 1.31 ms for the chunked
+            // kernel below.  With a point mask (a byte gather per vector), in f64, with several stages (24 B of operators per stage
+            // and vector: 3 stages 1.88 vs 1.38 ms) or in place with few active levels the chunked kernel is as fast or faster.
+            if (vec_prog && !mask && sizeof(T) == 4 && n_stage == 1 && !in_place && (n_vec + kBlock - 1) / kBlock <= 0x7fffffffll) {
+                hipLaunchKernelGGL((pointwise_cols_table_kernel<T, VEC>), dim3((unsigned)((n_vec + kBlock - 1) / kBlock)), dim3(kBlock), 0, st,
+                                   x, y, n_vec, n_lev, C, prog, vec_prog, n_stage, mask, in_place);
+                ATX_LAUNCH_CHECK("pointwise_stack");
+                return ATX_OK;
+            }
             int64_t blocks = (n_vec + (int64_t)kBlock * kPwUnroll - 1) / ((int64_t)kBlock * kPwUnroll);
             if (blocks > kMaxGrid) blocks = kMaxGrid;
             const size_t lds_flat = lds + (size_t)C;
@@ -503,8 +566,8 @@ static int pointwise_typed(const void* x_, void* y_, int64_t n_pts, int n_lev, i
 using namespace atx;
 
 extern "C" int atx_pointwise_stack(const void* x, void* y, int64_t n_pts, int64_t n_lev, int64_t x_pitch,
-                                   int64_t y_pitch, int dtype, int layout, const atx_level_op* prog, int32_t n_stage,
-                                   const uint8_t* point_mask, void* stream) {
+                                   int64_t y_pitch, int dtype, int layout, const atx_level_op* prog,
+                                   const atx_level_op* vec_prog, int32_t n_stage, const uint8_t* point_mask, void* stream) {
     ATX_REQUIRE(x && y && prog, ATX_EINVAL, "atx_pointwise_stack: null pointer");
     ATX_REQUIRE(dtype == ATX_F32 || dtype == ATX_F64, ATX_EINVAL, "atx_pointwise_stack: bad dtype %d", dtype);
     ATX_REQUIRE(layout == ATX_COLUMNS || layout == ATX_FIELDS, ATX_EINVAL, "atx_pointwise_stack: bad layout %d", layout);
@@ -516,8 +579,8 @@ extern "C" int atx_pointwise_stack(const void* x, void* y, int64_t n_pts, int64_
                 (long long)x_pitch, (long long)y_pitch, (long long)need);
     if (n_pts == 0) return ATX_OK;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (dtype == ATX_F32) return pointwise_typed<float>(x, y, n_pts, (int)n_lev, x_pitch, y_pitch, layout, prog, n_stage, point_mask, s);
-    return pointwise_typed<double>(x, y, n_pts, (int)n_lev, x_pitch, y_pitch, layout, prog, n_stage, point_mask, s);
+    if (dtype == ATX_F32) return pointwise_typed<float>(x, y, n_pts, (int)n_lev, x_pitch, y_pitch, layout, prog, vec_prog, n_stage, point_mask, s);
+    return pointwise_typed<double>(x, y, n_pts, (int)n_lev, x_pitch, y_pitch, layout, prog, vec_prog, n_stage, point_mask, s);
 }
 
 extern "C" int atx_mask_build(const void* m, int64_t m_stride, uint8_t* mask, int64_t n, int cmp, double threshold,

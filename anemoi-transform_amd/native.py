@@ -72,7 +72,7 @@ SIGNATURES: dict[str, tuple[Any, list[Any]]] = {
     "atx_check_indices": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_void_p]),
     "atx_pointwise_stack": (
         c_int,
-        [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int64, c_int, c_int, c_void_p, c_int32, c_void_p, c_void_p],
+        [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int64, c_int, c_int, c_void_p, c_void_p, c_int32, c_void_p, c_void_p],
     ),
     "atx_combine_stack": (
         c_int,
@@ -87,6 +87,7 @@ SIGNATURES: dict[str, tuple[Any, list[Any]]] = {
     "atx_knn_build": (c_int, [c_void_p, c_int64, c_void_p, c_size_t, c_void_p]),
     "atx_knn_query": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int32, c_void_p, c_void_p, c_void_p]),
     "atx_cutout_inside": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int32, c_void_p, c_void_p]),
+    "atx_vector_program": (c_int64, [c_void_p, c_int32, c_int64, c_int, c_void_p]),
     "atx_reduce": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_int, c_void_p]),
     "atx_relayout": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int64, c_int, c_int, c_int, c_void_p]),
     "atx_reduce_stack": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_int, c_void_p, c_int, c_int, c_void_p]),
@@ -240,15 +241,27 @@ def level_program(stages: list[list[tuple[int, int, float, float]]], device) -> 
         assert len(stage) == n_lev
         for l, (op, use_mask, p0, p1) in enumerate(stage):
             host[s * n_lev + l] = (op, use_mask, p0, p1)
-    raw = torch.from_numpy(host.view(np.uint8).copy())
-    return raw.to(device)
+    raw = torch.from_numpy(host.view(np.uint8).copy()).to(device)
+    # per-vector forms (atx_vector_program, host side) ride along: kernels given them need no per-workgroup set-up
+    raw.vec_prog = {}
+    if raw.is_cuda:
+        lib = load()
+        for tdtype, code in ((torch.float32, F32), (torch.float64, F64)):
+            n_entries = lib.atx_vector_program(host.ctypes.data, n_stage, n_lev, code, None)
+            table = np.zeros(n_entries, dtype=LEVEL_OP_DTYPE)
+            got = lib.atx_vector_program(host.ctypes.data, n_stage, n_lev, code, table.ctypes.data)
+            if got != n_entries:
+                raise AtxError(f"atx_vector_program: {lib.atx_last_error().decode()}")
+            raw.vec_prog[tdtype] = torch.from_numpy(table.view(np.uint8).copy()).to(device)
+    return raw
 
 
 def pointwise_stack(x, y, *, n_pts, n_lev, x_pitch, y_pitch, layout, prog, n_stage, point_mask=None) -> None:
     assert x.dtype == y.dtype
+    vec = getattr(prog, "vec_prog", {}).get(x.dtype)
     _call(
         "atx_pointwise_stack", _ptr(x), _ptr(y), n_pts, n_lev, x_pitch, y_pitch, dtype_code(x.dtype), layout,
-        _ptr(prog), n_stage, _ptr(point_mask), _stream(),
+        _ptr(prog), _ptr(vec), n_stage, _ptr(point_mask), _stream(),
     )
 
 

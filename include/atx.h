@@ -184,8 +184,17 @@ int atx_check_indices(const int32_t* idx, int64_t n, int64_t n_src, int64_t* n_b
  */
 int atx_pointwise_stack(const void* x, void* y, int64_t n_pts, int64_t n_lev,
                         int64_t x_pitch, int64_t y_pitch, int dtype, int layout,
-                        const atx_level_op* prog, int32_t n_stage, const uint8_t* point_mask,
-                        void* stream);
+                        const atx_level_op* prog, const atx_level_op* vec_prog, int32_t n_stage,
+                        const uint8_t* point_mask, void* stream);
+
+/* Per-vector form of a per-level program, computed on the HOST (no device access): out[s*C + c] is the operator shared
+ * by the levels c*V .. c*V+V-1 of stage s (V = 16 bytes / sizeof(dtype), C = ceil(n_lev / V); padding levels join any
+ * operator), with op = ATX_OP_MIXED (and use_mask = whether any of them uses the mask) where they differ once the parameters are rounded to dtype.  Returns the number of
+ * entries n_stage*C (out == NULL: only that), negative on error.  Uploaded and passed as `vec_prog` (of the stack's
+ * dtype) it lets atx_pointwise_stack run without any per-workgroup set-up — one 16-byte vector per lane, the launch
+ * shape that streams fastest on MI355X; vec_prog == NULL is always valid (the kernels then derive the table themselves). */
+#define ATX_OP_MIXED (-1)
+int64_t atx_vector_program(const atx_level_op* prog, int32_t n_stage, int64_t n_lev, int dtype, atx_level_op* out);
 
 /* ---- multi-input per-point transforms ------------------------------------------ */
 /* Operators of the reference's MatchingFieldsFilter family (R: filters/fields/matching.py:90-311):

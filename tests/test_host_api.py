@@ -413,7 +413,7 @@ def test_abi_argument_validation_without_a_gpu():
     assert lib.atx_regrid_ell(one, one, one, one, 8, 8, 99, 4, 4, 4, 0, 0, 0, None, 0, None, None) == native.EINVAL
     assert lib.atx_regrid_ell(one, one, one, None, 8, 8, 1, 4, 4, 4, 7, 0, 0, None, 0, None, None) == native.EINVAL
     assert lib.atx_regrid_ell(one, one, one, None, 8, 8, 1, 4, 4, 4, 0, 0, 1, None, 0, None, None) == native.EINVAL  # padded needs weights
-    assert lib.atx_pointwise_stack(one, one, 8, 4, 4, 4, 0, 0, one, 0, None, None) == native.EINVAL
+    assert lib.atx_pointwise_stack(one, one, 8, 4, 4, 4, 0, 0, one, None, 0, None, None) == native.EINVAL
     assert lib.atx_mask_build(one, 1, one, 8, 99, 0.0, 0, None) == native.EINVAL
     assert lib.atx_relayout(one, one, 8, 4, 4, 8, 0, 1, 0, None) == native.EINVAL  # in place
     assert lib.atx_mask_to_index_workspace(4096 * 3) >= 16
@@ -481,3 +481,24 @@ def test_derived_field_forwards_unknown_attributes(caplog):
     with pytest.raises(AttributeError):
         derived.no_such_attribute
     assert derived.clone(param="v").metadata("param") == "v"
+
+
+def test_vector_program_host_helper():
+    """atx_vector_program (host only): per-vector view of a per-level program; levels that differ mark the vector MIXED,
+    parameters are compared as the kernel will see them (rounded to the stack's dtype), padding levels join any operator."""
+    lib = native.load()
+    ops = [(native.OP_AFFINE, 0, 2.0, 1.0)] * 5 + [(native.OP_MUL, 0, 9.80665, 0.0)] * 3 + [(native.OP_AFFINE, 1, 2.0, 1.0)]
+    ops[3] = (native.OP_AFFINE, 0, 2.0 + 1e-12, 1.0)  # equal to 2.0 in float32, different in float64
+    host = np.zeros(len(ops), dtype=native.LEVEL_OP_DTYPE)
+    for i, o in enumerate(ops):
+        host[i] = o
+    for code, vec, want in ((native.F32, 4, [native.OP_AFFINE, -1, native.OP_AFFINE]),
+                            (native.F64, 2, [native.OP_AFFINE, -1, -1, native.OP_MUL, native.OP_AFFINE])):
+        n = lib.atx_vector_program(host.ctypes.data, 1, len(ops), code, None)
+        assert n == (len(ops) + vec - 1) // vec == len(want)
+        out = np.zeros(n, dtype=native.LEVEL_OP_DTYPE)
+        assert lib.atx_vector_program(host.ctypes.data, 1, len(ops), code, out.ctypes.data) == n
+        assert out["op"].tolist() == want
+        assert out["use_mask"][-1] == 1  # the last (partial) vector holds only level 8
+    assert lib.atx_vector_program(None, 1, 4, native.F32, None) == native.EINVAL
+    assert lib.atx_vector_program(host.ctypes.data, 9, 1, native.F32, None) == native.EINVAL
