@@ -27,10 +27,11 @@ from .stack import Stack
 
 
 # Cost of one target column relative to one first-touched source column in ``GatherPlan.bounds``.  By bytes alone the stored
-# column plus its k table entries are 1.06 column-equivalents at 137 f32 levels; least-squares fits of measured per-shard
-# times on MI355X (O1280 -> 0.25 degree, 4 and 8 shards; tools/shard_efficiency.py) give 1.1 for one launch per stack and
-# 1.4 for the batched launch the multi-GPU step uses (polar shards: many targets on few source columns).
-TARGET_COST = 1.4
+# column plus its k table entries are 1.06 column-equivalents at 137 f32 levels, but stores stream while gathered reads do not:
+# timing every shard of the 4- and 8-way cut on MI355X (O1280 -> 0.25 degree, tools/shard_efficiency.py <world> <cost>,
+# batched launch of the direct kernel) the slowest rank is fastest for weights of 0.5-0.7 (0.448-0.451 ms at 8 shards against
+# 0.455 at 1.1-1.4 and 0.57 for equal counts).
+TARGET_COST = 0.6
 
 
 class GatherPlan:

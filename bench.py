@@ -272,7 +272,7 @@ def main():
         },
         "roofline": {
             "bound": "hbm",
-            "kernel": "regrid_cols_ell_kernel" if layout == COLUMNS else "regrid_fields_ell_kernel",
+            "kernel": "regrid_cols_ell_direct_kernel" if layout == COLUMNS else "regrid_fields_ell_kernel",
             "achieved": achieved,
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",

@@ -18,6 +18,11 @@ n_src, n_tgt, L = len(src['latitudes']), len(tgt['latitudes']), 137
 idx, w = interp.knn_inverse_distance(src, tgt, k=4, device=True)
 plan = GatherPlan(n_src, n_tgt, index=idx, weights=w)
 world = int(sys.argv[1]) if len(sys.argv) > 1 else 8
+if len(sys.argv) > 2:  # try another weight of the shard cost model
+    from anemoi_transform_amd import gather as _gather
+
+    _gather.TARGET_COST = float(sys.argv[2])
+    print('TARGET_COST =', _gather.TARGET_COST)
 stacks = [bench.synth_stack(src, L, torch.float32, dev, s, COLUMNS) for s in range(world)]
 for name, bounds, batched in (("equal-count", [(n_tgt * r) // world for r in range(world + 1)], False),
                               ("traffic-balanced", plan.bounds(world), False),
