@@ -91,3 +91,28 @@ extern "C" int64_t atx_vector_program(const atx_level_op* prog, int32_t n_stage,
     }
     return (int64_t)n_stage * C;
 }
+
+namespace atx {
+struct alignas(16) Bytes16 {
+    uint32_t w[4];
+};
+__global__ void __launch_bounds__(kBlock) stream_copy_kernel(const Bytes16* __restrict__ src, Bytes16* __restrict__ dst, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i < n) dst[i] = src[i];
+}
+}  // namespace atx
+
+extern "C" int atx_stream_copy(const void* src, void* dst, int64_t n_bytes, void* stream) {
+    using namespace atx;
+    ATX_REQUIRE(src && dst, ATX_EINVAL, "atx_stream_copy: null pointer");
+    ATX_REQUIRE(n_bytes >= 0 && n_bytes % 16 == 0, ATX_EINVAL, "atx_stream_copy: n_bytes=%lld is not a multiple of 16", (long long)n_bytes);
+    ATX_REQUIRE(aligned16(src) && aligned16(dst), ATX_EALIGN, "atx_stream_copy: pointers must be 16-byte aligned");
+    const int64_t n = n_bytes / 16;
+    if (n == 0) return ATX_OK;
+    const int64_t blocks = (n + kBlock - 1) / kBlock;
+    ATX_REQUIRE(blocks <= 0x7fffffffll, ATX_ENOTIMPL, "atx_stream_copy: %lld bytes exceed one launch", (long long)n_bytes);
+    hipLaunchKernelGGL(stream_copy_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, static_cast<hipStream_t>(stream),
+                       static_cast<const Bytes16*>(src), static_cast<Bytes16*>(dst), n);
+    ATX_LAUNCH_CHECK("stream_copy");
+    return ATX_OK;
+}

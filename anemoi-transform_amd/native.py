@@ -87,6 +87,7 @@ SIGNATURES: dict[str, tuple[Any, list[Any]]] = {
     "atx_knn_build": (c_int, [c_void_p, c_int64, c_void_p, c_size_t, c_void_p]),
     "atx_knn_query": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int32, c_void_p, c_void_p, c_void_p]),
     "atx_cutout_inside": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int32, c_void_p, c_void_p]),
+    "atx_stream_copy": (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),
     "atx_vector_program": (c_int64, [c_void_p, c_int32, c_int64, c_int, c_void_p]),
     "atx_reduce": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_int, c_void_p]),
     "atx_relayout": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int64, c_int, c_int, c_int, c_void_p]),
@@ -353,6 +354,13 @@ def select_levels(src, dst, level_map, *, n_pts, n_src_lev, src_pitch, dst_pitch
     lm = (ctypes.c_int32 * len(level_map))(*[int(l) for l in level_map])
     _call("atx_select_levels", _ptr(src), _ptr(dst), ctypes.cast(lm, c_void_p), len(level_map), n_pts, n_src_lev,
           src_pitch, dst_pitch, dtype_code(src.dtype), layout, _stream())
+
+
+def stream_copy(src, dst) -> None:
+    """``atx_stream_copy``: the library's fixed reference streaming copy (calibration / ceiling measurements)."""
+    n_bytes = src.numel() * src.element_size()
+    assert dst.numel() * dst.element_size() == n_bytes and src.is_contiguous() and dst.is_contiguous()
+    _call("atx_stream_copy", _ptr(src), _ptr(dst), n_bytes, _stream())
 
 
 def relayout(src, dst, *, n_pts, n_lev, src_pitch, dst_pitch, src_layout, dst_layout) -> None:

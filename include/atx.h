@@ -279,6 +279,13 @@ int atx_knn_query(const void* workspace, int64_t n_src, const double* tgt_xyz, i
 int atx_cutout_inside(const double* global_xyz, int64_t n, const double* lam_xyz, int64_t n_lam,
                       const int32_t* neighbours, int32_t k, uint8_t* inside, void* stream);
 
+/* ---- measurement aid ------------------------------------------------------------ */
+/* dst[0..n_bytes) = src[0..n_bytes): a plain streaming copy, one 16-byte vector per lane, one workgroup per 4 KB, never
+ * tuned again.  It exists so that profiling has a FIXED kernel with a known byte count in the library's access width:
+ * tools/pmc_probe.py calibrates the FETCH_SIZE / WRITE_SIZE counters on it, tools/hbm_ceiling.py reports it as the
+ * device's practical 1 read : 1 write rate.  n_bytes a multiple of 16, both pointers 16-byte aligned. */
+int atx_stream_copy(const void* src, void* dst, int64_t n_bytes, void* stream);
+
 /* ---- layout --------------------------------------------------------------- */
 /* dst[p, l] = src[p, l] between layouts / pitches (LDS-tiled transpose when the
  * layouts differ, strided copy when they agree).  No reference counterpart:

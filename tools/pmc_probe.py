@@ -3,9 +3,8 @@
 
 Runs, on one GPU, with the bench's O1280 -> 0.25 degree k=4 x137 inputs:
   1. a CALIBRATION launch with a known byte count in the same access width as the
-     regrid kernel (16 B per lane): `atx_pointwise_stack` copying a field-major stack of
-     the same size out of place (aligned contiguous rows) -> reads n_src*n_lev*B bytes, writes the same;
-  2. `--launches` regrid launches (`regrid_cols_ell_kernel`).
+     regrid kernel (16 B per lane): `atx_stream_copy` over n_src*n_lev*B bytes (reads them, writes the same);
+  2. `--launches` regrid launches (`regrid_cols_ell_direct_kernel`).
 The counters of (1) give the correction factor MI355X_MICROARCH.md §HBM asks for
 (FETCH_SIZE reads ~1/2 of a wide coalesced stream on gfx950); tools/pmc_summarize.py
 applies it to (2) and writes profiles/traffic.json.
@@ -60,20 +59,16 @@ def main():
     out = Stack.empty(n_tgt, args.levels, tdtype, dev, COLUMNS)
     torch.cuda.synchronize()
 
-    # 1. calibration: a copy with a known byte count in the regrid kernel's access width (16 B per lane) over perfectly
-    #    aligned, contiguous rows — the field-major per-point kernel on a [levels, n_src] stack.  (The column-stack
-    #    per-point kernel is launched too: its workgroup chunks are not line aligned, so its own counters show a few %
-    #    of boundary-line refetch; it is reported, not used for calibration.)
-    from anemoi_transform_amd.stack import FIELDS
-
-    flat_src = Stack.empty(n_src, args.levels, tdtype, dev, FIELDS, zero=True)
-    flat_dst = Stack.empty(n_src, args.levels, tdtype, dev, FIELDS)
-    prog = native.level_program([[(native.OP_COPY, 0, 0.0, 0.0)] * args.levels], dev)
-    native.pointwise_stack(flat_src.data, flat_dst.data, n_pts=n_src, n_lev=args.levels, x_pitch=flat_src.pitch, y_pitch=flat_dst.pitch,
-                           layout=FIELDS, prog=prog, n_stage=1)
+    # 1. calibration: the library's fixed streaming copy (atx_stream_copy: one 16-byte vector per lane, aligned, known bytes) —
+    #    the regrid kernel's access width.  The column-stack per-point kernel is launched too and reported with the same
+    #    correction (it once showed a few % of boundary-line refetch that way).
+    flat_src = torch.zeros(n_src * args.levels, dtype=tdtype, device=dev)
+    flat_dst = torch.empty_like(flat_src)
+    native.stream_copy(flat_src, flat_dst)
     torch.cuda.synchronize()
     calib_bytes = n_src * args.levels * itemsize
     del flat_src, flat_dst
+    prog = native.level_program([[(native.OP_COPY, 0, 0.0, 0.0)] * args.levels], dev)
     copy = src.new_like()
     native.pointwise_stack(src.data, copy.data, n_pts=n_src, n_lev=args.levels, x_pitch=src.pitch, y_pitch=copy.pitch,
                            layout=COLUMNS, prog=prog, n_stage=1)
@@ -89,11 +84,11 @@ def main():
 
     meta = {
         "config": f"o1280->0.25 k={args.k} L={args.levels} {args.dtype} columns gpus=1",
-        "calibration_kernel": "pointwise_fields_kernel",
+        "calibration_kernel": "stream_copy_kernel",
         "cols_copy_bytes": cols_copy_bytes,
         "calibration_read_bytes": calib_bytes,
         "calibration_write_bytes": calib_bytes,
-        "regrid_kernel": "regrid_cols_ell_kernel",
+        "regrid_kernel": "regrid_cols_ell_direct_kernel",
         "regrid_launches": args.launches,
         "algorithmic_bytes_per_launch": bench.algorithmic_bytes(args.levels, itemsize, int(np.unique(idx64).size), n_tgt, args.k),
     }

@@ -29,7 +29,8 @@ def counters(directory: str, counter: str) -> dict[str, list[float]]:
                 if row["Counter_Name"] != counter:
                     continue
                 name = row["Kernel_Name"]
-                for key in ("pointwise_cols_kernel", "pointwise_fields_kernel", "regrid_cols_ell_kernel", "regrid_fields_ell_kernel"):
+                for key in ("stream_copy_kernel", "pointwise_cols_kernel", "pointwise_cols_flat_kernel", "pointwise_cols_table_kernel", "pointwise_fields_kernel",
+                            "regrid_cols_ell_direct_kernel", "regrid_cols_ell_kernel", "regrid_fields_ell_kernel"):
                     if key in name:
                         out.setdefault(key, []).append(float(row["Counter_Value"]))
     return out
@@ -76,11 +77,13 @@ def main():
         "algorithmic_bytes_per_launch": meta["algorithmic_bytes_per_launch"],
     }
     rec["traffic_over_algorithmic"] = rec["hbm_bytes_per_launch"] / rec["algorithmic_bytes_per_launch"]
-    if "pointwise_cols_kernel" in fetch and "cols_copy_bytes" in meta:  # the column-stack per-point copy, same correction
+    cols = next((k for k in ("pointwise_cols_table_kernel", "pointwise_cols_flat_kernel", "pointwise_cols_kernel") if k in fetch), None)
+    if cols and "cols_copy_bytes" in meta:  # the column-stack per-point copy, same correction
         rec["pointwise_cols_copy"] = {
+            "kernel": cols,
             "known_bytes_each_way": meta["cols_copy_bytes"],
-            "fetch_over_known": fetch["pointwise_cols_kernel"][0] * 1024 * read_corr / meta["cols_copy_bytes"],
-            "write_over_known": write["pointwise_cols_kernel"][0] * 1024 * write_corr / meta["cols_copy_bytes"],
+            "fetch_over_known": fetch[cols][0] * 1024 * read_corr / meta["cols_copy_bytes"],
+            "write_over_known": write[cols][0] * 1024 * write_corr / meta["cols_copy_bytes"],
         }
     table = {}
     if os.path.exists(args.out):
