@@ -71,16 +71,18 @@ __device__ __forceinline__ void combine_one(int op, int flags, const T* x, int n
 }
 
 // The stacks are contiguous runs of vectors (pitch is a multiple of the vector): a workgroup sweeps line-aligned chunks
-// of kBlock * U vectors, U = kCombUnroll independent loads per operand and lane in flight for up to 3 operands (the n-ary
-// sum keeps one: 8 operands x 4 vectors would not fit the register file).  Non-temporal stores measured no better.
-#ifndef ATX_COMB_UNROLL
-#define ATX_COMB_UNROLL 4  // measured on 137-level O1280 stacks: difference 2->1 f32 2.57 / 2.37 / 2.10 ms at 1 / 2 / 4
-#endif
+// of kBlock * U vectors, U independent loads per operand and lane in flight (comb_unroll below; the n-ary sum keeps one:
+// 8 operands x 4 vectors would not fit the register file).  Non-temporal stores measured no better.
+// Vectors per lane in flight and grid shape, measured on 137-level O1280 stacks (profiles/r01_kernel_bench.log):
+//   f32: 2 vectors per lane, one workgroup per chunk, no grid cap — difference 2->1 1.81 ms (4 per lane under a 65536-workgroup
+//        cap: 2.11 ms; 1 per lane uncapped: 1.78 ms but cos+sin 1->2 slower), snow_cover 2.66 -> 2.17 ms;
+//   f64: 4 vectors per lane under the 65536-workgroup cap — difference 3.63 ms (uncapped 1 / 2 per lane: 4.30 / 3.60 ms, the
+//        transcendental operators lose 10 % uncapped).
 #ifndef ATX_COMB_NT
 #define ATX_COMB_NT 0
 #endif
-constexpr int kCombUnroll = ATX_COMB_UNROLL;
-constexpr int comb_unroll(int nin) { return nin <= 3 ? kCombUnroll : 1; }
+constexpr int comb_unroll(int nin, int elem_bytes) { return nin > 3 ? 1 : (elem_bytes == 4 ? 2 : 4); }
+constexpr int64_t comb_grid_cap(int elem_bytes) { return elem_bytes == 4 ? 0x7fffffffll : kStreamGrid; }
 
 template <typename T, int N>
 __device__ __forceinline__ void comb_store(T* p, const Pack<T, N>& v) {
@@ -104,7 +106,7 @@ combine_kernel(CombArgs a, int op, int flags, int n_in, int n_out, int64_t n_row
     using V = Pack<T, VEC>;
     const int vec_per_row = (int)(pitch / VEC);  // pitch % VEC == 0 on this path (else VEC == 1)
     const int64_t total = n_rows * vec_per_row;
-    constexpr int U = comb_unroll(NIN);
+    constexpr int U = comb_unroll(NIN, (int)sizeof(T));
     constexpr int64_t kChunk = (int64_t)kBlock * U;
     const bool small_rows = vec_per_row < (1 << 20);  // columns layout: (row, col) from 32-bit arithmetic
     for (int64_t base = (int64_t)blockIdx.x * kChunk; base < total; base += (int64_t)gridDim.x * kChunk) {
@@ -164,9 +166,9 @@ static int combine_typed(const CombArgs& a, int op, int flags, int n_in, int n_o
     for (int k = 0; k < n_out; ++k) vec_ok = vec_ok && aligned16(a.out[k]);
     const int64_t n_rows = layout == ATX_COLUMNS ? n_pts : n_lev;
     const int64_t row_len = layout == ATX_COLUMNS ? n_lev : n_pts;
-    const int per_block = kBlock * comb_unroll(n_in <= 3 ? n_in : ATX_COMB_MAX_INPUTS);
+    const int per_block = kBlock * comb_unroll(n_in <= 3 ? n_in : ATX_COMB_MAX_INPUTS, (int)sizeof(T));
     int64_t blocks = (n_rows * (pitch / (vec_ok ? VEC : 1)) + per_block - 1) / per_block;
-    if (blocks > kStreamGrid) blocks = kStreamGrid;
+    if (blocks > comb_grid_cap((int)sizeof(T))) blocks = comb_grid_cap((int)sizeof(T));
     if (blocks < 1) blocks = 1;
 #define ATX_COMB_LAUNCH(V_, N_)                                                                                              \
     hipLaunchKernelGGL((combine_kernel<T, V_, N_>), dim3((unsigned)blocks), dim3(kBlock), 0, st, a, op, flags, n_in, n_out, n_rows, \
