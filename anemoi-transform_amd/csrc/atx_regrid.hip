@@ -252,10 +252,10 @@ regrid_cols_ell_kernel(EllBatch batch,
 // ---------------------------------------------------------------------------------
 // ATX_COLUMNS, fixed k, "direct" form: no shared memory, no barrier, no loop.  One (target, 16-byte vector) item per
 // lane; a lane reads its target's k indices / weights itself (the ~35 lanes of a target read the same words: one
-// request) and then the k source vectors.  The default for plain k <= 4 gathers, see the note at its launch site; the
-// tiled kernel above serves epilogues, padded rows and runtime k.
+// request) and then the k source vectors.  The default for k <= 4 gathers without an epilogue, see the note at its launch
+// site; the tiled kernel above serves epilogues and runtime k.
 // ---------------------------------------------------------------------------------
-template <typename T, int VEC, int K, bool WEIGHTED>
+template <typename T, int VEC, int K, bool WEIGHTED, bool PAD>
 __global__ void __launch_bounds__(kEllBlock)
 regrid_cols_ell_direct_kernel(EllBatch batch, const int32_t* __restrict__ idx, const T* __restrict__ w, int64_t n_items,
                               int C, int64_t src_pitch, int64_t out_pitch, unsigned n_blocks, int items_per_lane) {
@@ -277,15 +277,18 @@ regrid_cols_ell_direct_kernel(EllBatch batch, const int32_t* __restrict__ idx, c
         }
         V v[K];
 #pragma unroll
-        for (int j = 0; j < K; ++j) v[j] = load_src<T, VEC>(src + (int64_t)p[j] * src_pitch + (int64_t)c * VEC);
+        for (int j = 0; j < K; ++j)  // an absent entry of a padded row (index -1) loads column 0 and is skipped below
+            v[j] = load_src<T, VEC>(src + (int64_t)((PAD && p[j] < 0) ? 0 : p[j]) * src_pitch + (int64_t)c * VEC);
         V acc;
         if (WEIGHTED) {
 #pragma unroll
             for (int e = 0; e < VEC; ++e) acc.v[e] = T(0);
 #pragma unroll
             for (int j = 0; j < K; ++j) {
+                if (!PAD || p[j] >= 0) {
 #pragma unroll
-                for (int e = 0; e < VEC; ++e) acc.v[e] = acc.v[e] + wv[j] * v[j].v[e];
+                    for (int e = 0; e < VEC; ++e) acc.v[e] = acc.v[e] + wv[j] * v[j].v[e];
+                }
             }
         } else {
             acc = v[0];
@@ -516,17 +519,17 @@ static int launch_cols_ell(const EllBatch& batch, const int32_t* idx, const T* w
                            int n_lev, int64_t src_pitch, int64_t out_pitch, const atx_level_op* prog,
                            int n_stage, const uint8_t* tgt_mask, hipStream_t stream) {
     const int C = (n_lev + VEC - 1) / VEC;
-    // Plain fixed-k gathers (k <= 4, no epilogue, no padded rows) take the direct kernel.  Interleaved A/B on O1280 -> 0.25 deg,
+    // Fixed-k gathers with compile-time k (1-4; padded ragged rows 3-4) and no epilogue take the direct kernel.  Interleaved A/B on O1280 -> 0.25 deg,
     // 137 levels (profiles/r01_ab_direct_kernel.log): k=4 f32 0.4360 vs 0.4378 ms, k=1 f32 0.1926 vs 0.1992 ms, k=4 f64 0.8334 vs
     // 0.8343 ms; 1-60 levels equal or up to 15 % faster; 2 / 4 items per lane -4 % / -9 %.  Same bits, no tile heuristic to tune.
 #ifndef ATX_ELL_DIRECT
 #define ATX_ELL_DIRECT 1
 #endif
-    if constexpr (ATX_ELL_DIRECT && K > 0 && !PAD) {
+    if constexpr (ATX_ELL_DIRECT && K > 0) {
         if (!prog && g_tile_override <= 0) {  // atx_set_tuning(tile > 0) selects the tiled kernel below (A/B, tests)
             const int64_t n_items = n_tgt * C;
             const unsigned n_blocks = (unsigned)((n_items + kEllBlock - 1) / kEllBlock);
-            hipLaunchKernelGGL((regrid_cols_ell_direct_kernel<T, VEC, K, WEIGHTED>), dim3(n_blocks, batch.n), dim3(kEllBlock), 0, stream,
+            hipLaunchKernelGGL((regrid_cols_ell_direct_kernel<T, VEC, K, WEIGHTED, PAD>), dim3(n_blocks, batch.n), dim3(kEllBlock), 0, stream,
                                batch, idx, w, n_items, C, src_pitch, out_pitch, n_blocks, 1);
             ATX_LAUNCH_CHECK("regrid_cols_ell_direct");
             return ATX_OK;
