@@ -109,8 +109,9 @@ const char* atx_last_error(void);          /* host string, valid until the next 
 const char* atx_strerror(int code);        /* host string, static */
 /* Number of HIP devices visible, or a negative ATX_EHIP. */
 int atx_device_count(void);
-/* Tuning hook for benchmarks: targets per workgroup of the ATX_COLUMNS regrid
- * kernels (0 = built-in choice).  Process-wide; results never depend on it. */
+/* Tuning hook for benchmarks and tests: tile > 0 runs the ATX_COLUMNS regrid through the TILED kernels with that
+ * many targets per workgroup; 0 = built-in choice (the direct kernel where it applies, else the tile heuristic).
+ * Process-wide; results never depend on it. */
 int atx_set_tuning(int tile);
 
 /* ---- regrid: precomputed index(+weight) gather ---------------------------- */
