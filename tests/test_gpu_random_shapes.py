@@ -131,7 +131,10 @@ def test_random_regrid_cases(dev, seed):
             mask_dev[:n_tgt] = torch.from_numpy(mask_host.astype(np.uint8)).to(dev)
         kw = dict(n_src=n_src, n_tgt=n_tgt, n_lev=n_lev, src_pitch=src.pitch, out_pitch=out.pitch, layout=layout,
                   prog=prog, n_stage=len(ops) if with_prog else 0, tgt_mask=mask_dev)
-        what = f"seed {seed} case {case}: {kind} {np_dtype.__name__} layout {layout} L={n_lev} Ns={n_src} Nt={n_tgt} pitches {src.pitch}/{out.pitch} prog={with_prog}"
+        tile = int(rng.choice([0, 0, 8, 16, 40]))  # 0: built-in choice (direct kernel where it applies); > 0: the tiled kernels
+        native.set_tuning(tile)
+        what = (f"seed {seed} case {case}: {kind} {np_dtype.__name__} layout {layout} L={n_lev} Ns={n_src} Nt={n_tgt} "
+                f"pitches {src.pitch}/{out.pitch} prog={with_prog} tile={tile}")
         if kind == "gather":
             idx = rng.integers(0, n_src, n_tgt).astype(np.int32)
             native.regrid_ell(src.data, out.data, torch.from_numpy(idx).to(dev), None, k=1, **kw)
@@ -165,6 +168,7 @@ def test_random_regrid_cases(dev, seed):
             want = np.stack([oracle.csr_apply(data, indices, indptr, (n_tgt, n_src), f) for f in x])
         if with_prog:
             want = apply_program_host(want.astype(np_dtype), ops, mask_host)
+        native.set_tuning(0)
         check(out.values(), want.astype(np_dtype), what)
         assert out.padding_untouched(), what + " (padding of the output written)"
 
