@@ -56,3 +56,44 @@ def test_two_ranks_rehearsal_over_gloo(exchange):
     assert d["source_exchange"] == exchange and d["source_exchange_ms"] > 0
     assert d["end_to_end"]["value"] > 0 and d["end_to_end"]["value"] < d["value"]  # the exchange is inside that one
     assert "cpu_baseline" not in d  # rank 0 at N = 1 only
+
+
+def test_integration_md_ctypes_stub_runs(tmp_path):
+    """The reference-side binding shown in INTEGRATION.md is executable as written (only the library path is substituted)
+    and gives scipy's bits."""
+    import re
+
+    import numpy as np
+    import torch
+    from scipy.sparse import csr_array
+
+    from anemoi_transform_amd import interp, native
+    from anemoi_transform_amd.grids import lookup
+
+    text = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    blocks = re.findall(r"```python\n(.*?)```", text, flags=re.S)
+    stub = next(b for b in blocks if "class MIRMatrixHBM" in b)
+    stub = stub.replace('ctypes.CDLL("libatx.so")', f'ctypes.CDLL({native.lib_path()!r})')
+    scope: dict = {}
+    exec(compile(stub, "INTEGRATION.md", "exec"), scope)
+
+    src, tgt = lookup("o32"), lookup([5.0, 5.0])
+    idx, w = interp.knn_inverse_distance(src, tgt, k=4)
+    matrix = interp.ell_to_csr(idx, w, len(src["latitudes"]))
+    path = str(tmp_path / "m.npz")
+    np.savez(path, **matrix)
+    rng = np.random.default_rng(1)
+
+    class F:  # the two methods of an earthkit field the stub touches
+        def __init__(self, values):
+            self.values = values
+
+        def to_numpy(self, flatten=False):
+            return self.values
+
+    fields = [F(280 + rng.standard_normal(len(src["latitudes"]))) for _ in range(3)]
+    out = scope["MIRMatrixHBM"](path)(fields)
+    torch.cuda.synchronize()
+    m = csr_array((matrix["matrix_data"], matrix["matrix_indices"], matrix["matrix_indptr"]), shape=tuple(matrix["matrix_shape"]))
+    for f, got in zip(fields, out.cpu().numpy()):
+        assert np.array_equal(got, m @ f.values)
