@@ -6,21 +6,25 @@
 //   R: filters/fields/regrid.py:420  data[..., self.mask]
 // that the reference runs once per 2-D field in a Python loop (regrid.py:204-208).
 //
-// HBM-bound gather, no MFMA.  Design (DESIGN.md §kernels):
-//  * ATX_COLUMNS stacks: one target row is `C` 16-byte vectors; a workgroup owns a
-//    tile of consecutive targets, stages their neighbour indices / weights in LDS
-//    once (coalesced), then its 256 lanes sweep the flattened (target, vector)
-//    items — so consecutive lanes read consecutive 16 B of one source column and
-//    write consecutive 16 B of the output.  4 items per lane are in flight
-//    (up to 16 independent 16-byte loads).
-//  * tiles are dealt to XCDs in contiguous ranges (xcd_tile) so neighbouring
-//    targets that share source columns share an L2.
-//  * ATX_FIELDS stacks: lane = target, neighbour indices / weights live in
-//    registers and are reused for every level of the level chunk.
+// HBM-bound gather, no MFMA.  Design (DESIGN.md §3):
+//  * ATX_COLUMNS stacks, fixed k <= 4 without epilogue — the headline case — run the DIRECT kernel: one
+//    (target, 16-byte vector) item per lane, no shared memory, no barrier, no loop; consecutive lanes read consecutive
+//    16 B of one source column and write consecutive 16 B of the output.
+//  * epilogues and runtime k run the TILED kernel: a workgroup owns a tile of consecutive targets, stages their neighbour
+//    indices / weights (and the per-vector operator table) in LDS once, then sweeps the flattened (target, vector) items
+//    with up to 4 items per lane in flight; general CSR rows likewise from a staged slice of the CSR arrays.
+//  * workgroups are dealt to XCDs in contiguous ranges (xcd_tile) so neighbouring targets that share source columns share
+//    an L2; several stacks of one shape share a launch (grid.y = stack).
+//  * ATX_FIELDS stacks: lane = target, neighbour indices / weights live in registers and are reused for every level of
+//    the level chunk.
 #include "atx_common.hpp"
 
 namespace atx {
 
+// A/B knobs (build a variant with -D..., compare with tools/ab_bench.py; the defaults are the measured winners, logs under
+// profiles/r01_ab_*.log): items in flight per lane of the tiled kernel (2 and 8: no gain), non-temporal output stores (+3 %)
+// and index / weight loads (+2 %), non-temporal SOURCE loads (no gain), XCD-contiguous block ranges off (-3 %), lanes per
+// workgroup of the tiled kernel (64 / 128 / 512: same plateau).
 #ifndef ATX_UNROLL
 #define ATX_UNROLL 4
 #endif
