@@ -379,9 +379,11 @@ class Pipeline(Workflow):
         return forward_fused(self.filters, data)
 
     def backward(self, data: Any) -> Any:
-        for f in reversed(self.filters):
-            data = f.backward(data)
-        return data
+        # same result as `for f in reversed(filters): data = f.backward(data)` (R: workflows/pipeline.py:50-64), fused the
+        # same way: the backward of a filter is the forward of its ReversedTransform
+        from .filters.fusion import flatten, forward_fused
+
+        return forward_fused([ReversedTransform(f) for f in reversed(flatten(self.filters))], data)
 
 
 class Source(Transform):

@@ -158,6 +158,38 @@ def test_pointwise_run_without_regrid_is_one_launch(engine, launches):
     assert out[1] is source.ds[1] and out[2] is source.ds[2]  # untouched fields pass by identity
 
 
+def test_pipeline_backward_is_fused_and_equals_filter_by_filter(engine, launches, monkeypatch):
+    """Pipeline.backward (R: workflows/pipeline.py:50-64) runs the filters' backward transforms in reverse order — here as
+    one launch, with the results of the filter-by-filter loop."""
+    src = lookup("o16")
+    specs = synthetic_fields(src, 4)
+    for i, p in enumerate(["z", "t", "q", "t"]):
+        specs[i]["param"] = p
+    filters = [create_filter_by_name("orog_to_z"), create_filter_by_name("rescale", scale=1.8, offset=32.0, param="t")]
+    pipeline = filters[0] | filters[1]
+    from anemoi_transform_amd.fields import FieldList
+
+    fields = FieldList(list(test_source(specs)))
+    got = list(pipeline.backward(fields))
+    assert launches["pointwise_stack"] == 1
+    monkeypatch.setenv("ATX_NO_FUSION", "1")
+    want = list(filters[0].backward(filters[1].backward(fields)))
+    assert [f.metadata("param") for f in got] == ["orog", "t", "q", "t"] == [f.metadata("param") for f in want]
+    for a, b, spec in zip(got, want, specs):
+        assert np.array_equal(a.to_numpy(), b.to_numpy(), equal_nan=True)
+    assert np.array_equal(got[1].to_numpy(flatten=True), oracle.rescale_backward(specs[1]["values"], 1.8, 32.0))
+    assert np.array_equal(got[0].to_numpy(flatten=True), oracle.z_to_orog(specs[0]["values"]))
+    assert got[2] is fields[2]  # untouched fields pass through by identity
+    # forward then backward through the pipeline is the identity up to rounding
+    monkeypatch.delenv("ATX_NO_FUSION")
+    specs[0]["param"] = "orog"
+    fields = FieldList(list(test_source(specs)))
+    back = list(pipeline.backward(pipeline.forward(fields)))
+    assert [f.metadata("param") for f in back] == ["orog", "t", "q", "t"]
+    for f, spec in zip(back, specs):
+        np.testing.assert_allclose(f.to_numpy(flatten=True), spec["values"], rtol=1e-12)
+
+
 def test_unfusable_filters_cut_the_segment(engine, launches):
     src, tgt = lookup("o16"), lookup([10.0, 10.0])
     specs = synthetic_fields(src, 3, nan_frac=0.05)
