@@ -589,6 +589,9 @@ def select_levels(stack: Stack, levels: list[int]) -> Stack:
     return out
 
 
+MAX_STACK_LEVELS = 512
+
+
 def group_into_stacks(fields: Iterable[Any], positions: list[int] | None = None, sparse_ok: bool = False) -> list[StackGroup]:
     """Partition fields into stacks: device fields by the stack they live in, host fields by grid size.
 
@@ -623,7 +626,12 @@ def group_into_stacks(fields: Iterable[Any], positions: list[int] | None = None,
         else:
             arrays = [host_values(f) for f in group_fields]
             dtype = _host_dtype(arrays)
-            groups.append(StackGroup(Stack.from_fields(arrays, dtype=dtype, dev=_stack.device()), members, group_fields))
+            # long lists (config 4: thousands of fields on one grid) become several stacks of at most MAX_STACK_LEVELS:
+            # the operator tables of an 8-stage program then always fit the kernels' shared memory, the staging chunks
+            # stay bounded, and stacks that share a plan still go through one batched launch
+            for first in range(0, len(members), MAX_STACK_LEVELS):
+                part = slice(first, first + MAX_STACK_LEVELS)
+                groups.append(StackGroup(Stack.from_fields(arrays[part], dtype=dtype, dev=_stack.device()), members[part], group_fields[part]))
     return groups
 
 

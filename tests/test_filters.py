@@ -663,3 +663,26 @@ def test_foreign_fields_are_accepted(engine):
     assert np.array_equal(out[1].to_numpy(), oracle.orog_to_z(fields[1].to_numpy()[idx]))
     assert np.array_equal(out[2].grid_points()[0], tgt["latitudes"])
     assert out[0].metadata().get("param") == "t" and "levelist" in list(out[0].metadata().keys())
+
+
+def test_long_field_lists_are_split_into_bounded_stacks(engine, monkeypatch):
+    """Hundreds of host fields on one grid (BASELINE config 4 has 3288) become several stacks of bounded size; results and
+    order are those of the field-by-field loop."""
+    from anemoi_transform_amd import fields as fields_module
+    from anemoi_transform_amd.grids import lookup
+
+    monkeypatch.setattr(fields_module, "MAX_STACK_LEVELS", 7)
+    src, tgt = lookup("o16"), lookup([10.0, 10.0])
+    specs = synthetic_fields(src, 17)
+    for i, s_ in enumerate(specs):
+        s_["param"] = "t" if i % 3 else "q"
+    groups = fields_module.group_into_stacks(list(test_source(specs)))
+    assert [g.stack.n_lev for g in groups] == [7, 7, 3] and [p for g in groups for p in g.positions] == list(range(17))
+    regrid = create_filter_by_name("regrid", in_grid="o16", out_grid=[10.0, 10.0], method="nearest")
+    rescale = create_filter_by_name("rescale", scale=2.0, offset=1.0, param="t")
+    out = list(test_source(specs) | regrid | rescale)
+    want = oracle.filter_rescale(oracle.filter_regrid_nearest([dict(s_) for s_ in specs], in_grid=src, out_grid=tgt), scale=2.0, offset=1.0, param="t")
+    assert len(out) == 17
+    for f, w, spec in zip(out, want, specs):
+        assert f.metadata("levelist") == spec["levelist"] and f.metadata("param") == spec["param"]
+        assert np.array_equal(f.to_numpy(flatten=True), np.asarray(w["values"]).ravel(), equal_nan=True)
