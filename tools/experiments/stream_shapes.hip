@@ -76,6 +76,54 @@ __global__ void __launch_bounds__(256) k_table(const V4* __restrict__ x, V4* __r
     y[vi] = v;
 }
 
+struct Op12 { int op_mask; float p0; float p1; };
+
+// shape 4: shape 3 with 12-byte operators (op | use_mask << 16, p0, p1 as float), all stages fetched before the data
+__global__ void __launch_bounds__(256) k_table12(const V4* __restrict__ x, V4* __restrict__ y, int64_t n, int C, const Op12* __restrict__ table,
+                                                 int n_stage, const uint8_t* __restrict__ mask) {
+    const int64_t vi = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (vi >= n) return;
+    const unsigned row = (unsigned)(vi / C);
+    const int c = (int)(vi - (int64_t)row * C);
+    Op12 ops[8];
+#pragma unroll
+    for (int s = 0; s < 8; ++s) if (s < n_stage) ops[s] = table[s * C + c];
+    V4 v = x[vi];
+    const bool masked = mask ? mask[row] != 0 : false;
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+        if (s >= n_stage) break;
+        const float p0 = ops[s].p0, p1 = ops[s].p1;
+        switch (ops[s].op_mask & 0xffff) {
+            case 1:
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v.v[e] = v.v[e] * p0 + p1;
+                break;
+            case 2:
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v.v[e] = (v.v[e] - p1) / p0;
+                break;
+            case 3:
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v.v[e] = v.v[e] * p0;
+                break;
+            default: break;
+        }
+        if ((ops[s].op_mask >> 16) && masked) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v.v[e] = __uint_as_float(0x7fc00000u);
+        }
+    }
+    y[vi] = v;
+}
+
+extern "C" int run_table12(const void* x, void* y, int64_t n_vec, int C, const void* table, int n_stage, const void* mask, void* stream) {
+    const int64_t blocks = (n_vec + 255) / 256;
+    hipLaunchKernelGGL(k_table12, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const V4*)x, (V4*)y, n_vec, C, (const Op12*)table, n_stage,
+                       (const uint8_t*)mask);
+    return (int)hipGetLastError();
+}
+
 extern "C" int run_table(const void* x, void* y, int64_t n_vec, int C, const void* table, int n_stage, const void* mask, void* stream) {
     const int64_t blocks = (n_vec + 255) / 256;
     hipLaunchKernelGGL(k_table, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const V4*)x, (V4*)y, n_vec, C, (const Op*)table, n_stage,

@@ -28,5 +28,12 @@ for n_stage, use_mask in ((1, 0), (3, 0), (1, 1)):
     table = torch.from_numpy(t.view(np.uint8).reshape(-1)).to(dev)
     ms, _ = bench.time_launches(lambda: lib.run_table(x.data_ptr(), y.data_ptr(), n // 4, 35, table.data_ptr(), n_stage, mask.data_ptr() if use_mask else None, st), 20, 3)
     print(f"shape 3 table lookup, {n_stage} stage(s), mask={use_mask}: {ms:.3f} ms  {gb / ms:.2f} TB/s", flush=True)
+lib.run_table12.argtypes = lib.run_table.argtypes
+dt12 = np.dtype([("op_mask", np.int32), ("p0", np.float32), ("p1", np.float32)])
+for n_stage, use_mask in ((1, 0), (2, 0), (3, 0), (1, 1), (3, 1)):
+    t = np.zeros((n_stage, 35), dtype=dt12); t["op_mask"] = 1 | (use_mask << 16); t["p0"] = 2.0; t["p1"] = 1.0
+    table = torch.from_numpy(t.view(np.uint8).reshape(-1)).to(dev)
+    ms, _ = bench.time_launches(lambda: lib.run_table12(x.data_ptr(), y.data_ptr(), n // 4, 35, table.data_ptr(), n_stage, mask.data_ptr() if use_mask else None, st), 20, 3)
+    print(f"shape 4 table of 12-B operators, {n_stage} stage(s), mask={use_mask}: {ms:.3f} ms  {gb / ms:.2f} TB/s", flush=True)
 ms, _ = bench.time_launches(lambda: torch.add(x, 1.0, out=y), 20, 3)
 print(f"torch add(out=):           {ms:.3f} ms  {gb / ms:.2f} TB/s")
