@@ -502,3 +502,37 @@ def test_vector_program_host_helper():
         assert out["use_mask"][-1] == 1  # the last (partial) vector holds only level 8
     assert lib.atx_vector_program(None, 1, 4, native.F32, None) == native.EINVAL
     assert lib.atx_vector_program(host.ctypes.data, 9, 1, native.F32, None) == native.EINVAL
+
+
+def test_shard_bounds_invariants_on_random_plans(monkeypatch):
+    """Whatever the index table, world size and operator shape: bounds are monotone, start at 0, end at n_tgt; the shards
+    are contiguous row ranges of the plan and, applied one by one, reproduce the unsharded result bit for bit (kernels: the
+    oracle-backed double)."""
+    import native_double
+    import torch
+    from anemoi_transform_amd.stack import Stack
+
+    native_double.install(monkeypatch)
+    rng = np.random.default_rng(77)
+    for case in range(25):
+        n_src, n_tgt = int(rng.integers(1, 400)), int(rng.integers(0, 300))
+        world = int(rng.integers(1, 10))
+        kind = rng.choice(["gather", "ell", "padded", "csr"])
+        if kind == "gather":
+            plan = GatherPlan(n_src, n_tgt, index=rng.integers(0, n_src, n_tgt))
+        elif kind == "ell":
+            k = int(rng.integers(1, 6))
+            plan = GatherPlan(n_src, n_tgt, index=rng.integers(0, n_src, (n_tgt, k)), weights=rng.random((n_tgt, k)))
+        else:
+            lengths = rng.integers(0, 5 if kind == "padded" else 12, n_tgt)
+            indptr = np.concatenate([[0], np.cumsum(lengths)])
+            matrix = dict(matrix_data=rng.random(int(indptr[-1])), matrix_indices=rng.integers(0, n_src, int(indptr[-1])).astype(np.int32),
+                          matrix_indptr=indptr.astype(np.int32), matrix_shape=(n_tgt, n_src))
+            plan = GatherPlan.from_matrix(matrix) if n_tgt else GatherPlan(n_src, 0, index=np.zeros((0, 1), dtype=np.int64))
+        b = plan.bounds(world)
+        assert len(b) == world + 1 and b[0] == 0 and b[-1] == n_tgt and all(x <= y for x, y in zip(b, b[1:])), (case, b)
+        assert [plan.shard_range(r, world) for r in range(world)] == list(zip(b[:-1], b[1:]))
+        x = Stack.from_fields(rng.standard_normal((3, n_src)), dev=torch.device("cpu"))
+        full = plan.apply(x).numpy()
+        parts = [plan.shard(r, world).apply(x).numpy() for r in range(world)]
+        assert np.array_equal(np.concatenate(parts, axis=1), full, equal_nan=True), (case, kind, world)
