@@ -275,9 +275,9 @@ regrid_cols_ell_direct_kernel(EllBatch batch, const int32_t* __restrict__ idx, c
         int32_t p[K];
         T wv[K];
 #pragma unroll
-        for (int j = 0; j < K; ++j) {
-            p[j] = load_once(idx + (int64_t)t * K + j);
-            if (WEIGHTED) wv[j] = load_once(w + (int64_t)t * K + j);
+        for (int j = 0; j < K; ++j) {  // plain loads: a target's words are read again by the next wave when its vectors straddle two
+            p[j] = idx[(int64_t)t * K + j];
+            if (WEIGHTED) wv[j] = w[(int64_t)t * K + j];
         }
         V v[K];
 #pragma unroll
