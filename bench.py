@@ -285,6 +285,33 @@ def main():
         },
         "precompute_s": precompute_s,
     }
+    if world > 1 and args.exchange == "broadcast":
+        # comparison point (axis 2): shard the FIELDS instead of the target points — every rank interpolates the
+        # whole target grid of its own stack, nothing is exchanged at all.  Same units per step; reported next to `value`.
+        try:
+            full_idx = torch.from_numpy(idx64.astype(np.int32)).to(dev)
+            full_w = torch.from_numpy(w64.astype(np_dtype)).to(dev)
+            own, full_out = stacks[rank], Stack.empty(n_tgt, args.levels, tdtype, dev, layout)
+
+            def own_step():
+                launch(own, full_out, idx=full_idx, w=full_w, n_t=n_tgt)
+
+            for _ in range(args.warmup):
+                own_step()
+            torch.cuda.synchronize()
+            dist.barrier()
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                own_step()
+            torch.cuda.synchronize()
+            t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            result["field_axis_sharding"] = {"value": units_per_step * args.steps / float(t.item()), "unit": "grid-points/s",
+                                             "ms_per_step": float(t.item()) / args.steps * 1e3,
+                                             "note": "each rank regrids its own stack to the full target grid; no source exchange"}
+            del full_idx, full_w, full_out
+        except Exception as e:  # a comparison line must never take the bench line down
+            result["field_axis_sharding"] = {"error": f"{type(e).__name__}: {e}"}
     if world > 1 and args.end_to_end and layout == COLUMNS:
         from anemoi_transform_amd.distributed import pipelined_sharded_regrid
 

@@ -56,6 +56,8 @@ def test_two_ranks_rehearsal_over_gloo(exchange):
     assert d["source_exchange"] == exchange and d["source_exchange_ms"] > 0
     assert d["end_to_end"]["value"] > 0 and d["end_to_end"]["value"] < d["value"]  # the exchange is inside that one
     assert "cpu_baseline" not in d  # rank 0 at N = 1 only
+    if exchange == "broadcast":
+        assert d["field_axis_sharding"]["value"] > 0  # the no-exchange comparison point rides along
 
 
 def test_integration_md_ctypes_stub_runs(tmp_path):
