@@ -70,6 +70,26 @@ def test_latlon_grids_and_npz(tmp_path):
         grids.lookup("n320")  # classic reduced grids need the downloaded table (out of scope)
 
 
+def test_n320_sized_reduced_grid():
+    """BASELINE config 4's target: the SIZE of the classic N320 grid (542 080 points, SURVEY.md §8 header) on a locally
+    constructed row table — even rows proportional to cos(lat), 18 at the poles, 1280 at the equator, symmetric."""
+    rows = grids.sized_row_lengths(320, 542080)
+    assert rows.shape == (640,) and rows.sum() == 542080
+    assert np.array_equal(rows, rows[::-1]) and rows[0] == 18 and rows.max() == 1280 == rows[319]
+    assert np.all(np.diff(rows[:320]) >= 0) and np.all(rows % 2 == 0)
+    g = grids.lookup("n320-sized")
+    assert len(g["latitudes"]) == 542080 == len(g["longitudes"])
+    assert np.array_equal(np.unique(g["latitudes"])[::-1], grids.gaussian_latitudes(640))
+    assert g["longitudes"][18] == 0.0 and g["longitudes"][1] == 20.0 and g["longitudes"].max() < 360.0
+    # any admissible total is hit exactly, leftovers included
+    for total in (2 * 48 * 40 + 6, 2 * 48 * 18, 8 * 48 * 48):
+        assert grids.sized_row_lengths(48, total).sum() == total
+    with pytest.raises(ValueError):
+        grids.sized_row_lengths(48, 10)
+    with pytest.raises(ValueError):
+        grids.reduced_gaussian_sized(640)  # size of the classic N640 grid is not recorded
+
+
 def test_gaussian_latitudes_are_legendre_roots():
     lats = grids.gaussian_latitudes(64)
     x = np.sin(np.deg2rad(lats))
