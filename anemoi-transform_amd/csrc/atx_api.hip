@@ -38,6 +38,7 @@ extern "C" const char* atx_strerror(int code) {
         case ATX_EHIP: return "HIP runtime error";
         case ATX_EALIGN: return "alignment requirement not met";
         case ATX_EWORKSPACE: return "workspace too small";
+        case ATX_ECOMM: return "RCCL unavailable or collective failed";
         default: return "unknown error";
     }
 }

@@ -14,7 +14,11 @@
 // sqeuclidean_distance_double does for 3-D points: s = 0; s += dx*dx; s += dy*dy; s += dz*dz
 // in float64 without contraction — so the returned d^2 are BIT-IDENTICAL to cKDTree's and
 // the neighbour lists agree wherever the (k+1) smallest distances are distinct.  Exact ties
-// (cKDTree leaves their order to its traversal) are resolved here by the lower source index.
+// (cKDTree leaves their order to its traversal: which of two equidistant points it meets first
+// depends on std::nth_element's permutation during ITS tree build) are ordered here by the lower
+// source index; the host wrapper (interp.nearest_grid_points_device) asks for one neighbour more
+// than needed, finds the rows with an exact tie among those k+1 distances and lets cKDTree itself
+// decide these rows, so the index table it returns is identical to the reference's.
 // The box lower bound is computed with the same monotone operations, so pruning never drops
 // a point that could enter the list.
 #include "atx_common.hpp"
@@ -24,7 +28,7 @@
 namespace atx {
 
 constexpr int kLeaf = 8;      // source points per leaf bucket
-constexpr int kMaxK = 16;     // neighbours kept per target
+constexpr int kMaxK = 17;     // neighbours kept per target: 16 + the look-ahead neighbour of the tie detection
 constexpr int kStack = 64;    // >= 2 * tree depth (depth <= 28 for 2^31 points)
 
 struct KnnHeader {
@@ -236,8 +240,8 @@ __device__ __forceinline__ double dot3(const double a[3], const double b[3]) {
 }
 
 __global__ void __launch_bounds__(kBlock)
-cutout_inside_kernel(const double* __restrict__ g, int64_t n, const double* __restrict__ lam, const int32_t* __restrict__ nb,
-                     int k, uint8_t* __restrict__ inside) {
+cutout_inside_kernel(const double* __restrict__ g, int64_t n, const double* __restrict__ lam, int64_t n_lam,
+                     const int32_t* __restrict__ nb, int k, uint8_t* __restrict__ inside) {
     const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (i >= n) return;
     const double d[3] = {g[i * 3], g[i * 3 + 1], g[i * 3 + 2]};
@@ -245,6 +249,9 @@ cutout_inside_kernel(const double* __restrict__ g, int64_t n, const double* __re
     bool hit = false;
     for (int j = 0; j < k && !hit; ++j) {
         const int64_t i0 = nb[i * k + j], i1 = nb[i * k + (j + 1) % k], i2 = nb[i * k + (j + 2) % k];
+        // never read outside lam_xyz: a "not found" marker (n_lam, atx_knn_query with k > n_lam) or any other stray index
+        // skips the triangle (the host wrapper rejects such tables before the launch, as the reference's indexing would)
+        if (i0 < 0 || i0 >= n_lam || i1 < 0 || i1 >= n_lam || i2 < 0 || i2 >= n_lam) continue;
         double v0[3], e1[3], e2[3], s[3], h[3], q[3];
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
@@ -275,7 +282,7 @@ extern "C" int atx_cutout_inside(const double* global_xyz, int64_t n, const doub
                 (long long)n, (long long)n_lam, k);
     if (n == 0) return ATX_OK;
     hipLaunchKernelGGL(cutout_inside_kernel, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0,
-                       static_cast<hipStream_t>(stream), global_xyz, n, lam_xyz, neighbours, k, inside);
+                       static_cast<hipStream_t>(stream), global_xyz, n, lam_xyz, n_lam, neighbours, k, inside);
     ATX_LAUNCH_CHECK("cutout_inside");
     return ATX_OK;
 }
@@ -355,7 +362,8 @@ extern "C" int atx_knn_query(const void* workspace, int64_t n_src, const double*
             case 13: ATX_KNN_LAUNCH(13); break;
             case 14: ATX_KNN_LAUNCH(14); break;
             case 15: ATX_KNN_LAUNCH(15); break;
-            default: ATX_KNN_LAUNCH(16); break;
+            case 16: ATX_KNN_LAUNCH(16); break;
+            default: ATX_KNN_LAUNCH(17); break;
         }
     }
 #undef ATX_KNN_LAUNCH

@@ -22,6 +22,7 @@ __all__ = [
     "unit_sphere_xyz",
     "nearest_grid_points",
     "nearest_grid_points_device",
+    "device_knn",
     "knn_inverse_distance",
     "ell_to_csr",
     "csr_uniform_k",
@@ -35,8 +36,8 @@ _knn_engine: str | None = None
 
 
 def knn_engine() -> str:
-    """``"ckdtree"`` (default: the reference's own builder, identical tie order) or ``"device"``
-    (``atx_knn_*`` on the GPU; set with ``set_knn_engine`` or ``ATX_KNN=device``)."""
+    """``"ckdtree"`` (default: the reference's own builder) or ``"device"`` (``atx_knn_*`` on the GPU with
+    equidistant candidates settled by cKDTree — the same table; set with ``set_knn_engine`` or ``ATX_KNN=device``)."""
     import os
 
     return _knn_engine or os.environ.get("ATX_KNN", "ckdtree")
@@ -57,6 +58,63 @@ def unit_sphere_xyz(latitudes: np.ndarray, longitudes: np.ndarray) -> np.ndarray
     return np.array((cos_phi * np.cos(lda), cos_phi * np.sin(lda), np.sin(phi))).transpose()
 
 
+MAX_DEVICE_K = 16  # atx_knn_query keeps up to 17 neighbours: these 16 plus the look-ahead one of the tie detection
+
+
+def device_knn(src_xyz: np.ndarray, tgt_xyz: np.ndarray, k: int, *, ties: str = "ckdtree", max_distance: float | None = None):
+    """``(indices int64 [n, k], squared distances float64 [n, k], n_rows_resolved)`` — the k nearest rows of
+    ``src_xyz`` for every row of ``tgt_xyz``, searched on the MI355X (``atx_knn_build`` / ``atx_knn_query``).
+
+    The kernel's distances are bit-identical to cKDTree's, so its neighbour lists can differ from cKDTree's only in the
+    ORDER (or, at the k-th place, the choice) of EXACTLY equidistant candidates: the kernel orders them by source index,
+    cKDTree by whichever it meets first in its traversal (R: spatial.py:628 — an artefact of ``std::nth_element`` during
+    its tree build, not reproducible without running that build).  ``ties="ckdtree"`` (default) makes the result
+    identical to the reference's anyway: the device returns one neighbour more than asked for, rows in which two adjacent
+    distances among those k+1 are equal are found on the device, and only those rows (0.14 % for O1280 -> 0.25 degree)
+    are answered again by ``cKDTree(src).query`` on the host — the reference's own statement.  The host tree is built
+    only if such rows exist.  ``ties="index"`` skips that and keeps the kernel's deterministic order.
+    """
+    import torch
+
+    from . import native
+    from . import stack as _stack
+
+    if ties not in ("ckdtree", "index"):
+        raise ValueError(f"ties must be 'ckdtree' or 'index', got {ties!r}")
+    if not 1 <= k <= MAX_DEVICE_K:
+        raise ValueError(f"the device k-NN search returns 1..{MAX_DEVICE_K} neighbours, got k={k}")
+    dev = _stack.device()
+    src_xyz = np.ascontiguousarray(src_xyz, dtype=np.float64)
+    tgt_xyz = np.ascontiguousarray(tgt_xyz, dtype=np.float64)
+    n_tgt = len(tgt_xyz)
+    if n_tgt == 0:
+        return np.zeros((0, k), dtype=np.int64), np.zeros((0, k)), 0
+    ahead = 1 if ties == "ckdtree" else 0
+    idx_d, d2_d = native.KnnIndex(torch.from_numpy(src_xyz).to(dev)).query(torch.from_numpy(tgt_xyz).to(dev), k + ahead)
+    rows = None
+    if ahead:
+        # a finite distance equal to its successor: the candidates' order (or which of them is the k-th) is cKDTree's to decide
+        tied = ((d2_d[:, :-1] == d2_d[:, 1:]) & torch.isfinite(d2_d[:, :-1])).any(dim=1)
+        rows = torch.nonzero(tied).reshape(-1).cpu().numpy()
+    indices = idx_d[:, :k].cpu().numpy().astype(np.int64)
+    d2 = d2_d[:, :k].cpu().numpy()
+    if rows is not None and rows.size:
+        from scipy.spatial import cKDTree
+
+        kwargs = {} if max_distance is None else {"distance_upper_bound": max_distance}
+        host_d, host_i = cKDTree(src_xyz).query(tgt_xyz[rows], k=k, **kwargs)
+        host_d, host_i = host_d.reshape(len(rows), k), host_i.reshape(len(rows), k)
+        # cKDTree reports sqrt(d2); the squared distances are the same multiset per row, re-ordered like the indices
+        found = host_i < len(src_xyz)
+        diff = src_xyz[np.where(found, host_i, 0)] - tgt_xyz[rows][:, None, :]
+        host_d2 = np.zeros(host_i.shape)
+        for c in range(3):  # s = 0; s += dx*dx; ... — scipy's order, as in the kernel
+            host_d2 = host_d2 + diff[..., c] * diff[..., c]
+        indices[rows] = host_i
+        d2[rows] = np.where(found, host_d2, np.inf)
+    return indices, d2, 0 if rows is None else int(rows.size)
+
+
 def nearest_grid_points_device(
     source_latitudes,
     source_longitudes,
@@ -65,26 +123,20 @@ def nearest_grid_points_device(
     max_distance: float | None = None,
     num_neighbours_to_return: int = 1,
     return_distances: bool = False,
+    ties: str = "ckdtree",
 ):
     """``nearest_grid_points`` computed on the MI355X (``atx_knn_build`` / ``atx_knn_query``).
 
-    Same arguments and return values.  Distances are bit-identical to cKDTree's (the
-    coordinates are computed here on the host exactly as the reference does, and the kernel
-    repeats scipy's float64 arithmetic); indices agree wherever the candidate distances are
-    distinct — exact ties are ordered by source index (cKDTree: traversal order).
+    Same arguments and return values as R: spatial.py:587-635, and — with the default ``ties="ckdtree"`` — the same
+    bits: distances are bit-identical to cKDTree's (coordinates are computed on the host exactly as the reference does,
+    the kernel repeats scipy's float64 arithmetic), and rows with exactly equidistant candidates are settled by cKDTree
+    itself (``device_knn``).  ``ties="index"`` orders such candidates by source index and never touches the host tree.
     """
-    import torch
-
-    from . import native
-    from . import stack as _stack
-
     k = int(num_neighbours_to_return)
-    dev = _stack.device()
-    src = torch.from_numpy(np.ascontiguousarray(unit_sphere_xyz(source_latitudes, source_longitudes))).to(dev)
-    tgt = torch.from_numpy(np.ascontiguousarray(unit_sphere_xyz(target_latitudes, target_longitudes))).to(dev)
-    idx_d, d2_d = native.KnnIndex(src).query(tgt, k)
-    indices = idx_d.cpu().numpy().astype(np.int64)
-    distances = np.sqrt(d2_d.cpu().numpy())
+    src = unit_sphere_xyz(source_latitudes, source_longitudes)
+    tgt = unit_sphere_xyz(target_latitudes, target_longitudes)
+    indices, d2, _ = device_knn(src, tgt, k, ties=ties, max_distance=max_distance)
+    distances = np.sqrt(d2)
     if max_distance is not None:  # cKDTree: neighbours at d >= distance_upper_bound are "missing"
         missing = ~(distances < max_distance)
         indices[missing] = len(src)
@@ -130,16 +182,18 @@ def nearest_grid_points(
     return indices
 
 
-def knn_inverse_distance(in_grid: dict, out_grid: dict, k: int = 4, floor: float = 1e-12, device: bool = False):
+def knn_inverse_distance(in_grid: dict, out_grid: dict, k: int = 4, floor: float = 1e-12, device: bool = False,
+                         ties: str = "ckdtree"):
     """k-NN inverse-distance weights ``w_j = (1/max(d_j, floor)) / sum``.
 
     Returns ``(idx [Nt, k] int64, w [Nt, k] float64)``.  ``device=True`` runs the neighbour
-    search on the GPU (``nearest_grid_points_device``) instead of cKDTree.
+    search on the GPU (``nearest_grid_points_device``; ``ties`` as there) instead of cKDTree.
     """
+    kwargs = dict(ties=ties) if device else {}
     search = nearest_grid_points_device if device else nearest_grid_points
     idx, dist = search(
         in_grid["latitudes"], in_grid["longitudes"], out_grid["latitudes"], out_grid["longitudes"],
-        num_neighbours_to_return=k, return_distances=True,
+        num_neighbours_to_return=k, return_distances=True, **kwargs,
     )
     idx = idx.reshape(len(idx), -1)
     dist = dist.reshape(len(dist), -1)

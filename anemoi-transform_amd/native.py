@@ -42,7 +42,8 @@ COMB_SNOW_DEPTH_M, COMB_SNOW_COVER, COMB_COS_SIN, COMB_ATAN2, COMB_W_TO_WZ, COMB
 COMB_DEGREES = 1
 COMB_MAX_INPUTS = 8
 
-OK, EINVAL, ESHAPE, ENOTIMPL, EHIP, EALIGN, EWORKSPACE = 0, -1, -2, -3, -4, -5, -6
+OK, EINVAL, ESHAPE, ENOTIMPL, EHIP, EALIGN, EWORKSPACE, ECOMM = 0, -1, -2, -3, -4, -5, -6, -7
+COMM_ID_BYTES = 128
 
 # numpy layout of `atx_level_op` (24 bytes)
 LEVEL_OP_DTYPE = np.dtype([("op", "<i4"), ("use_mask", "<i4"), ("p0", "<f8"), ("p1", "<f8")])
@@ -93,6 +94,15 @@ SIGNATURES: dict[str, tuple[Any, list[Any]]] = {
     "atx_relayout": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int64, c_int, c_int, c_int, c_void_p]),
     "atx_reduce_stack": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_int, c_void_p, c_int, c_int, c_void_p]),
     "atx_select_levels": (c_int, [c_void_p, c_void_p, c_void_p, c_int32, c_int64, c_int64, c_int64, c_int64, c_int, c_int, c_void_p]),
+    "atx_comm_version": (c_int, []),
+    "atx_comm_unique_id": (c_int, [c_void_p]),
+    "atx_comm_init": (c_int, [POINTER(c_void_p), c_int32, c_int32, c_void_p]),
+    "atx_comm_destroy": (c_int, [c_void_p]),
+    "atx_comm_rank": (c_int, [c_void_p]),
+    "atx_comm_world": (c_int, [c_void_p]),
+    "atx_bcast": (c_int, [c_void_p, c_void_p, c_int64, c_int32, c_void_p]),
+    "atx_exchange": (c_int, [c_void_p, POINTER(c_void_p), POINTER(c_int64), POINTER(c_void_p), POINTER(c_int64), c_void_p]),
+    "atx_gather_shards": (c_int, [c_void_p, c_void_p, POINTER(c_int64), c_void_p]),
 }
 
 _lib: ctypes.CDLL | None = None
@@ -136,6 +146,8 @@ def _raise(code: int, fn: str) -> None:
         raise AssertionError(msg)
     if code == ENOTIMPL:
         raise NotImplementedError(msg)
+    if code == ECOMM:
+        raise AtxError(f"{fn}: {msg}")
     raise AtxError(f"{fn}: {msg} (code {code})")
 
 
@@ -361,6 +373,75 @@ def stream_copy(src, dst) -> None:
     n_bytes = src.numel() * src.element_size()
     assert dst.numel() * dst.element_size() == n_bytes and src.is_contiguous() and dst.is_contiguous()
     _call("atx_stream_copy", _ptr(src), _ptr(dst), n_bytes, _stream())
+
+
+class Comm:
+    """An RCCL communicator through the C ABI (``atx_comm_*``): one per process, bound to the current device.
+
+    ``Comm.unique_id()`` on rank 0, the 128 bytes handed to every rank out of band, then ``Comm(world, rank, id)``
+    everywhere (collective).  Calls enqueue on torch's current stream."""
+
+    def __init__(self, world: int, rank: int, unique_id: bytes) -> None:
+        if len(unique_id) != COMM_ID_BYTES:
+            raise ValueError(f"an RCCL unique id has {COMM_ID_BYTES} bytes, got {len(unique_id)}")
+        handle = c_void_p()
+        buf = ctypes.create_string_buffer(bytes(unique_id), COMM_ID_BYTES)
+        _call("atx_comm_init", ctypes.byref(handle), int(world), int(rank), ctypes.cast(buf, c_void_p))
+        self._handle = handle
+        self.world, self.rank = int(world), int(rank)
+
+    @staticmethod
+    def unique_id() -> bytes:
+        buf = ctypes.create_string_buffer(COMM_ID_BYTES)
+        _call("atx_comm_unique_id", ctypes.cast(buf, c_void_p))
+        return buf.raw
+
+    @staticmethod
+    def rccl_version() -> int:
+        v = load().atx_comm_version()
+        if v < 0:
+            _raise(v, "atx_comm_version")
+        return v
+
+    def bcast(self, t: torch.Tensor, root: int) -> None:
+        """``t`` (contiguous, in HBM) of rank ``root`` onto every rank, in place."""
+        assert t.is_contiguous()
+        _call("atx_bcast", self._handle, _ptr(t), t.numel() * t.element_size(), int(root), _stream())
+
+    def exchange(self, send: list, recv: list) -> None:
+        """``send[p]`` goes to rank ``p``, ``recv[p]`` is filled by rank ``p``; ``None`` / empty tensors skip the pair."""
+        assert len(send) == len(recv) == self.world
+
+        def table(tensors):
+            ptrs = (c_void_p * self.world)()
+            sizes = (c_int64 * self.world)()
+            for p, t in enumerate(tensors):
+                if t is not None and t.numel():
+                    assert t.is_contiguous()
+                    ptrs[p], sizes[p] = _ptr(t), t.numel() * t.element_size()
+            return ptrs, sizes
+
+        sp, sb = table(send)
+        rp, rb = table(recv)
+        _call("atx_exchange", self._handle, sp, sb, rp, rb, _stream())
+
+    def gather_shards(self, full: torch.Tensor, byte_offsets: list[int]) -> None:
+        """Every rank has filled its byte range ``[byte_offsets[rank], byte_offsets[rank + 1])`` of ``full``; afterwards all have all."""
+        assert full.is_contiguous() and len(byte_offsets) == self.world + 1
+        assert byte_offsets[-1] <= full.numel() * full.element_size()
+        offs = (c_int64 * (self.world + 1))(*[int(o) for o in byte_offsets])
+        _call("atx_gather_shards", self._handle, _ptr(full), offs, _stream())
+
+    def destroy(self) -> None:
+        if self._handle is not None:
+            handle, self._handle = self._handle, None
+            _call("atx_comm_destroy", handle)
+
+    def __del__(self) -> None:  # best effort; explicit destroy() is the documented way
+        try:
+            self.destroy()
+        except Exception:
+            pass
 
 
 def relayout(src, dst, *, n_pts, n_lev, src_pitch, dst_pitch, src_layout, dst_layout) -> None:

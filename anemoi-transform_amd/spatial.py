@@ -150,25 +150,33 @@ def cutout_mask(
 
 
 def _device_neighbours_and_inside(lam_points: np.ndarray, global_points: np.ndarray, neighbours: int):
-    """k nearest LAM points of every global point and the ray/triangle verdict, on the GPU."""
+    """k nearest LAM points of every global point (``interp.device_knn``: cKDTree's own order among equidistant
+    points, since the triangles are formed from CONSECUTIVE neighbours) and the ray/triangle verdict, on the GPU."""
     import torch
 
     from . import native
     from . import stack as _stack
+    from .interp import MAX_DEVICE_K, device_knn
 
+    if neighbours > len(lam_points):
+        # the host path fails the same way: cKDTree pads with the index len(lam_points), which then indexes out of range
+        raise IndexError(f"index {len(lam_points)} is out of bounds for axis 0 with size {len(lam_points)} "
+                         f"(neighbours={neighbours} > {len(lam_points)} limited-area points)")
+    if neighbours > MAX_DEVICE_K:
+        raise ValueError(f"cutout_mask(device=True) supports neighbours <= {MAX_DEVICE_K}, got {neighbours}; use device=False")
     if len(global_points) == 0:
         return np.zeros((0, neighbours)), np.zeros(0, dtype=bool)
     dev = _stack.device()
+    idx, d2, _ = device_knn(lam_points, global_points, neighbours)
     lam_d = torch.from_numpy(np.ascontiguousarray(lam_points)).to(dev)
     glob_d = torch.from_numpy(np.ascontiguousarray(global_points)).to(dev)
-    idx, d2 = native.KnnIndex(lam_d).query(glob_d, neighbours)
-    inside = native.cutout_inside(glob_d, lam_d, idx)
-    return np.sqrt(d2.cpu().numpy()), inside.cpu().numpy().astype(bool)
+    inside = native.cutout_inside(glob_d, lam_d, torch.from_numpy(idx.astype(np.int32)).to(dev))
+    return np.sqrt(d2), inside.cpu().numpy().astype(bool)
 
 
 def thinning_mask(lats, lons, global_lats, global_lons, cropping_distance: float = 2.0, device: bool = False) -> np.ndarray:
     """Indices of the LAM points closest to each global point of the surrounding box (R: spatial.py:443-503).
-    ``device=True``: the k = 1 search runs on the GPU (``atx_knn_*``; equidistant candidates resolve to the lower index)."""
+    ``device=True``: the k = 1 search runs on the GPU (``atx_knn_*``; equidistant candidates settled by cKDTree: same indices)."""
     from scipy.spatial import cKDTree
 
     _check_latlon_arrays(lats, lons, global_lats, global_lons)

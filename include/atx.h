@@ -44,7 +44,7 @@
 extern "C" {
 #endif
 
-#define ATX_VERSION 100 /* 0.1.0 */
+#define ATX_VERSION 200 /* 0.2.0 */
 
 /* ---- status codes --------------------------------------------------------- */
 enum {
@@ -54,7 +54,8 @@ enum {
     ATX_ENOTIMPL = -3, /* unsupported combination -> NotImplementedError (R: regrid.py:332-335) */
     ATX_EHIP = -4,     /* HIP runtime error at launch */
     ATX_EALIGN = -5,   /* pointer / pitch alignment not met for the requested layout */
-    ATX_EWORKSPACE = -6 /* workspace too small */
+    ATX_EWORKSPACE = -6, /* workspace too small */
+    ATX_ECOMM = -7      /* RCCL missing or a collective failed */
 };
 
 typedef enum { ATX_F32 = 0, ATX_F64 = 1 } atx_dtype;
@@ -264,7 +265,10 @@ int atx_reduce_stack(const void* x, int64_t n_pts, int64_t n_lev, int64_t pitch,
  * `workspace` (atx_knn_workspace_bytes(n_src) bytes, 256-byte aligned, owned by the caller,
  * reusable for any number of queries).  atx_knn_query writes, per target, the k nearest
  * source indices (int32, ascending distance, ties by lower index, n_src if fewer than k
- * exist) and their SQUARED distances, bit-identical to scipy's float64 arithmetic. */
+ * exist) and their SQUARED distances, bit-identical to scipy's float64 arithmetic; k <= 17
+ * (16 neighbours plus one to look ahead: a caller that needs cKDTree's own order among
+ * EXACTLY equidistant candidates queries k+1, finds the rows with equal adjacent distances and
+ * re-resolves those with cKDTree — what the host mirror's nearest_grid_points_device does). */
 size_t atx_knn_workspace_bytes(int64_t n_src);
 int atx_knn_build(const double* src_xyz, int64_t n_src, void* workspace, size_t workspace_bytes, void* stream);
 int atx_knn_query(const void* workspace, int64_t n_src, const double* tgt_xyz, int64_t n_tgt, int32_t k,
@@ -276,9 +280,44 @@ int atx_knn_query(const void* workspace, int64_t n_src, const double* tgt_xyz, i
  * (Moeller-Trumbore, epsilon 1e-7) — the per-point loop of
  *   R: spatial.py:404-424 (cutout_mask) over R: spatial.py:186-233 (Triangle3D.intersect)
  * evaluated for all points at once.  global_xyz [n,3] and lam_xyz [n_lam,3] float64 unit-sphere
- * coordinates, neighbours int32 [n,k] (from atx_knn_query), inside uint8 [n]. */
+ * coordinates, neighbours int32 [n,k] (from atx_knn_query; k <= 17), inside uint8 [n].  A triangle with a vertex
+ * index outside [0, n_lam) is skipped, never dereferenced. */
 int atx_cutout_inside(const double* global_xyz, int64_t n, const double* lam_xyz, int64_t n_lam,
                       const int32_t* neighbours, int32_t k, uint8_t* inside, void* stream);
+
+/* ---- multi-GPU: the source exchange of a target-sharded regrid ------------------------ */
+/* One process per GPU; RCCL (over xGMI on an MI355X node) is bound at first use (dlopen), so the library loads without
+ * it.  The regrid path itself needs no collective: rows of the operator are independent, every rank computes a
+ * contiguous slice of the target points (R: filters/fields/regrid.py:204-208 is a single-process loop — there is no
+ * reference counterpart).  What has to travel is the SOURCE stack, once:
+ *   atx_bcast          the whole pitched stack from its owner ("source broadcast once")
+ *   atx_exchange       or only the slab of source columns each peer's target slice references (ATX_COLUMNS: a
+ *                      contiguous byte range), grouped send/recv — about 1/world of the bytes for lat-lon targets
+ *   atx_gather_shards  optionally the target slices back onto every rank
+ * All calls enqueue on `stream` of the CURRENT device and return; buffers are device memory owned by the caller.
+ * A communicator belongs to the device that was current in atx_comm_init.  Errors: ATX_ECOMM + atx_last_error(). */
+typedef struct atx_comm atx_comm;
+#define ATX_COMM_ID_BYTES 128
+/* RCCL's version code (e.g. 22205), or a negative status if RCCL cannot be loaded. */
+int atx_comm_version(void);
+/* Rank 0 fills `id` (HOST, ATX_COMM_ID_BYTES) and hands it to every rank out of band (file, socket, MPI, a
+ * torch.distributed store ...). */
+int atx_comm_unique_id(void* id);
+/* Collective over all `world` ranks: join the job identified by `id` as `rank`, on the current HIP device. */
+int atx_comm_init(atx_comm** comm, int32_t world, int32_t rank, const void* id);
+int atx_comm_destroy(atx_comm* comm);
+int atx_comm_rank(const atx_comm* comm);
+int atx_comm_world(const atx_comm* comm);
+/* buf[0..n_bytes) of rank `root` onto every rank, in place. */
+int atx_bcast(atx_comm* comm, void* buf, int64_t n_bytes, int32_t root, void* stream);
+/* send_ptrs / send_bytes / recv_ptrs / recv_bytes: HOST arrays of `world` entries, one per peer; entry p of the send
+ * side goes to rank p, entry p of the receive side is filled by rank p (byte counts must match pairwise across ranks;
+ * zero skips the pair; the own entry is a device-to-device copy). */
+int atx_exchange(atx_comm* comm, const void* const* send_ptrs, const int64_t* send_bytes, void* const* recv_ptrs,
+                 const int64_t* recv_bytes, void* stream);
+/* byte_offsets: HOST array of world + 1 non-decreasing offsets into buf; rank p owns [byte_offsets[p], byte_offsets[p+1])
+ * and has filled it; afterwards every rank holds all ranges (ATX_COLUMNS: a rank's target slice is such a range). */
+int atx_gather_shards(atx_comm* comm, void* buf, const int64_t* byte_offsets, void* stream);
 
 /* ---- measurement aid ------------------------------------------------------------ */
 /* dst[0..n_bytes) = src[0..n_bytes): a plain streaming copy, one 16-byte vector per lane, one workgroup per 4 KB, never

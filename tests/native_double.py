@@ -200,7 +200,42 @@ def select_levels(src, dst, level_map, *, n_pts, n_src_lev, src_pitch, dst_pitch
             d[j] = s[l]
 
 
-PATCHED = ["regrid_ell", "regrid_ell_batch", "regrid_csr", "check_indices", "pointwise_stack", "combine_stack", "mask_build", "mask_count", "mask_to_index",
+class KnnIndex:
+    """Brute-force stand-in for the device k-NN index: scipy's squared-distance arithmetic, candidates ordered by
+    (distance, source index) — the contract of ``atx_knn_query``."""
+
+    def __init__(self, src_xyz: torch.Tensor) -> None:
+        self.src = src_xyz.numpy()
+        self.n_src = len(self.src)
+
+    def query(self, tgt_xyz: torch.Tensor, k: int):
+        tgt = tgt_xyz.numpy()
+        idx = np.full((len(tgt), k), self.n_src, dtype=np.int32)
+        d2 = np.full((len(tgt), k), np.inf)
+        for t, x in enumerate(tgt):
+            diff = self.src - x
+            s = np.zeros(self.n_src)
+            for c in range(3):
+                s = s + diff[:, c] * diff[:, c]
+            order = np.lexsort((np.arange(self.n_src), s))[:k]
+            idx[t, : len(order)] = order
+            d2[t, : len(order)] = s[order]
+        return torch.from_numpy(idx), torch.from_numpy(d2)
+
+
+def cutout_inside(global_xyz, lam_xyz, neighbours):
+    g, lam, nb = global_xyz.numpy(), lam_xyz.numpy(), neighbours.numpy()
+    n, k = nb.shape
+    inside = np.zeros(n, dtype=np.uint8)
+    for i in range(n):
+        for j in range(k):
+            if oracle.triangle_intersect(lam[nb[i, j]], lam[nb[i, (j + 1) % k]], lam[nb[i, (j + 2) % k]], np.zeros(3), g[i]):
+                inside[i] = 1
+                break
+    return torch.from_numpy(inside)
+
+
+PATCHED = ["KnnIndex", "cutout_inside", "regrid_ell", "regrid_ell_batch", "regrid_csr", "check_indices", "pointwise_stack", "combine_stack", "mask_build", "mask_count", "mask_to_index",
            "reduce", "relayout", "reduce_stack", "select_levels"]
 
 

@@ -76,3 +76,78 @@ def test_vectorised_builders_equal_the_loop_restatement(seed):
     assert np.all(np.diff(a) > 0)  # sorted unique: what regrid(mask=...) consumes (R: spatial.py:533-536)
     box = spatial.cropping_mask(global_lats, global_lons, 50, 350, 30, 370)
     assert np.array_equal(box, oracle.cropping_mask(global_lats, global_lons, 50, 350, 30, 370)) and box.any()
+
+
+# ---- device k-NN wrapper: tie handling (host logic, through the CPU double of the kernel) --------------------------
+def _regular(dlat, dlon):
+    from anemoi_transform_amd.grids import regular_latlon_grid
+
+    return regular_latlon_grid(dlat, dlon)
+
+
+@pytest.mark.parametrize("k", [1, 3, 4])
+def test_device_knn_wrapper_settles_ties_like_ckdtree(monkeypatch, k):
+    """``interp.device_knn`` asks the kernel for k+1 neighbours, finds rows with exactly equidistant candidates and lets
+    cKDTree decide them: the table must EQUAL the reference statement's (R: spatial.py:628) — on a tie-heavy case, a
+    lat-lon source whose pole rows are dozens of coincident points, queried from a symmetric lat-lon target."""
+    import native_double
+    from anemoi_transform_amd import interp
+
+    native_double.install(monkeypatch)
+    src, tgt = _regular(15.0, 15.0), _regular(10.0, 10.0)
+    want_i, want_d = oracle.nearest_grid_points(src["latitudes"], src["longitudes"], tgt["latitudes"], tgt["longitudes"],
+                                                num_neighbours_to_return=k, return_distances=True)
+    got_i, got_d = interp.nearest_grid_points_device(src["latitudes"], src["longitudes"], tgt["latitudes"], tgt["longitudes"],
+                                                     num_neighbours_to_return=k, return_distances=True)
+    assert np.array_equal(got_i, want_i) and np.array_equal(got_d, want_d)
+    # the kernel's own order (lower index first) differs from cKDTree's on this case — the wrapper really had work to do
+    raw_i = interp.nearest_grid_points_device(src["latitudes"], src["longitudes"], tgt["latitudes"], tgt["longitudes"],
+                                              num_neighbours_to_return=k, ties="index")
+    if k > 1:  # (for k = 1 cKDTree happens to pick the lower index on this case too)
+        assert not np.array_equal(raw_i, want_i)
+    _, _, resolved = interp.device_knn(interp.unit_sphere_xyz(src["latitudes"], src["longitudes"]),
+                                       interp.unit_sphere_xyz(tgt["latitudes"], tgt["longitudes"]), k)
+    assert resolved <= len(tgt["latitudes"]) and (resolved > 0 or k == 1)
+
+
+def test_device_knn_wrapper_max_distance_and_arguments(monkeypatch):
+    import native_double
+    from anemoi_transform_amd import interp
+
+    native_double.install(monkeypatch)
+    src, tgt = _regular(30.0, 30.0), _regular(20.0, 20.0)
+    for k in (1, 2):
+        want = oracle.nearest_grid_points(src["latitudes"], src["longitudes"], tgt["latitudes"], tgt["longitudes"], max_distance=0.2,
+                                          num_neighbours_to_return=k, return_distances=True)
+        got = interp.nearest_grid_points_device(src["latitudes"], src["longitudes"], tgt["latitudes"], tgt["longitudes"],
+                                                max_distance=0.2, num_neighbours_to_return=k, return_distances=True)
+        assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1])
+        assert (want[0] == len(src["latitudes"])).any()  # some targets have no source within reach
+    xyz = interp.unit_sphere_xyz(src["latitudes"], src["longitudes"])
+    with pytest.raises(ValueError):
+        interp.device_knn(xyz, xyz, 17)
+    with pytest.raises(ValueError):
+        interp.device_knn(xyz, xyz, 2, ties="random")
+    i, d2, n = interp.device_knn(xyz, xyz[:0], 2)
+    assert i.shape == (0, 2) and d2.shape == (0, 2) and n == 0
+
+
+def test_cutout_mask_device_argument_errors_match_the_host_path(monkeypatch):
+    """``neighbours`` beyond the number of LAM points must fail as the host path does (IndexError from
+    indexing with cKDTree's padding index), never reach the kernel; beyond the kernel's 16 it is a ValueError."""
+    import native_double
+    from anemoi_transform_amd import spatial
+
+    native_double.install(monkeypatch)
+    lam_lats, lam_lons = np.array([45.0, 45.5, 46.0]), np.array([1.0, 2.0, 1.5])
+    g_lats, g_lons = np.array([45.4, 50.0, 44.0]), np.array([1.5, 1.0, 1.2])
+    with pytest.raises(IndexError):
+        spatial.cutout_mask(lam_lats, lam_lons, g_lats, g_lons, neighbours=4)
+    with pytest.raises(IndexError):
+        spatial.cutout_mask(lam_lats, lam_lons, g_lats, g_lons, neighbours=4, device=True)
+    lam = _regular(10.0, 10.0)
+    with pytest.raises(ValueError, match="neighbours <= 16"):
+        spatial.cutout_mask(lam["latitudes"][:200] * 0.1 + 45, lam["longitudes"][:200] * 0.05, g_lats, g_lons, neighbours=17, device=True)
+    a = spatial.cutout_mask(lam_lats, lam_lons, g_lats, g_lons, neighbours=3, device=True)
+    b = spatial.cutout_mask(lam_lats, lam_lons, g_lats, g_lons, neighbours=3)
+    assert np.array_equal(a, b) and np.array_equal(b, oracle.cutout_mask(lam_lats, lam_lons, g_lats, g_lons, neighbours=3))

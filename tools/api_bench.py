@@ -41,7 +41,7 @@ def main():
     torch.cuda.set_device(dev)
     L = 137
     src, tgt = lookup("o1280"), lookup("0.25")
-    idx, w = interp.knn_inverse_distance(src, tgt, k=4, device=True)
+    idx, w = interp.knn_inverse_distance(src, tgt, k=4, device=True, ties="index")
     matrix = {**interp.ell_to_csr(idx, w, len(src["latitudes"])), "out_latitudes": tgt["latitudes"], "out_longitudes": tgt["longitudes"]}
     x = bench.synth_stack(src, L, torch.float32, dev, 0, COLUMNS)
     template = ArrayField(np.zeros(1), {"param": "t"}, np.zeros(1), np.zeros(1))

@@ -31,7 +31,7 @@ def main():
     L = int(sys.argv[1]) if len(sys.argv) > 1 else 137
     src, tgt = lookup("o1280"), lookup("0.25")
     n_src, n_tgt = len(src["latitudes"]), len(tgt["latitudes"])
-    idx, w = interp.knn_inverse_distance(src, tgt, k=4, device=True)
+    idx, w = interp.knn_inverse_distance(src, tgt, k=4, device=True, ties="index")
     matrix = {**interp.ell_to_csr(idx, w, n_src), "out_latitudes": tgt["latitudes"], "out_longitudes": tgt["longitudes"]}
     rng = np.random.default_rng(3)
     host = [(280 + rng.standard_normal(n_src)).astype(np.float32) for _ in range(L)]

@@ -27,7 +27,7 @@ def main():
     torch.cuda.set_device(dev)
     src, tgt = lookup("o1280"), lookup("0.25")
     n_src, n_tgt = len(src["latitudes"]), len(tgt["latitudes"])
-    idx64, w64 = interp.knn_inverse_distance(src, tgt, k=4, device=True)
+    idx64, w64 = interp.knn_inverse_distance(src, tgt, k=4, device=True, ties="index")
     U = {4: int(np.unique(idx64).size), 1: int(np.unique(idx64[:, 0]).size)}
     for tdt, npdt, B, tag in ((torch.float32, np.float32, 4, "f32"), (torch.float64, np.float64, 8, "f64")):
         for L in (1, 4, 13, 37, 60, 137):

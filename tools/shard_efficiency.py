@@ -15,7 +15,7 @@ from anemoi_transform_amd.stack import COLUMNS, Stack
 dev = torch.device('cuda', 0); torch.cuda.set_device(dev)
 src, tgt = lookup('o1280'), lookup('0.25')
 n_src, n_tgt, L = len(src['latitudes']), len(tgt['latitudes']), 137
-idx, w = interp.knn_inverse_distance(src, tgt, k=4, device=True)
+idx, w = interp.knn_inverse_distance(src, tgt, k=4, device=True, ties="index")
 plan = GatherPlan(n_src, n_tgt, index=idx, weights=w)
 world = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 if len(sys.argv) > 2:  # try another weight of the shard cost model
