@@ -14,6 +14,11 @@ single-process loop.  The partitioning follows SURVEY.md §8e:
   ``exchange_source_bands``): in the column layout that band is one contiguous slab;
 * outputs stay sharded (``FieldList`` per rank); ``gather_target_shards``
   assembles the full field on every rank for callers that need it.
+
+Two transports, same functions: ``torch.distributed`` (default; ``comm=None``), or the library's own C-ABI
+communicator (``native.Comm`` = ``atx_comm_*`` of include/atx.h, RCCL bound directly) passed as ``comm=`` —
+the route a ctypes-only binder of the reference would take.  ``atx_comm_from_torch`` creates
+one inside a torch.distributed job (the unique id travels through the job's store).
 """
 
 from __future__ import annotations
@@ -43,26 +48,48 @@ def init_process_group(backend: str | None = None) -> tuple[int, int]:
     return dist.get_rank(), dist.get_world_size()
 
 
+def atx_comm_from_torch():
+    """A ``native.Comm`` (RCCL through the C ABI) spanning the ranks of the initialised torch.distributed job: rank 0
+    draws the unique id, the job's own transport (any backend) hands it round."""
+    from . import native
+
+    rank, world = dist.get_rank(), dist.get_world_size()
+    box = [native.Comm.unique_id() if rank == 0 else None]
+    if world > 1:
+        dist.broadcast_object_list(box, src=0)
+    return native.Comm(world, rank, box[0])
+
+
+def _rank_world(comm) -> tuple[int, int]:
+    if comm is not None:
+        return comm.rank, comm.world
+    return dist.get_rank(), dist.get_world_size()
+
+
 def broadcast_stack(stack: Stack | None, src: int, *, n_pts: int, n_lev: int, dtype: torch.dtype, device: torch.device,
-                    layout: int = COLUMNS) -> Stack:
+                    layout: int = COLUMNS, comm=None) -> Stack:
     """The source stack of rank ``src`` on every rank (one broadcast of the whole pitched tensor)."""
-    if dist.get_rank() == src:
+    rank, _ = _rank_world(comm)
+    if rank == src:
         assert stack is not None and (stack.n_pts, stack.n_lev, stack.layout) == (n_pts, n_lev, layout)
         buf = stack
     else:
         buf = Stack.empty(n_pts, n_lev, dtype, device, layout)
-    dist.broadcast(buf.data, src=src)
+    if comm is not None:
+        comm.bcast(buf.data, src)
+    else:
+        dist.broadcast(buf.data, src=src)
     return buf
 
 
-def exchange_stacks(mine: Stack) -> list[Stack]:
+def exchange_stacks(mine: Stack, comm=None) -> list[Stack]:
     """Every rank contributes one stack of identical shape; every rank ends up with all of them
     (``world`` broadcasts — the "source broadcast once" step of a target-sharded job)."""
-    rank, world = dist.get_rank(), dist.get_world_size()
+    rank, world = _rank_world(comm)
     out = []
     for r in range(world):
         out.append(broadcast_stack(mine if r == rank else None, r, n_pts=mine.n_pts, n_lev=mine.n_lev, dtype=mine.dtype,
-                                   device=mine.device, layout=mine.layout))
+                                   device=mine.device, layout=mine.layout, comm=comm))
     return out
 
 
@@ -85,7 +112,7 @@ def rebase_plan(plan: GatherPlan, lo: int, hi: int) -> GatherPlan:
     return GatherPlan(hi - lo, plan.n_tgt, csr=(plan.data, plan.indices.astype(np.int64) - lo, plan.indptr))
 
 
-def exchange_source_bands(mine: Stack, plan: GatherPlan) -> tuple[list[Stack], GatherPlan]:
+def exchange_source_bands(mine: Stack, plan: GatherPlan, comm=None) -> tuple[list[Stack], GatherPlan]:
     """Band-limited source exchange: every rank contributes one source stack and receives, from every
     rank, only the slab of source columns its own target slice references.
 
@@ -96,10 +123,14 @@ def exchange_source_bands(mine: Stack, plan: GatherPlan) -> tuple[list[Stack], G
     ``1/world`` of a stack plus the stencil margin, instead of ``world - 1`` whole stacks with a broadcast.
     """
     assert mine.layout == COLUMNS, "a band is a contiguous row range of a column stack"
-    rank, world = dist.get_rank(), dist.get_world_size()
+    rank, world = _rank_world(comm)
     ranges = [source_band(plan.shard(r, world)) for r in range(world)]  # same on every rank: the plan is replicated
     lo, hi = ranges[rank]
     bands = [Stack.empty(hi - lo, mine.n_lev, mine.dtype, mine.device, COLUMNS) for _ in range(world)]
+    if comm is not None:  # atx_exchange: one grouped send/recv, the own slab a device copy
+        comm.exchange([mine.data[r_lo:r_hi] if r_hi > r_lo else None for r_lo, r_hi in ranges],
+                      [b.data if hi > lo else None for b in bands])
+        return bands, rebase_plan(plan.shard(rank, world), lo, hi)
     bands[rank].data.copy_(mine.data[lo:hi])
     ops = []
     for r in range(world):
@@ -123,18 +154,42 @@ def sharded_regrid(plan: GatherPlan, src: Stack, rank: int | None = None, world:
     return plan.shard(rank, world).apply(src)
 
 
-def pipelined_sharded_regrid(plan: GatherPlan, mine: Stack) -> list[Stack]:
+def pipelined_sharded_regrid(plan: GatherPlan, mine: Stack, comm=None) -> list[Stack]:
     """End-to-end form of the target-sharded step: every rank contributes one source stack; the broadcast of stack
     ``r + 1`` runs (on the collective's own stream) while this rank interpolates its target slice of stack ``r``.
     Returns this rank's slice of every rank's stack, in rank order.  Two source buffers are alive at a time instead of
     ``world`` (SURVEY.md §7 "broadcast >> kernel": chunk by 137-level stack and double-buffer)."""
-    rank, world = dist.get_rank(), dist.get_world_size()
+    rank, world = _rank_world(comm)
     local = plan.shard(rank, world)
 
     def incoming(r: int) -> Stack:
         return mine if r == rank else Stack.empty(mine.n_pts, mine.n_lev, mine.dtype, mine.device, mine.layout)
 
     outs: list[Stack] = []
+    if comm is not None:
+        # the same pipeline on explicit HIP streams: broadcasts are enqueued on a side stream, the launch of stack r waits
+        # (on the device, via an event) for broadcast r only, so broadcast r + 1 runs under it
+        compute = torch.cuda.current_stream()
+        side = torch.cuda.Stream(device=mine.device)
+        side.wait_stream(compute)  # `mine` may still be being written by the compute stream
+
+        def start(r: int):
+            b = incoming(r)
+            with torch.cuda.stream(side):
+                comm.bcast(b.data, r)
+                done = torch.cuda.Event()
+                done.record(side)
+            b.data.record_stream(side)
+            return b, done
+
+        buf, done = start(0)
+        for r in range(world):
+            compute.wait_event(done)
+            current = buf
+            if r + 1 < world:
+                buf, done = start(r + 1)
+            outs.append(local.apply(current))
+        return outs
     buf = incoming(0)
     work = dist.broadcast(buf.data, src=0, async_op=True)
     for r in range(world):
@@ -147,12 +202,19 @@ def pipelined_sharded_regrid(plan: GatherPlan, mine: Stack) -> list[Stack]:
     return outs
 
 
-def gather_target_shards(local: Stack, plan: GatherPlan) -> Stack:
+def gather_target_shards(local: Stack, plan: GatherPlan, comm=None) -> Stack:
     """All target slices of ``plan`` on every rank (column layout: each slice is a contiguous row range)."""
     assert local.layout == COLUMNS, "target shards are row ranges of a column stack"
-    rank, world = dist.get_rank(), dist.get_world_size()
+    rank, world = _rank_world(comm)
     n_tgt = plan.n_tgt
     full = Stack.empty(n_tgt, local.n_lev, local.dtype, local.device, COLUMNS)
+    if comm is not None:  # atx_gather_shards: the slices are byte ranges of the column stack
+        bounds = plan.bounds(world)
+        assert local.n_pts == bounds[rank + 1] - bounds[rank]
+        full.data[bounds[rank]:bounds[rank + 1]].copy_(local.data)
+        row_bytes = full.pitch * full.data.element_size()
+        comm.gather_shards(full.data, [b * row_bytes for b in bounds])
+        return full
     for r in range(world):
         lo, hi = plan.shard_range(r, world)
         if r == rank:

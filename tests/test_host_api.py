@@ -423,7 +423,7 @@ def test_library_exports_every_declared_symbol():
 def test_abi_argument_validation_without_a_gpu():
     """Bad arguments are rejected before anything touches HIP, with the reference's exception types."""
     lib = native.load()
-    assert lib.atx_version() == 100
+    assert lib.atx_version() == 200
     assert lib.atx_strerror(native.ESHAPE) == b"shape mismatch"
     assert lib.atx_regrid_ell(None, None, None, None, 1, 1, 1, 1, 1, 1, 0, 0, 0, None, 0, None, None) == native.EINVAL
     assert b"null" in lib.atx_last_error()
@@ -437,6 +437,17 @@ def test_abi_argument_validation_without_a_gpu():
     assert lib.atx_mask_build(one, 1, one, 8, 99, 0.0, 0, None) == native.EINVAL
     assert lib.atx_relayout(one, one, 8, 4, 4, 8, 0, 1, 0, None) == native.EINVAL  # in place
     assert lib.atx_mask_to_index_workspace(4096 * 3) >= 16
+    # collective entry points: argument checks come before RCCL or HIP are touched
+    assert lib.atx_bcast(None, one, 16, 0, None) == native.EINVAL and b"communicator" in lib.atx_last_error()
+    assert lib.atx_comm_init(None, 1, 0, one) == native.EINVAL
+    handle = ctypes.c_void_p()
+    assert lib.atx_comm_init(ctypes.byref(handle), 2, 5, one) == native.EINVAL and b"rank 5" in lib.atx_last_error()
+    assert lib.atx_exchange(None, None, None, None, None, None) == native.EINVAL
+    assert lib.atx_gather_shards(None, one, None, None) == native.EINVAL
+    assert lib.atx_comm_destroy(None) == native.OK and lib.atx_comm_rank(None) == native.EINVAL
+    assert lib.atx_strerror(native.ECOMM).startswith(b"RCCL")
+    with pytest.raises(ValueError, match="128 bytes"):
+        native.Comm(1, 0, b"short")
     with pytest.raises(RuntimeError, match="HBM-resident"):
         import torch
 

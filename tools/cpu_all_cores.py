@@ -3,7 +3,8 @@
 `csr_array(k=4) @ x` (float64, R: regrid.py:310) over independent fields on W worker PROCESSES (scipy holds the GIL in
 csr_matvec, threads do not scale).  Touches no GPU; bench.py runs it as a child process and copies the JSON line.
 
-    python tools/cpu_all_cores.py --workers 16 --seconds 8
+    python tools/cpu_all_cores.py --seconds 8                      # os.cpu_count() workers
+    python tools/cpu_all_cores.py --sweep 16,32,64,128,256 --seconds 6   # one JSON line per worker count + the best
 """
 
 from __future__ import annotations
@@ -38,7 +39,8 @@ def _work(args):
 def main():
     global _matrix, _fields
     ap = argparse.ArgumentParser()
-    ap.add_argument("--workers", type=int, default=min(16, os.cpu_count() or 1))
+    ap.add_argument("--workers", type=int, default=os.cpu_count() or 1)
+    ap.add_argument("--sweep", default="", help="comma-separated worker counts: time each, print every line, then the best again")
     ap.add_argument("--seconds", type=float, default=8.0)
     ap.add_argument("--src-grid", default="o1280")
     ap.add_argument("--tgt-grid", default="0.25")
@@ -66,14 +68,33 @@ def main():
     _matrix @ _fields[0]
 
     ctx = mp.get_context("fork")  # workers inherit the matrix and the fields; nothing here has touched a GPU
-    with ctx.Pool(args.workers) as pool:
-        t0 = time.perf_counter()
-        deadline = t0 + args.seconds
-        done = sum(pool.map(_work, [(i, deadline) for i in range(args.workers)]))
-        elapsed = time.perf_counter() - t0
-    print(json.dumps({"value": done * n_tgt / elapsed, "unit": "grid-points/s", "cores": args.workers, "kind": "port",
-                      "fields": done, "seconds": elapsed, "ms_per_field_per_worker": elapsed * args.workers / max(done, 1) * 1e3,
-                      "host_logical_cores": os.cpu_count()}))
+
+    def cpu_quota():
+        try:  # cgroup v2 CPU quota of the box, in cores
+            quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+            return None if quota == "max" else float(quota) / float(period)
+        except Exception:
+            return None
+
+    def run(workers: int) -> dict:
+        with ctx.Pool(workers) as pool:
+            pool.map(_work, [(i, time.perf_counter() + 0.2) for i in range(workers)])  # all workers forked and warm
+            t0 = time.perf_counter()
+            deadline = t0 + args.seconds
+            done = sum(pool.map(_work, [(i, deadline) for i in range(workers)], chunksize=1))
+            elapsed = time.perf_counter() - t0
+        return {"value": done * n_tgt / elapsed, "unit": "grid-points/s", "cores": workers, "kind": "port", "fields": done,
+                "seconds": elapsed, "ms_per_field_per_worker": elapsed * workers / max(done, 1) * 1e3,
+                "host_logical_cores": os.cpu_count(), "usable_cores": len(os.sched_getaffinity(0)), "cpu_quota_cores": cpu_quota()}
+
+    if args.sweep:
+        results = [run(int(w)) for w in args.sweep.split(",")]
+        for r in results:
+            print(json.dumps(r), flush=True)
+        best = max(results, key=lambda r: r["value"])
+        print(json.dumps(dict(best, sweep={str(r["cores"]): r["value"] for r in results})))
+    else:
+        print(json.dumps(run(args.workers)))
 
 
 if __name__ == "__main__":
