@@ -48,6 +48,17 @@ def init_process_group(backend: str | None = None) -> tuple[int, int]:
     return dist.get_rank(), dist.get_world_size()
 
 
+_data_group = None  # process group that carries stacks (None = the default group)
+
+
+def set_data_group(group) -> None:
+    """Carry the stack traffic of this module on ``group`` (e.g. an ``nccl`` group = RCCL over xGMI) while the job's default
+    group stays a host-side one (``gloo``) for barriers and small reductions — how bench.py runs, so that its timing
+    skeleton does not depend on the collective library it measures."""
+    global _data_group
+    _data_group = group
+
+
 def atx_comm_from_torch():
     """A ``native.Comm`` (RCCL through the C ABI) spanning the ranks of the initialised torch.distributed job: rank 0
     draws the unique id, the job's own transport (any backend) hands it round."""
@@ -78,7 +89,7 @@ def broadcast_stack(stack: Stack | None, src: int, *, n_pts: int, n_lev: int, dt
     if comm is not None:
         comm.bcast(buf.data, src)
     else:
-        dist.broadcast(buf.data, src=src)
+        dist.broadcast(buf.data, src=src, group=_data_group)
     return buf
 
 
@@ -138,9 +149,9 @@ def exchange_source_bands(mine: Stack, plan: GatherPlan, comm=None) -> tuple[lis
             continue
         r_lo, r_hi = ranges[r]
         if r_hi > r_lo:
-            ops.append(dist.P2POp(dist.isend, mine.data[r_lo:r_hi], r))
+            ops.append(dist.P2POp(dist.isend, mine.data[r_lo:r_hi], r, group=_data_group))
         if hi > lo:
-            ops.append(dist.P2POp(dist.irecv, bands[r].data, r))
+            ops.append(dist.P2POp(dist.irecv, bands[r].data, r, group=_data_group))
     if ops:
         for work in dist.batch_isend_irecv(ops):
             work.wait()
@@ -191,13 +202,13 @@ def pipelined_sharded_regrid(plan: GatherPlan, mine: Stack, comm=None) -> list[S
             outs.append(local.apply(current))
         return outs
     buf = incoming(0)
-    work = dist.broadcast(buf.data, src=0, async_op=True)
+    work = dist.broadcast(buf.data, src=0, async_op=True, group=_data_group)
     for r in range(world):
         work.wait()  # the compute stream waits for broadcast r; the host does not block on the GPU
         current = buf
         if r + 1 < world:
             buf = incoming(r + 1)
-            work = dist.broadcast(buf.data, src=r + 1, async_op=True)  # overlaps with the launch below
+            work = dist.broadcast(buf.data, src=r + 1, async_op=True, group=_data_group)  # overlaps with the launch below
         outs.append(local.apply(current))
     return outs
 
@@ -221,5 +232,5 @@ def gather_target_shards(local: Stack, plan: GatherPlan, comm=None) -> Stack:
             assert local.n_pts == hi - lo
             full.data[lo:hi].copy_(local.data)
         if hi > lo:
-            dist.broadcast(full.data[lo:hi], src=r)
+            dist.broadcast(full.data[lo:hi], src=r, group=_data_group)
     return full

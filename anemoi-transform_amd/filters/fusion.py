@@ -127,7 +127,10 @@ def _run_segment(data: Any, head: RegridFilter | None, stages: list[Stage]) -> F
             return FieldList(out)
         for group in group_into_stacks(fields, positions, sparse_ok=True):
             src = group.stack
-            group_mask = None if mask is None else mask.for_fields(group.fields, src.n_pts)
+            # the point mask belongs to the fields some stage masks; a group none of whose operators uses it (another grid,
+            # say) must not be measured against it — filter by filter those fields never meet the mask either
+            needs_mask = mask is not None and any(row[p][1] for row in ops for p in group.positions)
+            group_mask = mask.for_fields(group.fields, src.n_pts) if needs_mask else None
             dst = src.new_like()
             stages = []
             for row in ops:
@@ -155,8 +158,8 @@ def _run_segment(data: Any, head: RegridFilter | None, stages: list[Stage]) -> F
             plan, lat, lon = interp._sharded(plan, head.shard), lat[lo:hi], lon[lo:hi]
         kwargs = {}
         if any(touched[p] for p in group.positions):
-            tgt_mask = mask
-            if mask is not None and mask.n_points != plan.n_tgt:
+            tgt_mask = mask if any(row[p][1] for row in ops for p in group.positions) else None  # only groups that use it
+            if tgt_mask is not None and mask.n_points != plan.n_tgt:
                 if window is None or mask.n_points != full_targets:
                     raise IndexError(f"boolean index did not match indexed array: mask has {mask.n_points} points, field has {plan.n_tgt}")
                 tgt_mask = mask.window(window[0], window[1])  # a full-grid mask on this rank's slice of the targets

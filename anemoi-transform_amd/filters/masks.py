@@ -70,14 +70,10 @@ class MaskVariable(Filter):
         param: str | list[str] | None = None,
         return_mask: bool = False,
     ) -> None:
-        self.path = path
-        self.mask_param = mask_param
-        self.mask_value = mask_value
-        self.threshold = threshold
-        self.threshold_operator = threshold_operator
-        self.rename = rename
-        self.param = param if not isinstance(param, str) else [param]
-        self.return_mask = return_mask
+        # the configuration is kept as plain attributes (the reference's filters expose their config that way, R: filter.py:184-186)
+        vars(self).update(path=path, mask_param=mask_param, mask_value=mask_value, threshold=threshold,
+                          threshold_operator=threshold_operator, rename=rename, return_mask=return_mask)
+        self.param = [param] if isinstance(param, str) else param
         self.mask: PointMask | None = None
         self._file_values: np.ndarray | None = None
         self.prepare_filter()
@@ -119,17 +115,13 @@ class MaskVariable(Filter):
                     host = host.astype(np.float64)
                 self.mask = self._compute_mask(torch.from_numpy(np.ascontiguousarray(host)).to(_stack.device()), 1, host.size)
             return self.mask, list(fields)
-        mask_field = None
-        remaining = []
-        for field in fields:
-            if field.metadata("param") == self.mask_param:
-                if mask_field is None:
-                    mask_field = field
-                if not self.return_mask:
-                    continue
-            remaining.append(field)
-        if mask_field is None:
+        # the mask is the FIRST field carrying `mask_param`; every field of that name leaves the stream unless `return_mask`
+        fields = list(fields)
+        is_mask = [f.metadata("param") == self.mask_param for f in fields]
+        if not any(is_mask):
             raise ValueError(f"Mask parameter '{self.mask_param}' not found in input data.")
+        mask_field = fields[is_mask.index(True)]
+        remaining = fields if self.return_mask else [f for f, m in zip(fields, is_mask) if not m]
         return self._compute_mask(*_level_tensor(mask_field)), remaining
 
     def forward_transform(self, field: Any) -> Any:

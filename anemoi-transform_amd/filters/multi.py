@@ -23,7 +23,6 @@ from __future__ import annotations
 import logging
 from abc import abstractmethod
 from collections import defaultdict
-from dataclasses import dataclass, replace
 from inspect import signature
 from itertools import chain
 from typing import Any, Callable, Iterable, Iterator
@@ -39,49 +38,67 @@ from ..grouping import GroupByParam, GroupByParamVertical
 LOG = logging.getLogger(__name__)
 
 
-@dataclass(frozen=True)
+def _names(value: Any) -> tuple[str, ...]:
+    """A single name or any iterable of names, as a tuple."""
+    if isinstance(value, str):
+        return (value,)
+    try:
+        return tuple(value)
+    except TypeError as e:
+        raise TypeError(f"Expected str or iterable, got {type(value)}") from e
+
+
 class MatchingSpec:
-    """Which constructor arguments name the forward / backward operands (R: matching.py:35-81)."""
+    """Which constructor arguments of a filter name its forward / backward operands, and which of the matched input
+    fields are passed on next to the results (R: matching.py:35-81 — same arguments, same errors).
 
-    select: str = "param"
-    forward: tuple[str, ...] = ()
-    backward: tuple[str, ...] = ()
-    return_inputs: Any = "none"  # "all" | "none" | tuple of operand names
-    vertical: bool = False
+    Immutable value object: ``forward`` / ``backward`` are tuples of argument names; ``return_inputs`` is ``"all"``,
+    ``"none"`` or a tuple of operand names (a subset of forward + backward); ``vertical`` groups by level type too.
+    """
 
-    @staticmethod
-    def _to_tuple_of_str(x: Any) -> tuple[str, ...]:
-        if isinstance(x, str):
-            return (x,)
-        try:
-            return tuple(x)
-        except TypeError as e:
-            raise TypeError(f"Expected str or iterable, got {type(x)}") from e
+    __slots__ = ("select", "forward", "backward", "return_inputs", "vertical")
+    _KEYWORDS = ("all", "none")
 
-    def __post_init__(self) -> None:
-        if self.select != "param":
+    def __init__(self, select: str = "param", forward: Any = (), backward: Any = (), return_inputs: Any = "none",
+                 vertical: bool = False) -> None:
+        if select != "param":
             raise NotImplementedError("Only 'select=param' is supported for now.")
-        object.__setattr__(self, "forward", self._to_tuple_of_str(self.forward))
-        object.__setattr__(self, "backward", self._to_tuple_of_str(self.backward))
-        if self.return_inputs not in ("all", "none"):
-            object.__setattr__(self, "return_inputs", self._to_tuple_of_str(self.return_inputs))
-            all_params = set(self.forward) | set(self.backward)
-            if not set(self.return_inputs).issubset(all_params):
-                raise ValueError(f"Returned input names must subset {all_params}")
+        fwd, bwd = _names(forward), _names(backward)
+        kept = return_inputs if return_inputs in self._KEYWORDS else _names(return_inputs)
+        if kept not in self._KEYWORDS:
+            operands = set(fwd) | set(bwd)
+            if set(kept) - operands:
+                raise ValueError(f"Returned input names must subset {operands}")
+        for name, value in zip(self.__slots__, (select, fwd, bwd, kept, bool(vertical))):
+            object.__setattr__(self, name, value)
+
+    def __setattr__(self, name: str, value: Any) -> None:
+        raise AttributeError(f"MatchingSpec is immutable (tried to set {name!r})")
+
+    def _key(self) -> tuple:
+        return tuple(getattr(self, name) for name in self.__slots__)
+
+    def __eq__(self, other: Any) -> bool:
+        return isinstance(other, MatchingSpec) and self._key() == other._key()
+
+    def __hash__(self) -> int:
+        return hash(self._key())
+
+    def __repr__(self) -> str:
+        return "MatchingSpec(" + ", ".join(f"{name}={getattr(self, name)!r}" for name in self.__slots__) + ")"
 
     def update_return_inputs(self, return_inputs: Any) -> "MatchingSpec":
-        if return_inputs not in ("all", "none"):
-            return_inputs = self._to_tuple_of_str(return_inputs)
-        if return_inputs == self.return_inputs:
+        """This spec with another ``return_inputs`` (``self`` if nothing changes)."""
+        kept = return_inputs if return_inputs in self._KEYWORDS else _names(return_inputs)
+        if kept == self.return_inputs:
             return self
-        return replace(self, return_inputs=return_inputs)
+        return MatchingSpec(self.select, self.forward, self.backward, kept, self.vertical)
 
     def inputs(self, direction: str) -> tuple[str, ...]:
-        if self.return_inputs == "all":
-            return tuple(getattr(self, direction))
+        """Names of the operands of ``direction`` ("forward" / "backward") whose fields are returned with the results."""
         if self.return_inputs == "none":
             return ()
-        return self.return_inputs
+        return tuple(getattr(self, direction)) if self.return_inputs == "all" else self.return_inputs
 
 
 def inputs_generator(input_list: Iterable[str], **kwargs: Any) -> Iterator[Any]:

@@ -88,26 +88,51 @@ class _Interpolator:
 
 
 class EarthkitRegrid(_Interpolator):
-    """Default interpolator of the reference: delegates to ``earthkit.regrid.interpolate``, which
-    fetches a pre-generated MIR matrix from a remote inventory (R: regrid.py:211-259).  That
-    third-party path is unavailable offline: constructing it raises unless
-    earthkit-regrid is importable; use ``matrix=`` (see ``interp``) or ``method="nearest"``."""
+    """The reference's DEFAULT interpolator (``method`` not given, or anything but ``"nearest"`` —
+    R: regrid.py:455-467): there it hands each field to ``earthkit.regrid.interpolate(values, in_grid=, out_grid=,
+    method="linear")`` (R: regrid.py:233-259), a third-party package that downloads a pre-computed MIR matrix for the
+    grid pair from a remote inventory and applies it as a sparse matrix-vector product.
+
+    Neither the package nor its inventory exists offline, so the MATRIX is built in-tree instead and runs on the same
+    HBM gather as ``matrix=``: for ``method="linear"`` between formula grids (``O<N>``, ``F<N>``, ``N320-sized``, regular
+    lat-lon increments as the source; any resolvable grid as the target) the 4-point bilinear weights of
+    ``interp.bilinear_rows``.  MIR's linear method triangulates the source points (3 weights per target) — same order of
+    accuracy, not the same numbers: **parity with MIR is unpinned** (SURVEY.md §8c names this boundary as unpinned in the
+    reference's own tests, too: tests/field_filters/test_regrid.py:83-88 is a smoke test).  A warning says so once per
+    filter.  Every other method / grid raises ``NotImplementedError`` pointing at ``matrix=``.
+    """
 
     def __init__(self, *, in_grid: Any, out_grid: Any, method: str = "linear", check: bool = False) -> None:
+        from ..grids import row_structure
+        from ..interp import bilinear_rows
+
         self.in_grid = as_gridspec(in_grid)
         self.out_grid = as_gridspec(out_grid)
         self.method = method
         if check:
             LOG.warning("Check is not supported by EarthkitRegrid")
-        try:
-            import earthkit.regrid  # type: ignore # noqa: F401
-        except ImportError as e:
+        rows = row_structure(self.in_grid)
+        if method != "linear" or rows is None:
             raise NotImplementedError(
-                f"regrid(method={method!r}) needs earthkit-regrid and its remote matrix inventory, which are not "
-                "available here; pass a pre-computed `matrix` (anemoi_transform_amd.interp writes the same npz "
-                "format) or use method='nearest'"
-            ) from e
-        raise NotImplementedError("earthkit-regrid matrices are not wired to the HBM path yet; pass `matrix=`")
+                f"regrid(method={method!r}, in_grid={in_grid!r}) needs earthkit-regrid and its remote matrix inventory, which are "
+                "not available here; the in-tree default covers method='linear' from O<N> / F<N> / regular lat-lon source grids. "
+                "Pass a pre-computed `matrix` (anemoi_transform_amd.interp writes the same npz format) or use method='nearest'"
+            )
+        self.out_griddata = as_griddata(out_grid) or {}
+        if "latitudes" not in self.out_griddata:
+            raise ValueError("out_grid is required, but not provided")
+        LOG.warning("regrid(method='linear'): in-tree 4-point bilinear weights stand in for earthkit-regrid's MIR matrix "
+                    "(remote inventory unavailable); values agree with MIR to interpolation accuracy, not bit for bit")
+        self.plan = GatherPlan.from_matrix(bilinear_rows(*rows, self.out_griddata))
+
+    def plan_for(self, first_field: Any) -> GatherPlan:
+        n = int(np.prod(first_field.shape))
+        if n != self.plan.n_src:
+            raise ValueError(f"field has {n} points, in_grid {self.in_grid['grid']!r} has {self.plan.n_src}")
+        return self.plan
+
+    def out_latlon(self, first_field: Any):
+        return self.out_griddata["latitudes"], self.out_griddata["longitudes"]
 
 
 class MIRMatrix(_Interpolator):

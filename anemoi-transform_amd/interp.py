@@ -27,6 +27,7 @@ __all__ = [
     "ell_to_csr",
     "csr_uniform_k",
     "bilinear_octahedral",
+    "bilinear_rows",
     "save_matrix_npz",
     "load_matrix_npz",
 ]
@@ -220,16 +221,19 @@ def csr_uniform_k(indptr: np.ndarray) -> int | None:
     return None
 
 
-def bilinear_octahedral(n: int, out_grid: dict) -> dict[str, np.ndarray]:
-    """Bilinear weights from the octahedral grid ``O<n>`` to arbitrary target points.
+def bilinear_rows(row_latitudes: np.ndarray, row_lengths: np.ndarray, out_grid: dict) -> dict[str, np.ndarray]:
+    """Bilinear weights from a ROW-STRUCTURED global grid (rows of constant latitude, north to south, row ``r`` holding
+    ``row_lengths[r]`` equally spaced longitudes starting at 0 — octahedral / classic reduced / full Gaussian and regular
+    lat-lon grids) to arbitrary target points.
 
-    Two bracketing Gaussian rows x two bracketing longitudes per row (periodic),
-    linear in longitude on each row, then linear in latitude; above the first /
-    below the last row the nearest row is used alone.  Always 4 entries per target
-    (zero weights are kept) so the matrix is fixed-k.
+    Two bracketing rows x two bracketing longitudes per row (periodic), linear in longitude on each row, then linear in
+    latitude; above the first / below the last row the nearest row is used alone.  Always 4 entries per target (zero
+    weights are kept) so the matrix is fixed-k.
     """
-    lats = gaussian_latitudes(2 * n)  # north -> south
-    nlon = octahedral_row_lengths(n)
+    lats = np.asarray(row_latitudes, dtype=np.float64)  # north -> south
+    nlon = np.asarray(row_lengths, dtype=np.int64)
+    if lats.ndim != 1 or lats.shape != nlon.shape or len(lats) < 1 or np.any(np.diff(lats) >= 0) or np.any(nlon < 1):
+        raise ValueError("rows must be given north to south with strictly decreasing latitudes and positive lengths")
     row_start = np.concatenate([[0], np.cumsum(nlon)[:-1]])
     tlat = np.asarray(out_grid["latitudes"], dtype=np.float64)
     tlon = np.mod(np.asarray(out_grid["longitudes"], dtype=np.float64), 360.0)
@@ -257,6 +261,11 @@ def bilinear_octahedral(n: int, out_grid: dict) -> dict[str, np.ndarray]:
         w[:, 2 * slot] = w_row * (1.0 - frac)
         w[:, 2 * slot + 1] = w_row * frac
     return ell_to_csr(idx, w, int(nlon.sum()))
+
+
+def bilinear_octahedral(n: int, out_grid: dict) -> dict[str, np.ndarray]:
+    """``bilinear_rows`` from the octahedral grid ``O<n>`` (BASELINE config 2: O96 -> 1 degree)."""
+    return bilinear_rows(gaussian_latitudes(2 * n), octahedral_row_lengths(n), out_grid)
 
 
 def save_matrix_npz(path: str, matrix: dict[str, np.ndarray], in_grid: dict, out_grid: dict) -> None:

@@ -5,24 +5,27 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
-A *step* is one pass of the regrid hot path over one batch of synthetic input
-already resident in HBM: at N = 1 one 137-level stack on the O1280 octahedral
-grid (6 599 680 points) is interpolated to the 0.25 degree lat-lon grid
-(1 038 240 points) with k = 4 inverse-distance weights from cKDTree (BASELINE.json
-configs[2], the config the metric is quoted on), float32, one `atx_regrid_ell`
-launch.  At N > 1 (weak scaling, one process per GPU) the job is N such stacks
-(N variables x 137 levels); the source stacks are exchanged ONCE by RCCL
-broadcasts before the timed region (reported as `source_exchange_ms`), and the
-target points are sharded N ways: every rank interpolates its 1/N slice of the
-target grid for all N stacks — N launches per step, no collective in the data
-path.  value = point-fields all ranks produced / max-over-ranks wall time.
+A *step* is one pass of the regrid hot path over one batch of synthetic input already resident in HBM: at N = 1 one
+137-level stack on the O1280 octahedral grid (6 599 680 points) is interpolated to the 0.25 degree lat-lon grid
+(1 038 240 points) with k = 4 inverse-distance weights from cKDTree (BASELINE.json configs[2], the configuration the
+metric is quoted on), float32, one `atx_regrid_ell` launch.
 
-Also reported on the same JSON line:
-  roofline     algorithmic bytes of one launch / its average HIP-event duration,
-               against the 8 TB/s HBM3E peak
-  cpu_baseline the oracle's scipy `csr_array @ x` statement (the reference's CPU
-               path, R: filters/fields/regrid.py:310) timed on one host core on a
-               bounded sample of the same workload (rank 0, N = 1 only)
+N > 1 (weak scaling, one process per GPU): the job is N such stacks (N variables x 137 levels) and the target points
+are sharded N ways — every rank interpolates its traffic-balanced 1/N slice of the target grid for all N stacks in ONE
+batched launch per step; no collective in the data path.  `value` = point-fields all ranks produced / max-over-ranks
+wall time of the K steps, with the N source stacks already resident on every rank (that is what "inputs resident in
+HBM" means for a target-sharded job).  What it costs to GET them there is measured in the same run and reported next
+to `value`, never inside it: `source_exchange_ms.broadcast` (N RCCL broadcasts of 3.7 GB), `source_exchange_ms.bands`
+(band-limited RCCL send/recv), each verified bit-equal against the stacks the rank synthesised itself, and
+`end_to_end` — one step INCLUDING the exchange, broadcast r+1 overlapped with launch r.  `strong` is the fixed-total-
+work line (ONE stack split over the N ranks) and `field_axis_sharding` the exchange-free alternative.
+Host-side barriers and the max-over-ranks reduction run on a gloo group, stack traffic on an nccl (= RCCL) group.
+
+Also on the same JSON line:
+  roofline     algorithmic bytes of one launch / its average HIP-event duration against the 8 TB/s HBM3E peak
+  cpu_baseline the oracle's scipy `csr_array @ x` statement (the reference's CPU path, R: filters/fields/regrid.py:310)
+               timed on one host core on a bounded sample of the same workload (rank 0, N = 1 only)
+  extras       (N = 1) k = 1, f64, field-major, fused epilogue, BASELINE configs 2 and 4, the device k-NN build, all-core CPU
 """
 
 from __future__ import annotations
@@ -31,6 +34,7 @@ import argparse
 import json
 import os
 import sys
+import threading
 import time
 
 import numpy as np
@@ -58,22 +62,21 @@ def parse_args():
     ap.add_argument("--layout", default="columns", choices=["columns", "fields"])
     ap.add_argument("--tile", type=int, default=0, help="targets per workgroup (0 = library default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-extras", action="store_true", help="skip the secondary k=1 / f64 / field-major lines")
+    ap.add_argument("--no-extras", action="store_true", help="skip the secondary lines (N = 1: extras; N > 1: exchange / end-to-end / strong)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline sample")
-    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="collective backend for N > 1 (nccl = RCCL)")
-    ap.add_argument("--exchange", default="broadcast", choices=["broadcast", "bands"],
-                    help="N > 1 source exchange before timing: whole stacks by RCCL broadcast, or only the band of source columns "
-                         "each rank's target slice references by send/recv (distributed.exchange_source_bands)")
-    ap.add_argument("--end-to-end", action="store_true",
-                    help="N > 1: also time one step INCLUDING the source exchange, broadcasts double-buffered against the launches "
-                         "(distributed.pipelined_sharded_regrid); reported as `end_to_end`, never as `value`")
+    ap.add_argument("--cpu-workers", type=int, default=0,
+                    help="worker processes of extras.cpu_all_cores (0 = all cores this process may use: os.cpu_count() capped by the cgroup quota)")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="N > 1: backend of the group that carries the stacks (nccl = RCCL over xGMI); barriers always run on gloo")
+    ap.add_argument("--secondary-seconds", type=float, default=240.0,
+                    help="N > 1: wall-clock budget of the lines measured after `value`; when it runs out the JSON line is printed with what is there")
     ap.add_argument("--share-device", action="store_true",
                     help="REHEARSAL ONLY: all ranks use cuda:0 (exercises the N > 1 code path on a 1-GPU box; needs --backend gloo)")
     return ap.parse_args()
 
 
 def synth_stack(grid, n_lev, dtype, dev, stack_id, layout):
-    """v[l, p] = 280 + 30 sin(lat) cos(2 lon + 0.1 l) + N(0, 1)   (SURVEY.md §8d), built in HBM."""
+    """v[l, p] = 280 + 30 sin(lat) cos(2 lon + 0.1 l) + N(0, 1)   (SURVEY.md §8d), built in HBM; a pure function of stack_id."""
     from anemoi_transform_amd.stack import COLUMNS, Stack
 
     n_pts = len(grid["latitudes"])
@@ -102,7 +105,7 @@ def algorithmic_bytes(n_lev, itemsize, n_unique, n_tgt, k):
 
 
 def time_launches(fn, steps, warmup):
-    """Average HIP-event duration (ms) of `fn` (one launch) on the current stream."""
+    """Average HIP-event duration (ms) of `fn` (one launch) on the current stream — the stream libatx launches on."""
     for _ in range(warmup):
         fn()
     torch.cuda.synchronize()
@@ -114,6 +117,11 @@ def time_launches(fn, steps, warmup):
     torch.cuda.synchronize()
     ms = [a.elapsed_time(b) for a, b in evs]
     return float(np.mean(ms)), float(np.min(ms))
+
+
+def line(n_units, ms, alg_bytes):
+    gbs = alg_bytes / (ms * 1e-3) / 1e9
+    return {"value": n_units / (ms * 1e-3), "avg_launch_ms": ms, "achieved_GBs": gbs, "frac": gbs / HBM_PEAK_GBS}
 
 
 def main():
@@ -128,6 +136,7 @@ def main():
 
     graft.load_package()
     from anemoi_transform_amd import native
+    from anemoi_transform_amd.gather import GatherPlan
     from anemoi_transform_amd.grids import lookup
     from anemoi_transform_amd.interp import knn_inverse_distance
     from anemoi_transform_amd.stack import COLUMNS, FIELDS, Stack
@@ -136,15 +145,24 @@ def main():
     assert torch.cuda.is_available(), "bench.py needs an MI355X"
     dev = torch.device("cuda", 0 if args.share_device else local_rank)
     torch.cuda.set_device(dev)
+    dist = None
     if world > 1:
         import torch.distributed as dist
 
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        if args.backend == "nccl":
-            assert not args.share_device, "RCCL needs one GPU per rank"
-            dist.init_process_group("nccl", device_id=dev)  # RCCL over xGMI
-        else:
-            dist.init_process_group("gloo")
+        assert not (args.share_device and args.backend == "nccl"), "RCCL needs one GPU per rank"
+        dist.init_process_group("gloo")  # host-side: barriers, the max-over-ranks of the elapsed time
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    def max_over_ranks(seconds: float) -> float:
+        if world == 1:
+            return seconds
+        t = torch.tensor([seconds], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
 
     tdtype = torch.float32 if args.dtype == "f32" else torch.float64
     np_dtype = np.float32 if args.dtype == "f32" else np.float64
@@ -163,69 +181,40 @@ def main():
 
     # target-point shard of this rank: contiguous, balanced by HBM traffic (GatherPlan.bounds) — equal-count
     # shards of a lat-lon target are 1.8x apart in cost (polar targets share their source columns)
-    from anemoi_transform_amd.gather import GatherPlan
-
     plan = GatherPlan(n_src, n_tgt, index=idx64, weights=w64)
     bounds = plan.bounds(world)
     lo, hi = bounds[rank], bounds[rank + 1]
-    # ---- sources resident in HBM before the timed region
-    mine = synth_stack(src_grid, args.levels, tdtype, dev, rank, layout)
-    stacks = [mine]
-    exchange_ms = None
-    band_lo, n_src_local = 0, n_src
-    if world > 1:
-        torch.cuda.synchronize()
-        dist.barrier()
-        t0 = time.perf_counter()
-        if args.exchange == "bands":
-            from anemoi_transform_amd.distributed import exchange_source_bands, source_band
 
-            stacks, _ = exchange_source_bands(mine, plan)
-            band_lo, band_hi = source_band(plan.shard(rank, world))
-            n_src_local = band_hi - band_lo
-            del mine
-        else:
-            stacks = []
-            for r in range(world):
-                buf = mine if r == rank else Stack.empty(n_src, args.levels, tdtype, dev, layout)
-                dist.broadcast(buf.data, src=r)  # the one-off source exchange (RCCL)
-                stacks.append(buf)
-        torch.cuda.synchronize()
-        dist.barrier()
-        exchange_ms = (time.perf_counter() - t0) * 1e3
-    idx_d = torch.from_numpy((idx64[lo:hi] - band_lo).astype(np.int32)).to(dev)
+    # ---- sources resident in HBM before the timed region: the N stacks of the step, each a pure function of its id
+    stacks = [synth_stack(src_grid, args.levels, tdtype, dev, r, layout) for r in range(world)]
+    idx_d = torch.from_numpy(idx64[lo:hi].astype(np.int32)).to(dev)
     w_d = torch.from_numpy(w64[lo:hi].astype(np_dtype)).to(dev)
-    assert native.check_indices(idx_d, n_src_local) == 0
+    assert native.check_indices(idx_d, n_src) == 0
     outs = [Stack.empty(hi - lo, args.levels, tdtype, dev, layout) for _ in stacks]
-    weighted = args.k > 1
 
     def launch(src, out, idx=idx_d, w=w_d, k=args.k, n_t=hi - lo):
-        native.regrid_ell(src.data, out.data, idx, w if weighted or k > 1 else None, n_src=n_src_local, n_tgt=n_t, k=k,
+        native.regrid_ell(src.data, out.data, idx, w if k > 1 else None, n_src=n_src, n_tgt=n_t, k=k,
                           n_lev=src.n_lev, src_pitch=src.pitch, out_pitch=out.pitch, layout=src.layout)
 
     def step():  # one launch over all stacks of the step (atx_regrid_ell_batch: grid.y = stack)
         if len(stacks) == 1:
             launch(stacks[0], outs[0])
         else:
-            native.regrid_ell_batch([s.data for s in stacks], [o.data for o in outs], idx_d, w_d, n_src=n_src_local, n_tgt=hi - lo,
+            native.regrid_ell_batch([s.data for s in stacks], [o.data for o in outs], idx_d, w_d, n_src=n_src, n_tgt=hi - lo,
                                     k=args.k, n_lev=args.levels, src_pitch=stacks[0].pitch, out_pitch=outs[0].pitch, layout=layout)
 
     # ---- timed region: W warm-up steps, then exactly K steps between barriers
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
+    barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    if world > 1:
-        dist.barrier()
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    barrier()
+    elapsed = max_over_ranks(elapsed)
 
     units_per_step = n_tgt * args.levels * world  # all ranks together: N stacks x the full target grid (shards tile it)
     value = units_per_step * args.steps / elapsed
@@ -237,13 +226,17 @@ def main():
     shard_unique = int(np.unique(idx64[lo:hi]).size)
     alg = algorithmic_bytes(args.levels, itemsize, shard_unique, hi - lo, args.k) * (len(stacks) if one_launch else 1)
     achieved = alg / (avg_ms * 1e-3) / 1e9
-    traffic = None
+    traffic, traffic_source = None, None
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tpath):
         try:
             rec = json.load(open(tpath))
             key = f"{args.src_grid}->{args.tgt_grid} k={args.k} L={args.levels} {args.dtype} {args.layout} gpus={world}"
-            traffic = rec.get(key, {}).get("hbm_bytes_per_launch")
+            if key in rec:
+                traffic = rec[key].get("hbm_bytes_per_launch")
+                # NOT measured by this process: PMC counters need rocprofv3 around the run (tools/pmc_probe.py)
+                traffic_source = ("carried from profiles/traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this same "
+                                  f"launch ({rec[key].get('measured', rec.get('_measured', 'round 1'))}), not re-measured in this run")
         except Exception:
             traffic = None
 
@@ -265,9 +258,12 @@ def main():
                         f"k={args.k} inverse-distance regrid x {args.levels} levels per stack",
             "layout": args.layout,
             "stacks_per_step": world,
-            "sharding": ("target points over ranks (contiguous, traffic-balanced); sources exchanged once before timing by "
-                         + ("RCCL broadcast" if args.exchange == "broadcast" else "band-limited send/recv")) if world > 1 else "single GPU",
+            "sharding": ("target points over ranks (contiguous, traffic-balanced), every rank holds the N source stacks before the timed "
+                         "region; `value` EXCLUDES the source exchange, which is measured beside it (source_exchange_ms, end_to_end)")
+                        if world > 1 else "single GPU",
             "launches_per_step_per_gpu": 1 if layout == COLUMNS else world,
+            **({"collectives": f"stacks: {args.backend} group ({'RCCL over xGMI' if args.backend == 'nccl' else 'gloo'}); "
+                               "barriers and the max-over-ranks of the elapsed time: gloo group"} if world > 1 else {}),
             **({"rehearsal": "ranks share one GPU over gloo; not a scaling measurement"} if args.share_device else {}),
         },
         "roofline": {
@@ -278,6 +274,7 @@ def main():
             "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS,
             "traffic": traffic,
+            "traffic_source": traffic_source,
             "algorithmic_bytes_per_launch": alg,
             "avg_launch_ms": avg_ms,
             "min_launch_ms": min_ms,
@@ -285,153 +282,328 @@ def main():
         },
         "precompute_s": precompute_s,
     }
-    if world > 1 and args.exchange == "broadcast":
-        # comparison point (axis 2): shard the FIELDS instead of the target points — every rank interpolates the
-        # whole target grid of its own stack, nothing is exchanged at all.  Same units per step; reported next to `value`.
-        try:
-            full_idx = torch.from_numpy(idx64.astype(np.int32)).to(dev)
-            full_w = torch.from_numpy(w64.astype(np_dtype)).to(dev)
-            own, full_out = stacks[rank], Stack.empty(n_tgt, args.levels, tdtype, dev, layout)
 
-            def own_step():
-                launch(own, full_out, idx=full_idx, w=full_w, n_t=n_tgt)
-
-            for _ in range(args.warmup):
-                own_step()
-            torch.cuda.synchronize()
-            dist.barrier()
-            t0 = time.perf_counter()
-            for _ in range(args.steps):
-                own_step()
-            torch.cuda.synchronize()
-            t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            result["field_axis_sharding"] = {"value": units_per_step * args.steps / float(t.item()), "unit": "grid-points/s",
-                                             "ms_per_step": float(t.item()) / args.steps * 1e3,
-                                             "note": "each rank regrids its own stack to the full target grid; no source exchange"}
-            del full_idx, full_w, full_out
-        except Exception as e:  # a comparison line must never take the bench line down
-            result["field_axis_sharding"] = {"error": f"{type(e).__name__}: {e}"}
-    if world > 1 and args.end_to_end and layout == COLUMNS:
-        from anemoi_transform_amd.distributed import pipelined_sharded_regrid
-
-        del outs
-        torch.cuda.empty_cache()
-        mine_again = synth_stack(src_grid, args.levels, tdtype, dev, rank, layout)
-        pipelined_sharded_regrid(plan, mine_again)  # warm-up (communicator, allocations)
-        torch.cuda.synchronize()
-        dist.barrier()
-        t0 = time.perf_counter()
-        pipelined_sharded_regrid(plan, mine_again)
-        torch.cuda.synchronize()
-        t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        result["end_to_end"] = {"ms_per_step": float(t.item()) * 1e3, "value": units_per_step / float(t.item()), "unit": "grid-points/s",
-                                "note": "one step including the exchange of the N source stacks (broadcast r+1 overlapped with launch r)"}
-    if exchange_ms is not None:
-        result["source_exchange_ms"] = exchange_ms
-        result["source_exchange"] = args.exchange
-        result["source_bytes_held_per_gpu"] = sum(s.data.numel() * s.data.element_size() for s in stacks)
+    if world > 1 and not args.no_extras:
+        multi_gpu_lines(args, result, dist, rank, world, dev, plan, stacks, outs, launch, units_per_step, barrier, max_over_ranks,
+                        src_grid, n_src, n_tgt, tdtype, np_dtype, idx64, w64, layout)
 
     if rank == 0 and world == 1:
-        # ---- parity spot check + CPU baseline on a bounded sample of the same workload
-        sys.path.insert(0, ROOT)
-        from oracle import oracle  # checker / baseline only
-
-        n_sample = min(8, args.levels)
-        levels = np.linspace(0, args.levels - 1, n_sample).astype(int)
-        sample64 = np.stack([stacks[0].level_numpy(int(l)).astype(np.float64) for l in levels])
-        got = np.stack([outs[0].level_numpy(int(l)) for l in levels])
-        indptr = (np.arange(n_tgt + 1, dtype=np.int64) * args.k).astype(np.int32)
-        indices = idx64.astype(np.int32).reshape(-1)
-        want = np.stack([
-            oracle.csr_apply(w64.astype(np_dtype).reshape(-1), indices, indptr, (n_tgt, n_src), f.astype(np_dtype))
-            for f in sample64
-        ])
-        result["parity_max_rel_err"] = float(np.max(np.abs(got - want) / np.maximum(np.abs(want), 1e-30)))
-
-        if not args.no_cpu_baseline:
-            torch.set_num_threads(1)
-            data64 = w64.reshape(-1)
-            # the reference's dtype is float64 (to_numpy default): time csr_array @ x per field, one thread
-            from scipy.sparse import csr_array
-
-            matrix = csr_array((data64, indices, indptr), shape=(n_tgt, n_src))
-            matrix @ sample64[0]
-            n_done, t0 = 0, time.perf_counter()
-            while time.perf_counter() - t0 < args.cpu_seconds:
-                for f in sample64:
-                    _ = matrix @ f
-                    n_done += 1
-            cpu_s = time.perf_counter() - t0
-            result["cpu_baseline"] = {
-                "value": n_done * n_tgt / cpu_s,
-                "unit": "grid-points/s",
-                "cores": 1,
-                "kind": "port",
-                "sample": f"{n_done} fields ({n_sample} distinct levels of the same synthetic stack, float64 as in the "
-                          f"reference) x scipy csr_array(k={args.k}) @ x, {cpu_s:.1f} s on 1 thread; "
-                          f"host has {os.cpu_count()} logical cores",
-                "ms_per_field": cpu_s / n_done * 1e3,
-            }
-
-        if not args.no_extras:
-            extras = {}
-            # k = 1 nearest-neighbour gather (R: regrid.py:380), same stack
-            idx1 = torch.from_numpy(idx64[:, 0].astype(np.int32).copy()).to(dev)
-            ms1, _ = time_launches(lambda: launch(stacks[0], outs[0], idx=idx1, w=None, k=1, n_t=n_tgt), 10, 2)
-            alg1 = algorithmic_bytes(args.levels, itemsize, int(np.unique(idx64[:, 0]).size), n_tgt, 1)
-            extras["nearest_k1"] = {"value": n_tgt * args.levels / (ms1 * 1e-3), "avg_launch_ms": ms1,
-                                    "achieved_GBs": alg1 / (ms1 * 1e-3) / 1e9, "frac": alg1 / (ms1 * 1e-3) / 1e9 / HBM_PEAK_GBS}
-            # config-5 shape on the same stack: regrid -> orog_to_z -> convert fused in ONE launch
-            prog = native.level_program([[(native.OP_MUL, 0, 9.80665, 0.0)] * args.levels,
-                                         [(native.OP_AFFINE, 0, 1.0, -273.15)] * args.levels], dev)
-            msf, _ = time_launches(lambda: native.regrid_ell(
-                stacks[0].data, outs[0].data, idx_d, w_d, n_src=n_src, n_tgt=n_tgt, k=args.k, n_lev=args.levels,
-                src_pitch=stacks[0].pitch, out_pitch=outs[0].pitch, layout=stacks[0].layout, prog=prog, n_stage=2), 10, 2)
-            extras["fused_regrid_orog_to_z_convert"] = {"value": n_tgt * args.levels / (msf * 1e-3), "avg_launch_ms": msf,
-                                                        "achieved_GBs": alg / (msf * 1e-3) / 1e9,
-                                                        "frac": alg / (msf * 1e-3) / 1e9 / HBM_PEAK_GBS}
-            # the one-off index build on the device instead of cKDTree (interp.nearest_grid_points_device)
-            from anemoi_transform_amd import interp as _interp
-
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            di, dd = _interp.nearest_grid_points_device(src_grid["latitudes"], src_grid["longitudes"], tgt_grid["latitudes"],
-                                                        tgt_grid["longitudes"], num_neighbours_to_return=args.k, return_distances=True)
-            extras["knn_device_s"] = time.perf_counter() - t0
-            extras["knn_rows_identical_to_ckdtree"] = float((di.reshape(n_tgt, -1) == idx64).all(axis=1).mean())
-            del stacks, outs, mine
-            torch.cuda.empty_cache()
-            for name, dt, npdt, isz, lay in (("f64_columns", torch.float64, np.float64, 8, COLUMNS),
-                                             ("f32_fields", torch.float32, np.float32, 4, FIELDS)):
-                s = synth_stack(src_grid, args.levels, dt, dev, 0, lay)
-                o = Stack.empty(n_tgt, args.levels, dt, dev, lay)
-                wd = torch.from_numpy(w64.astype(npdt)).to(dev)
-                ms, _ = time_launches(lambda: launch(s, o, w=wd), 10, 2)
-                a = algorithmic_bytes(args.levels, isz, n_unique, n_tgt, args.k)
-                extras[name] = {"value": n_tgt * args.levels / (ms * 1e-3), "avg_launch_ms": ms,
-                                "achieved_GBs": a / (ms * 1e-3) / 1e9, "frac": a / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
-                del s, o, wd
-                torch.cuda.empty_cache()
-            # the CPU's best case (SURVEY.md §8d baseline B): the same statement on 16 worker processes, run as a child
-            # process that never touches the GPU; reported next to the one-thread "as the reference runs" baseline
-            if not args.no_cpu_baseline:
-                import subprocess
-
-                try:
-                    child = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "cpu_all_cores.py"), "--seconds", "8",
-                                            "--src-grid", args.src_grid, "--tgt-grid", args.tgt_grid, "--k", str(args.k)],
-                                           capture_output=True, text=True, timeout=180)
-                    extras["cpu_all_cores"] = json.loads(child.stdout.strip().splitlines()[-1])
-                except Exception as e:  # a baseline must never take the bench line down
-                    extras["cpu_all_cores"] = {"error": f"{type(e).__name__}: {e}"}
-            result["extras"] = extras
+        single_gpu_lines(args, result, dev, stacks, outs, launch, idx_d, w_d, idx64, w64, n_src, n_tgt, n_unique, alg, src_grid, tgt_grid,
+                         tdtype, np_dtype, itemsize)
 
     if rank == 0:
-        print(json.dumps(result))
+        print(json.dumps(result), flush=True)
     if world > 1:
+        barrier()
         dist.destroy_process_group()
+
+
+# ------------------------------------------------------------------------------------------------------------------------
+# N > 1: what is measured AFTER `value` — the exchange over RCCL, end to end, strong scaling, field-axis sharding
+# ------------------------------------------------------------------------------------------------------------------------
+def multi_gpu_lines(args, result, dist, rank, world, dev, plan, stacks, outs, launch, units_per_step, barrier, max_over_ranks,
+                    src_grid, n_src, n_tgt, tdtype, np_dtype, idx64, w64, layout):
+    from anemoi_transform_amd import distributed as atxd
+    from anemoi_transform_amd.stack import COLUMNS, Stack
+
+    # A hung collective must not cost the line that is already measured: when the budget runs out every rank leaves, and
+    # rank 0 prints what it has.  (Exceptions are caught per section; this is for waits that never return.)
+    state = {"section": "start"}
+
+    def give_up():
+        if rank == 0:
+            result["secondary_timed_out_in"] = state["section"]
+            print(json.dumps(result), flush=True)
+        os._exit(0)
+
+    watchdog = threading.Timer(args.secondary_seconds, give_up)
+    watchdog.daemon = True
+    watchdog.start()
+
+    def section(name, fn):
+        """Run one secondary measurement on all ranks; an exception on any rank is recorded and the ranks stay in step."""
+        state["section"] = name
+        barrier()
+        try:
+            out = fn()
+            ok = 1.0
+        except Exception as e:  # a comparison line must never take the bench line down
+            out, ok = {"error": f"{type(e).__name__}: {e}"}, 0.0
+        flag = torch.tensor([ok], dtype=torch.float64)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if flag.item() < 1.0 and ok == 1.0:
+            out = {"error": "failed on another rank"}
+        return out
+
+    # ---- strong scaling: the SAME total work as N = 1 (one stack, BASELINE configs[2]) with its target points over the N ranks
+    def strong():
+        own_out = outs[0]
+        for _ in range(args.warmup):
+            launch(stacks[0], own_out)
+        torch.cuda.synchronize()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            launch(stacks[0], own_out)
+        torch.cuda.synchronize()
+        t = max_over_ranks(time.perf_counter() - t0)
+        return {"value": n_tgt * args.levels * args.steps / t, "unit": "grid-points/s", "ms_per_step": t / args.steps * 1e3,
+                "scaling": "strong", "note": "ONE 137-level stack (the N = 1 job), each rank its 1/N target slice; source resident on every rank"}
+
+    result["strong"] = section("strong", strong)
+
+    # ---- field-axis sharding (SURVEY.md §8e, axis 2): every rank regrids its own stack to the WHOLE target grid — no exchange at all
+    def field_axis():
+        full_idx = torch.from_numpy(idx64.astype(np.int32)).to(dev)
+        full_w = torch.from_numpy(w64.astype(np_dtype)).to(dev)
+        own, full_out = stacks[rank], Stack.empty(n_tgt, args.levels, tdtype, dev, layout)
+
+        def own_step():
+            launch(own, full_out, idx=full_idx, w=full_w, n_t=n_tgt)
+
+        for _ in range(args.warmup):
+            own_step()
+        torch.cuda.synchronize()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            own_step()
+        torch.cuda.synchronize()
+        t = max_over_ranks(time.perf_counter() - t0)
+        return {"value": units_per_step * args.steps / t, "unit": "grid-points/s", "ms_per_step": t / args.steps * 1e3,
+                "note": "each rank regrids its own stack to the full target grid; no source exchange"}
+
+    result["field_axis_sharding"] = section("field_axis_sharding", field_axis)
+    if layout != COLUMNS:
+        watchdog.cancel()
+        return
+
+    # ---- the source exchange itself, on the data group (RCCL): first use creates the communicators
+    state["section"] = "data group"
+    atxd.set_data_group(dist.new_group(backend=args.backend))
+    mine = stacks[rank]
+    exchange_ms, verified = {}, {}
+
+    def timed(fn):
+        torch.cuda.synchronize()
+        barrier()
+        t0 = time.perf_counter()
+        out = fn()
+        torch.cuda.synchronize()
+        return out, max_over_ranks(time.perf_counter() - t0) * 1e3
+
+    def broadcast():
+        atxd.exchange_stacks(mine)  # warm-up: communicator set-up, allocator
+        got, ms = timed(lambda: atxd.exchange_stacks(mine))
+        exchange_ms["broadcast"] = ms
+        # every received stack must be the one this rank synthesised for that id
+        verified["broadcast"] = all(torch.equal(g.data, s.data) for g, s in zip(got, stacks))
+        return {"ms": ms, "bytes_received_per_gpu": (world - 1) * mine.data.numel() * mine.data.element_size(),
+                "verified_bit_equal": verified["broadcast"]}
+
+    def bands():
+        atxd.exchange_source_bands(mine, plan)
+        (got, local_plan), ms = timed(lambda: atxd.exchange_source_bands(mine, plan))
+        exchange_ms["bands"] = ms
+        # the banded plan on the received slabs must reproduce this rank's slice of every stack, bit for bit (outs: the timed region's)
+        banded = local_plan.apply_many(got)
+        verified["bands"] = all(torch.equal(b.data, o.data) for b, o in zip(banded, outs))
+        return {"ms": ms, "bytes_received_per_gpu": sum(b.data.numel() * b.data.element_size() for i, b in enumerate(got) if i != rank),
+                "verified_bit_equal": verified["bands"]}
+
+    detail = {"broadcast": section("exchange broadcast", broadcast), "bands": section("exchange bands", bands)}
+    result["source_exchange_ms"] = exchange_ms
+    result["source_exchange"] = detail
+
+    def end_to_end():
+        atxd.pipelined_sharded_regrid(plan, mine)  # warm-up
+        reps = 3
+        (got, ms) = timed(lambda: [atxd.pipelined_sharded_regrid(plan, mine) for _ in range(reps)][-1])
+        same = all(torch.equal(g.data, o.data) for g, o in zip(got, outs))
+        return {"ms_per_step": ms / reps, "value": units_per_step / (ms / reps * 1e-3), "unit": "grid-points/s", "verified_bit_equal": same,
+                "note": "one step INCLUDING the exchange of the N source stacks: broadcast r+1 (RCCL) overlapped with launch r, two source buffers alive"}
+
+    result["end_to_end"] = section("end_to_end", end_to_end)
+    watchdog.cancel()
+
+
+# ------------------------------------------------------------------------------------------------------------------------
+# N = 1: parity spot check, CPU baseline, secondary kernel lines, BASELINE configs 2 and 4
+# ------------------------------------------------------------------------------------------------------------------------
+def single_gpu_lines(args, result, dev, stacks, outs, launch, idx_d, w_d, idx64, w64, n_src, n_tgt, n_unique, alg, src_grid, tgt_grid,
+                     tdtype, np_dtype, itemsize):
+    from anemoi_transform_amd import interp, native
+    from anemoi_transform_amd.gather import GatherPlan
+    from anemoi_transform_amd.grids import lookup
+    from anemoi_transform_amd.stack import COLUMNS, FIELDS, Stack
+
+    from oracle import oracle  # checker / baseline only
+
+    n_sample = min(8, args.levels)
+    levels = np.linspace(0, args.levels - 1, n_sample).astype(int)
+    sample64 = np.stack([stacks[0].level_numpy(int(l)).astype(np.float64) for l in levels])
+    got = np.stack([outs[0].level_numpy(int(l)) for l in levels])
+    indptr = (np.arange(n_tgt + 1, dtype=np.int64) * args.k).astype(np.int32)
+    indices = idx64.astype(np.int32).reshape(-1)
+    want = np.stack([
+        oracle.csr_apply(w64.astype(np_dtype).reshape(-1), indices, indptr, (n_tgt, n_src), f.astype(np_dtype))
+        for f in sample64
+    ])
+    result["parity_max_rel_err"] = float(np.max(np.abs(got - want) / np.maximum(np.abs(want), 1e-30)))
+
+    if not args.no_cpu_baseline:
+        torch.set_num_threads(1)
+        # the reference's dtype is float64 (to_numpy default): time csr_array @ x per field, one thread
+        from scipy.sparse import csr_array
+
+        matrix = csr_array((w64.reshape(-1), indices, indptr), shape=(n_tgt, n_src))
+        matrix @ sample64[0]
+        n_done, t0 = 0, time.perf_counter()
+        while time.perf_counter() - t0 < args.cpu_seconds:
+            for f in sample64:
+                _ = matrix @ f
+                n_done += 1
+        cpu_s = time.perf_counter() - t0
+        result["cpu_baseline"] = {
+            "value": n_done * n_tgt / cpu_s,
+            "unit": "grid-points/s",
+            "cores": 1,
+            "kind": "port",
+            "dtype": "f64",
+            "sample": f"{n_done} fields ({n_sample} distinct levels of the same synthetic stack, float64 as in the "
+                      f"reference) x scipy csr_array(k={args.k}) @ x, {cpu_s:.1f} s on 1 thread; "
+                      f"host has {os.cpu_count()} logical cores",
+            "ms_per_field": cpu_s / n_done * 1e3,
+        }
+
+    if args.no_extras:
+        return
+    extras = {}
+    n_lev = args.levels
+    # k = 1 nearest-neighbour gather (R: regrid.py:380), same stack
+    idx1 = torch.from_numpy(idx64[:, 0].astype(np.int32).copy()).to(dev)
+    ms1, _ = time_launches(lambda: launch(stacks[0], outs[0], idx=idx1, w=None, k=1, n_t=n_tgt), 10, 2)
+    extras["nearest_k1"] = line(n_tgt * n_lev, ms1, algorithmic_bytes(n_lev, itemsize, int(np.unique(idx64[:, 0]).size), n_tgt, 1))
+    # config-5 shape on the same stack: regrid -> orog_to_z -> convert fused in ONE launch
+    prog = native.level_program([[(native.OP_MUL, 0, 9.80665, 0.0)] * n_lev, [(native.OP_AFFINE, 0, 1.0, -273.15)] * n_lev], dev)
+    msf, _ = time_launches(lambda: native.regrid_ell(
+        stacks[0].data, outs[0].data, idx_d, w_d, n_src=n_src, n_tgt=n_tgt, k=args.k, n_lev=n_lev,
+        src_pitch=stacks[0].pitch, out_pitch=outs[0].pitch, layout=stacks[0].layout, prog=prog, n_stage=2), 10, 2)
+    extras["fused_regrid_orog_to_z_convert"] = line(n_tgt * n_lev, msf, alg)
+
+    # the one-off index build on the device instead of cKDTree: raw kernel order, and with equidistant candidates settled by
+    # cKDTree (the table the reference builds, bit for bit)
+    args4 = (src_grid["latitudes"], src_grid["longitudes"], tgt_grid["latitudes"], tgt_grid["longitudes"])
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    raw_i = interp.nearest_grid_points_device(*args4, num_neighbours_to_return=args.k, ties="index")
+    extras["knn_device_s"] = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    di = interp.nearest_grid_points_device(*args4, num_neighbours_to_return=args.k)
+    extras["knn_device_ties_settled_s"] = time.perf_counter() - t0
+    extras["knn_rows_identical_to_ckdtree"] = float((di.reshape(n_tgt, -1) == idx64).all(axis=1).mean())
+    extras["knn_rows_identical_to_ckdtree_kernel_order"] = float((raw_i.reshape(n_tgt, -1) == idx64).all(axis=1).mean())
+    del raw_i, di
+
+    stacks.clear()
+    outs.clear()
+    torch.cuda.empty_cache()
+    for name, dt, npdt, isz, lay in (("f64_columns", torch.float64, np.float64, 8, COLUMNS),
+                                     ("f32_fields", torch.float32, np.float32, 4, FIELDS)):
+        s = synth_stack(src_grid, n_lev, dt, dev, 0, lay)
+        o = Stack.empty(n_tgt, n_lev, dt, dev, lay)
+        wd = torch.from_numpy(w64.astype(npdt)).to(dev)
+        ms, _ = time_launches(lambda: launch(s, o, w=wd), 10, 2)
+        extras[name] = line(n_tgt * n_lev, ms, algorithmic_bytes(n_lev, isz, n_unique, n_tgt, args.k))
+        del s, o, wd
+        torch.cuda.empty_cache()
+    if "cpu_baseline" in result:  # the like-for-like ratio: the reference's own width on both sides
+        extras["f64_columns_over_cpu_f64_one_core"] = extras["f64_columns"]["value"] / result["cpu_baseline"]["value"]
+
+    # ---- BASELINE configs[1]: O96 -> 1 degree bilinear, ONE surface field (the thin-stack regime: a 1-level column stack)
+    try:
+        g96, g1 = lookup("o96"), lookup([1.0, 1.0])
+        m = interp.bilinear_octahedral(96, g1)
+        p2 = GatherPlan.from_matrix(m)
+        u2 = int(np.unique(m["matrix_indices"]).size)
+        c2 = {"workload": "O96 (40320 pts) -> 1 deg lat-lon (65160 pts), bilinear k=4 matrix, 1 field per launch"}
+        for name, dt, isz in (("f64", torch.float64, 8), ("f32", torch.float32, 4)):
+            s = synth_stack(g96, 1, dt, dev, 0, COLUMNS)
+            ms, mn = time_launches(lambda: p2.apply(s), 50, 5)
+            c2[name] = dict(line(p2.n_tgt, ms, algorithmic_bytes(1, isz, u2, p2.n_tgt, 4)), min_launch_ms=mn)
+        c2["note"] = "0.9 MB of algorithmic traffic per launch: launch-latency bound, not HBM bound (includes the output allocation of GatherPlan.apply)"
+        extras["config2"] = c2
+    except Exception as e:
+        extras["config2"] = {"error": f"{type(e).__name__}: {e}"}
+
+    # ---- BASELINE configs[3]: O1280 -> N320-sized, 6 variables x 137 levels x 4 timesteps = 24 stacks, 8 target shards
+    try:
+        extras["config4"] = config4_lines(args, dev, src_grid, n_src, tdtype, np_dtype, itemsize)
+    except Exception as e:
+        extras["config4"] = {"error": f"{type(e).__name__}: {e}"}
+    torch.cuda.empty_cache()
+
+    # the CPU's best case (SURVEY.md §8d baseline B): the same statement on every core this process may use (os.cpu_count() capped
+    # by the cgroup quota — 16 on the MI355X boxes, where 32-256 workers measured SLOWER, profiles/r02_cpu_workers_sweep.jsonl), run
+    # as a child process that never touches the GPU; reported next to the one-thread "as the reference runs" baseline
+    if not args.no_cpu_baseline:
+        import subprocess
+
+        try:
+            child = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "cpu_all_cores.py"), "--seconds", "8", "--workers", str(args.cpu_workers),
+                                    "--src-grid", args.src_grid, "--tgt-grid", args.tgt_grid, "--k", str(args.k)],
+                                   capture_output=True, text=True, timeout=240)
+            extras["cpu_all_cores"] = json.loads(child.stdout.strip().splitlines()[-1])
+        except Exception as e:  # a baseline must never take the bench line down
+            extras["cpu_all_cores"] = {"error": f"{type(e).__name__}: {e}"}
+    result["extras"] = extras
+
+
+def config4_lines(args, dev, src_grid, n_src, tdtype, np_dtype, itemsize):
+    """The whole 3 288-field batch of BASELINE configs[3] resident on ONE MI355X (88.7 GB f32): all target points (what one
+    GPU does alone), and each of the 8 traffic-balanced target shards (what each of 8 GPUs would do; the slowest bounds the job)."""
+    from anemoi_transform_amd import native
+    from anemoi_transform_amd.gather import GatherPlan
+    from anemoi_transform_amd.grids import lookup
+    from anemoi_transform_amd.interp import knn_inverse_distance
+    from anemoi_transform_amd.stack import COLUMNS, Stack
+
+    tgt = lookup("n320-sized")
+    n_tgt, n_lev, n_stack, k = len(tgt["latitudes"]), args.levels, 24, 4
+    idx, w = knn_inverse_distance(src_grid, tgt, k=k)
+    plan = GatherPlan(n_src, n_tgt, index=idx, weights=w)
+    gen = torch.Generator(device=dev)
+    stacks = []
+    for i in range(n_stack):
+        gen.manual_seed(SEED + 7 * i)
+        st = Stack.empty(n_src, n_lev, tdtype, dev, COLUMNS, zero=True)
+        st.data[:, :n_lev].normal_(250.0 + 5.0 * (i // 4), 20.0, generator=gen)
+        stacks.append(st)
+    outs = [Stack.empty(n_tgt, n_lev, tdtype, dev, COLUMNS) for _ in range(n_stack)]
+
+    def run(lo, hi):
+        idx_d = torch.from_numpy(idx[lo:hi].astype(np.int32)).to(dev)
+        w_d = torch.from_numpy(w[lo:hi].astype(np_dtype)).to(dev)
+        views = [o.data[lo:hi] for o in outs]
+
+        def go():  # atx_regrid_ell_batch: one launch per 16 stacks -> 2 launches for the 24
+            native.regrid_ell_batch([s.data for s in stacks], views, idx_d, w_d, n_src=n_src, n_tgt=hi - lo, k=k, n_lev=n_lev,
+                                    src_pitch=stacks[0].pitch, out_pitch=outs[0].pitch, layout=COLUMNS)
+
+        ms, _ = time_launches(go, 10, 2)
+        u = int(np.unique(idx[lo:hi]).size)
+        return dict(line((hi - lo) * n_lev * n_stack, ms, n_stack * algorithmic_bytes(n_lev, itemsize, u, hi - lo, k)), targets=hi - lo)
+
+    out = {"workload": f"O1280 -> N320-sized reduced Gaussian ({n_tgt} pts, grids.sized_row_lengths), k=4, {n_stack} stacks x {n_lev} levels "
+                       f"= {n_stack * n_lev} fields resident ({sum(s.data.numel() for s in stacks) * itemsize / 1e9:.1f} GB)",
+           "all_targets_one_gpu": run(0, n_tgt)}
+    bounds = plan.bounds(8)
+    shards = [run(bounds[r], bounds[r + 1]) for r in range(8)]
+    slowest = max(shards, key=lambda s: s["avg_launch_ms"])
+    out["shards_of_8"] = {"ms": [s["avg_launch_ms"] for s in shards], "targets": [s["targets"] for s in shards], "slowest": slowest,
+                          "job_value_bound_by_slowest_shard": n_tgt * n_lev * n_stack / (slowest["avg_launch_ms"] * 1e-3),
+                          "note": "each shard timed alone on this GPU with all 24 source stacks resident: the per-GPU step of the 8-GPU job"}
+    return out
 
 
 if __name__ == "__main__":

@@ -470,12 +470,56 @@ def test_regrid_nearest_checks(engine):
 
     with pytest.raises(ValueError, match="out_grid is required"):
         create_filter_by_name("regrid", in_grid="o32", method="nearest")
-    with pytest.raises(NotImplementedError):
-        create_filter_by_name("regrid", in_grid="o32", out_grid="o48", method="linear")
+    with pytest.raises(NotImplementedError, match="matrix"):  # only 'linear' has an in-tree stand-in for earthkit-regrid
+        create_filter_by_name("regrid", in_grid="o32", out_grid="o48", method="conservative")
     source = test_source(synthetic_fields(lookup("o32"), 1))
     wrong = create_filter_by_name("regrid", in_grid="o48", out_grid=[5.0, 5.0], method="nearest")
     with pytest.raises(AssertionError):  # R: regrid.py:377-378
         list(source | wrong)
+
+
+def test_regrid_default_route(engine, tmp_path, caplog):
+    """R: regrid.py:455-467 + 211-259 — no ``method`` (the reference's stock recipe form) resolves to the default
+    interpolator with method="linear"; here the matrix is the in-tree bilinear one (earthkit-regrid's inventory is
+    remote), applied like ``matrix=``: equal, bit for bit, to the oracle's csr statement on that same matrix."""
+    import logging
+
+    from anemoi_transform_amd import interp
+    from anemoi_transform_amd.filters.regrid import EarthkitRegrid, _interpolator
+    from anemoi_transform_amd.grids import lookup
+
+    assert _interpolator() == "EarthkitRegrid" == _interpolator(method="linear")
+    src, tgt = lookup("o32"), lookup([5.0, 5.0])
+    specs = synthetic_fields(src, 4)
+    with caplog.at_level(logging.WARNING):
+        regrid = create_filter_by_name("regrid", in_grid="O32", out_grid=[5.0, 5.0])
+    assert isinstance(regrid.interpolator, EarthkitRegrid) and regrid.interpolator.method == "linear"
+    assert any("bilinear" in r.message and "MIR" in r.message for r in caplog.records)  # parity vs MIR is unpinned: said once
+    out = list(test_source(specs) | regrid)
+    matrix = interp.bilinear_octahedral(32, tgt)
+    want = oracle.filter_regrid_matrix([dict(s) for s in specs], matrix={**matrix, "out_latitudes": tgt["latitudes"], "out_longitudes": tgt["longitudes"]})
+    assert len(out) == 4
+    for f, w_ in zip(out, want):
+        assert np.array_equal(f.to_numpy(flatten=True), w_["values"])
+        lat, lon = f.grid_points()
+        assert np.array_equal(lat, tgt["latitudes"]) and np.array_equal(lon, tgt["longitudes"]) and f.metadata("param") == "t"
+    # config form, other row-structured sources, explicit method
+    for in_grid, name in (("f16", "f16"), ([10.0, 10.0], [10.0, 10.0])):
+        g = lookup(name)
+        lin = [{"param": "t", "values": g["latitudes"] * 2.0 + 1.0, "latitudes": g["latitudes"], "longitudes": g["longitudes"]}]
+        got = list(test_source(lin) | create_filter(None, {"regrid": {"in_grid": in_grid, "out_grid": "o16", "method": "linear"}}))[0]
+        o16 = lookup("o16")
+        inside = np.abs(o16["latitudes"]) < 80
+        np.testing.assert_allclose(got.to_numpy()[inside], o16["latitudes"][inside] * 2.0 + 1.0, rtol=1e-12)  # linear in latitude: reproduced
+    # what the in-tree default cannot serve fails loudly, at construction
+    path = str(tmp_path / "grid.npz")
+    np.savez(path, latitudes=src["latitudes"], longitudes=src["longitudes"])
+    with pytest.raises(NotImplementedError, match="matrix"):
+        create_filter_by_name("regrid", in_grid=path, out_grid=[5.0, 5.0])
+    with pytest.raises(TypeError):  # in_grid is a required argument of the default interpolator, as in the reference
+        create_filter_by_name("regrid", out_grid=[5.0, 5.0])
+    with pytest.raises(ValueError, match="points"):
+        list(test_source(synthetic_fields(lookup("o16"), 1)) | regrid)
 
 
 @pytest.mark.parametrize("kind", ["bilinear_k4", "knn_k3", "ragged_csr"])

@@ -245,3 +245,37 @@ def test_sparse_selection_on_a_device_stack_keeps_levels_in_place(engine):
     out = create_filter_by_name("orog_to_z").forward(on_device)
     assert out[5].stack_ref()[0].n_lev == 1 and out[0] is on_device[0]
     assert np.array_equal(out[5].to_numpy(), oracle.orog_to_z(on_device[5].to_numpy()), equal_nan=True)
+
+
+def test_fused_mask_only_meets_the_fields_it_masks_two_grids(engine, tmp_path, monkeypatch):
+    """a FieldList with two grids — `rescale` touches param t on grid A, `apply_mask(path=)` (a grid-B mask)
+    touches param sd on grid B.  Filter by filter (and in the reference) the mask never meets grid A; the fused run must
+    not measure it against grid A either, and must give the same fields."""
+    grid_a, grid_b = lookup("o16"), lookup("o32")
+    specs = synthetic_fields(grid_a, 2) + synthetic_fields(grid_b, 2, seed=1)
+    for s in specs[2:]:
+        s["param"] = "sd"
+    mask_path = str(tmp_path / "mask_b.npy")
+    rng = np.random.default_rng(4)
+    mask_b = (rng.random(len(grid_b["latitudes"])) < 0.3).astype(np.float64)
+    np.save(mask_path, mask_b)
+
+    def pipeline():
+        return [create_filter_by_name("rescale", scale=2.0, offset=1.0, param="t"),
+                create_filter_by_name("apply_mask", path=mask_path, mask_value=1, param="sd")]
+
+    def run():
+        out = test_source(specs)
+        for f in pipeline():
+            out = out | f
+        return list(out)
+
+    fused = run()
+    monkeypatch.setenv("ATX_NO_FUSION", "1")
+    plain = run()
+    assert len(fused) == len(plain) == 4
+    for a, b in zip(fused, plain):
+        assert a.metadata("param") == b.metadata("param")
+        assert np.array_equal(a.to_numpy(), b.to_numpy(), equal_nan=True)
+    assert np.array_equal(fused[0].to_numpy(), oracle.rescale_forward(specs[0]["values"], 2.0, 1.0))
+    assert np.array_equal(np.isnan(fused[2].to_numpy()), mask_b.astype(bool))

@@ -40,24 +40,43 @@ def test_single_gpu_line():
     assert d["parity_max_rel_err"] <= 1e-6
 
 
-@pytest.mark.parametrize("exchange", ["broadcast", "bands"])
-def test_two_ranks_rehearsal_over_gloo(exchange):
+def test_two_ranks_rehearsal_over_gloo():
+    """`--gpus 2` by default carries every N > 1 line: value (exchange excluded), both source exchanges timed and verified bit-equal,
+    end_to_end (exchange inside), strong scaling, field-axis sharding — no opt-in flags."""
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", *SMALL, "--backend", "gloo", "--share-device", "--exchange", exchange,
-           "--end-to-end"]
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", *SMALL, "--backend", "gloo", "--share-device"]
     run = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT)
     assert run.returncode == 0, run.stderr[-2000:]
     d = last_json(run.stdout)
     assert KEYS <= set(d) and d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 0
     assert d["config"]["stacks_per_step"] == 2 and d["config"]["launches_per_step_per_gpu"] == 1
-    assert d["source_exchange"] == exchange and d["source_exchange_ms"] > 0
+    assert "EXCLUDES the source exchange" in d["config"]["sharding"] and "gloo" in d["config"]["collectives"]
+    assert set(d["source_exchange_ms"]) == {"broadcast", "bands"} and all(v > 0 for v in d["source_exchange_ms"].values())
+    for kind in ("broadcast", "bands"):
+        assert d["source_exchange"][kind]["verified_bit_equal"] is True
+    assert d["source_exchange"]["bands"]["bytes_received_per_gpu"] < d["source_exchange"]["broadcast"]["bytes_received_per_gpu"]
+    assert d["end_to_end"]["verified_bit_equal"] is True
     assert d["end_to_end"]["value"] > 0 and d["end_to_end"]["value"] < d["value"]  # the exchange is inside that one
-    assert "cpu_baseline" not in d  # rank 0 at N = 1 only
-    if exchange == "broadcast":
-        assert d["field_axis_sharding"]["value"] > 0  # the no-exchange comparison point rides along
+    assert d["strong"]["scaling"] == "strong" and d["strong"]["value"] > 0
+    assert d["field_axis_sharding"]["value"] > 0  # the no-exchange comparison point rides along
+    assert "cpu_baseline" not in d and "secondary_timed_out_in" not in d  # rank 0 at N = 1 only
+
+
+def test_secondary_lines_cannot_cost_the_value():
+    """A stuck secondary section (budget of 0 seconds: the watchdog fires at once) still yields the ONE JSON line with `value`."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", *SMALL, "--backend", "gloo", "--share-device",
+           "--secondary-seconds", "0"]
+    run = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert run.returncode == 0, run.stderr[-2000:]
+    d = last_json(run.stdout)
+    assert d["value"] > 0 and d["n_gpus"] == 2 and "secondary_timed_out_in" in d
 
 
 def test_integration_md_ctypes_stub_runs(tmp_path):

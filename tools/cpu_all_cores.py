@@ -39,7 +39,10 @@ def _work(args):
 def main():
     global _matrix, _fields
     ap = argparse.ArgumentParser()
-    ap.add_argument("--workers", type=int, default=os.cpu_count() or 1)
+    ap.add_argument("--workers", type=int, default=0,
+                    help="worker processes; 0 = every core this process may use: os.cpu_count(), capped by the cgroup CPU quota "
+                         "(the MI355X test boxes grant 16 of 256 host threads; more workers than that only time-slice — "
+                         "profiles/r02_cpu_workers_sweep.jsonl: 16 -> 3.7e9, 32 -> 2.5e9, 256 -> 0.8e9 points/s)")
     ap.add_argument("--sweep", default="", help="comma-separated worker counts: time each, print every line, then the best again")
     ap.add_argument("--seconds", type=float, default=8.0)
     ap.add_argument("--src-grid", default="o1280")
@@ -75,6 +78,11 @@ def main():
             return None if quota == "max" else float(quota) / float(period)
         except Exception:
             return None
+
+    if args.workers <= 0:
+        args.workers = len(os.sched_getaffinity(0))
+        if cpu_quota():
+            args.workers = max(1, min(args.workers, int(cpu_quota())))
 
     def run(workers: int) -> dict:
         with ctx.Pool(workers) as pool:
