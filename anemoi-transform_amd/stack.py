@@ -36,8 +36,14 @@ def device() -> torch.device:
 
 
 def column_pitch(n_lev: int, dtype: torch.dtype) -> int:
-    """Row pitch (elements) of a columns stack: n_lev rounded up to a 16-byte multiple."""
+    """Row pitch (elements) of a columns stack: n_lev rounded up to a 16-byte multiple, so that every column starts on a
+    16-byte boundary and the kernels move 16-byte vectors — except for stacks thinner than one vector (1-3 float32
+    levels, 1 float64 level), which are stored tight: padding a single surface field to 16 bytes per point would move 4x
+    the bytes (measured on O1280 -> 0.25 degree, k = 4: 23.4 us padded, 12.7 us tight — the launch floor;
+    profiles/r02_thin_stacks.log), and a tight 1-level column stack IS the field, contiguous."""
     per16 = 16 // torch.empty((), dtype=dtype).element_size()
+    if n_lev < per16:
+        return n_lev
     return (n_lev + per16 - 1) // per16 * per16
 
 
