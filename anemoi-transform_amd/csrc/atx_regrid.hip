@@ -19,12 +19,15 @@
 //    the level chunk.
 #include "atx_common.hpp"
 
+#include <cstring>
+
 namespace atx {
 
 // A/B knobs (build a variant with -D..., compare with tools/ab_bench.py; the defaults are the measured winners, logs under
-// profiles/r01_ab_*.log): items in flight per lane of the tiled kernel (2 and 8: no gain), non-temporal output stores (+3 %)
-// and index / weight loads (+2 %), non-temporal SOURCE loads (no gain), XCD-contiguous block ranges off (-3 %), lanes per
-// workgroup of the tiled kernel (64 / 128 / 512: same plateau).
+// profiles/r01_ab_*.log): items in flight per lane of the tiled kernel (2 and 8: no gain), non-temporal output stores (+3 %),
+// non-temporal index / weight loads IN THE TILED KERNEL (+2 %: every word is read once there; the direct kernel reads a
+// target's words from several lanes and waves and uses plain loads), non-temporal SOURCE loads (no gain), XCD-contiguous block
+// ranges off (-3 %), lanes per workgroup of the tiled kernel (64 / 128 / 512: same plateau).
 #ifndef ATX_UNROLL
 #define ATX_UNROLL 4
 #endif
@@ -259,10 +262,47 @@ regrid_cols_ell_kernel(EllBatch batch,
 // request) and then the k source vectors.  The default for k <= 4 gathers without an epilogue, see the note at its launch
 // site; the tiled kernel above serves epilogues and runtime k.
 // ---------------------------------------------------------------------------------
-template <typename T, int VEC, int K, bool WEIGHTED, bool PAD>
+// Epilogue of the direct kernel (the fused regrid -> per-point chain, K10) without shared memory or a barrier:
+//   kEpiUniform  per stage, the levels run ONE operator, or one operator up to a level and another from there on (a stack of
+//                "136 levels of t, then orog" — BASELINE config 5 — or of two variables), the change falling on a 16-byte
+//                vector boundary; <= kMaxUniform stages, any operators, with or without the point mask: the operators travel BY
+//                VALUE in the kernel arguments (scalar registers), the dispatch on the operator is a scalar branch; with two
+//                pieces both are evaluated and the lane keeps the one its vector belongs to;
+//   kEpiTable    programs of the multiply-add family only (COPY / AFFINE / MUL, with or without the point mask — rescale, convert,
+//                orog_to_z, apply_mask: BASELINE config 5), <= kMaxTable stages, operators differing from level to level: the
+//                per-VECTOR operator table the host built once (atx_vector_program, n_stage x C entries, a few hundred bytes
+//                that stay in L1) is read one entry per stage and lane, REQUESTED BEFORE THE GATHER so its latency passes under
+//                it, and applied without a branch (x*p0, (x*p0)+p1 and x are all formed, the operator selects: the same two
+//                roundings as the statement it replaces).  Vectors whose levels differ (marker ATX_OP_MIXED) go level by level
+//                through the per-level program.
+// Everything else (clip / impute / exp / log / divisions, more stages) stays on the tiled kernel: its general operator switch
+// costs registers (f64: 88 VGPRs, 5 waves per SIMD instead of 8) and time the gather cannot hide (profiles/r02_ab_epilogue_routes.log).
+constexpr int kEpiNone = 0, kEpiUniform = 1, kEpiTable = 2;
+constexpr int kMaxUniform = 4;
+constexpr int kMaxTable = 4;
+
+// COPY / AFFINE / MUL (+ mask) on one element, branch-free; bit-identical to apply_level_op for these operators.
+template <typename T>
+__device__ __forceinline__ T apply_madd_family(const LevelOp<T>& o, T x, bool masked) {
+    const T m = x * o.p0;
+    const T a = m + o.p1;
+    T y = o.op == ATX_OP_AFFINE ? a : (o.op == ATX_OP_MUL ? m : x);
+    return (o.use_mask && masked) ? quiet_nan<T>() : y;
+}
+template <typename T>
+struct UniformOps {
+    int n_stage;
+    int split[kMaxUniform];          // first vector column of the second piece of stage s (>= C: the stage has one piece)
+    LevelOp<T> stage[kMaxUniform];   // first piece
+    LevelOp<T> second[kMaxUniform];  // second piece
+};
+
+template <typename T, int VEC, int K, bool WEIGHTED, bool PAD, int EPI>
 __global__ void __launch_bounds__(kEllBlock)
 regrid_cols_ell_direct_kernel(EllBatch batch, const int32_t* __restrict__ idx, const T* __restrict__ w, int64_t n_items,
-                              int C, int64_t src_pitch, int64_t out_pitch, unsigned n_blocks, int items_per_lane) {
+                              int C, int64_t src_pitch, int64_t out_pitch, unsigned n_blocks, int items_per_lane,
+                              UniformOps<T> uniform, const atx_level_op* __restrict__ vec_prog,
+                              const atx_level_op* __restrict__ prog, int n_stage, int n_lev, const uint8_t* __restrict__ tgt_mask) {
     using V = Pack<T, VEC>;
     const T* __restrict__ src = static_cast<const T*>(batch.src[blockIdx.y]);
     T* __restrict__ out = static_cast<T*>(batch.out[blockIdx.y]);
@@ -278,6 +318,21 @@ regrid_cols_ell_direct_kernel(EllBatch batch, const int32_t* __restrict__ idx, c
         for (int j = 0; j < K; ++j) {  // plain loads: a target's words are read again by the next wave when its vectors straddle two
             p[j] = idx[(int64_t)t * K + j];
             if (WEIGHTED) wv[j] = w[(int64_t)t * K + j];
+        }
+        // table route: the first operators and the mask byte are requested HERE, together with the index words, so that their
+        // latency passes under the gather instead of after it (loaded after the accumulation they cost 9 %: 478 vs 439 us)
+        LevelOp<T> pre[kMaxTable];
+        bool masked = false;
+        if (EPI == kEpiUniform) masked = tgt_mask ? (tgt_mask[t] != 0) : false;
+        if (EPI == kEpiTable) {
+#pragma unroll
+            for (int s = 0; s < kMaxTable; ++s) {
+                pre[s].op = ATX_OP_COPY;
+                pre[s].use_mask = 0;
+                pre[s].p0 = pre[s].p1 = T(0);
+                if (s < n_stage) pre[s] = load_level_op<T>(vec_prog, (int64_t)s * C + c);
+            }
+            masked = tgt_mask ? (tgt_mask[t] != 0) : false;
         }
         V v[K];
 #pragma unroll
@@ -296,6 +351,34 @@ regrid_cols_ell_direct_kernel(EllBatch batch, const int32_t* __restrict__ idx, c
             }
         } else {
             acc = v[0];
+        }
+        if (EPI == kEpiUniform) {
+            for (int s = 0; s < uniform.n_stage; ++s) {
+                if (uniform.split[s] >= C) {  // scalar condition: one piece
+                    apply_level_op_vec<T, VEC>(uniform.stage[s], acc, masked);
+                } else {
+                    V other = acc;
+                    apply_level_op_vec<T, VEC>(uniform.stage[s], acc, masked);
+                    apply_level_op_vec<T, VEC>(uniform.second[s], other, masked);
+                    if (c >= uniform.split[s]) acc = other;
+                }
+            }
+        } else if (EPI == kEpiTable) {
+#pragma unroll
+            for (int s = 0; s < kMaxTable; ++s) {
+                if (s < n_stage) {
+                    if (pre[s].op != kOpMixed) {
+#pragma unroll
+                        for (int e = 0; e < VEC; ++e) acc.v[e] = apply_madd_family(pre[s], acc.v[e], masked);
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < VEC; ++e) {
+                            const int l = c * VEC + e;
+                            if (l < n_lev) acc.v[e] = apply_madd_family(load_level_op<T>(prog, (int64_t)s * n_lev + l), acc.v[e], masked);
+                        }
+                    }
+                }
+            }
         }
         store_out(reinterpret_cast<V*>(out + (int64_t)t * out_pitch + (int64_t)c * VEC), acc);
     }
@@ -516,27 +599,112 @@ static int pick_tile(int64_t n_tgt, int C, bool epilogue) {
     return tile;
 }
 
-static int g_tile_override = 0;  // tuning hook (atx_set_tuning)
+static int g_tile_override = 0;  // tuning hook (atx_set_tuning): process-wide, meant for benchmarks and tests (results never depend on it)
+
+// The fused per-level program as the launchers see it: `prog` (device, per level) is always there when n_stage > 0; the two
+// optional companions let the direct kernel take the epilogue — `vec_prog` (device: atx_vector_program of the stack's dtype)
+// and `host_prog` (HOST copy of `prog`: the only way the library can SEE the program without a device round trip).
+struct Epilogue {
+    const atx_level_op* prog = nullptr;
+    const atx_level_op* vec_prog = nullptr;
+    const atx_level_op* host_prog = nullptr;
+    int n_stage = 0;
+    const uint8_t* mask = nullptr;
+};
+
+// Every operator of the program is COPY, AFFINE or MUL (masked or not) and there are <= kMaxTable stages: the direct
+// kernel's table route applies.
+static bool madd_family_program(const Epilogue& e, int n_lev) {
+    if (!e.host_prog || !e.vec_prog || e.n_stage < 1 || e.n_stage > kMaxTable) return false;
+    for (int64_t i = 0; i < (int64_t)e.n_stage * n_lev; ++i) {
+        const int op = e.host_prog[i].op;
+        if (op != ATX_OP_COPY && op != ATX_OP_AFFINE && op != ATX_OP_MUL) return false;
+    }
+    return true;
+}
+
+// Per stage the levels run one operator, or one up to a level that is a multiple of `vec` and another from there on
+// (<= kMaxUniform stages): the operators can travel by value.
+template <typename T>
+static bool uniform_program(const Epilogue& e, int n_lev, int vec, UniformOps<T>& out) {
+    if (!e.host_prog || e.n_stage < 1 || e.n_stage > kMaxUniform) return false;
+    auto typed = [](const atx_level_op& o) {
+        LevelOp<T> r;
+        r.op = o.op;
+        r.use_mask = o.use_mask ? 1 : 0;
+        r.p0 = static_cast<T>(o.p0);
+        r.p1 = static_cast<T>(o.p1);
+        return r;
+    };
+    auto same = [](const LevelOp<T>& a, const LevelOp<T>& b) {
+        return a.op == b.op && a.use_mask == b.use_mask && std::memcmp(&a.p0, &b.p0, sizeof(T)) == 0 && std::memcmp(&a.p1, &b.p1, sizeof(T)) == 0;
+    };
+    const int C = (n_lev + vec - 1) / vec;
+    out.n_stage = e.n_stage;
+    for (int s = 0; s < kMaxUniform; ++s) out.split[s] = C;
+    for (int s = 0; s < e.n_stage; ++s) {
+        const atx_level_op* row = e.host_prog + (int64_t)s * n_lev;
+        const LevelOp<T> first = typed(row[0]);
+        int l = 1;
+        while (l < n_lev && same(typed(row[l]), first)) ++l;
+        out.stage[s] = out.second[s] = first;
+        if (l == n_lev) continue;  // one piece
+        if (l % vec != 0) return false;  // the change must fall on a vector boundary
+        const LevelOp<T> second = typed(row[l]);
+        for (int m = l + 1; m < n_lev; ++m)
+            if (!same(typed(row[m]), second)) return false;  // a third piece
+        out.second[s] = second;
+        out.split[s] = l / vec;
+    }
+    for (int s = 0; s < e.n_stage; ++s)
+        if ((out.stage[s].use_mask || out.second[s].use_mask) && !e.mask) return false;  // (rejected by validation anyway)
+    return true;
+}
 
 template <typename T, int VEC, int K, bool WEIGHTED, bool PAD = false>
 static int launch_cols_ell(const EllBatch& batch, const int32_t* idx, const T* w, int64_t n_tgt, int k,
-                           int n_lev, int64_t src_pitch, int64_t out_pitch, const atx_level_op* prog,
-                           int n_stage, const uint8_t* tgt_mask, hipStream_t stream) {
+                           int n_lev, int64_t src_pitch, int64_t out_pitch, const Epilogue& epi, hipStream_t stream) {
     const int C = (n_lev + VEC - 1) / VEC;
-    // Fixed-k gathers with compile-time k (1-4; padded ragged rows 3-4) and no epilogue take the direct kernel.  Interleaved A/B on O1280 -> 0.25 deg,
+    const atx_level_op* prog = epi.prog;
+    const int n_stage = epi.n_stage;
+    const uint8_t* tgt_mask = epi.mask;
+    // Fixed-k gathers with compile-time k (1-4; padded ragged rows 3-4) take the direct kernel.  Interleaved A/B on O1280 -> 0.25 deg,
     // 137 levels (profiles/r01_ab_direct_kernel.log): k=4 f32 0.4360 vs 0.4378 ms, k=1 f32 0.1926 vs 0.1992 ms, k=4 f64 0.8334 vs
     // 0.8343 ms; 1-60 levels equal or up to 15 % faster; 2 / 4 items per lane -4 % / -9 %.  Same bits, no tile heuristic to tune.
+    // With an epilogue it still does when the operators can reach it without a per-workgroup set-up: by value (uniform
+    // program seen through host_prog) or, for multiply-add programs, through the host-built per-vector table (vec_prog);
+    // profiles/r02_ab_epilogue_routes.log.
 #ifndef ATX_ELL_DIRECT
 #define ATX_ELL_DIRECT 1
 #endif
+#ifndef ATX_EPI_DIRECT
+#define ATX_EPI_DIRECT 1
+#endif
     if constexpr (ATX_ELL_DIRECT && K > 0) {
-        if (!prog && g_tile_override <= 0) {  // atx_set_tuning(tile > 0) selects the tiled kernel below (A/B, tests)
+        if (g_tile_override <= 0) {  // atx_set_tuning(tile > 0) selects the tiled kernel below (A/B, tests)
             const int64_t n_items = n_tgt * C;
             const unsigned n_blocks = (unsigned)((n_items + kEllBlock - 1) / kEllBlock);
-            hipLaunchKernelGGL((regrid_cols_ell_direct_kernel<T, VEC, K, WEIGHTED, PAD>), dim3(n_blocks, batch.n), dim3(kEllBlock), 0, stream,
-                               batch, idx, w, n_items, C, src_pitch, out_pitch, n_blocks, 1);
-            ATX_LAUNCH_CHECK("regrid_cols_ell_direct");
-            return ATX_OK;
+            UniformOps<T> uniform{};
+            if (!prog) {
+                hipLaunchKernelGGL((regrid_cols_ell_direct_kernel<T, VEC, K, WEIGHTED, PAD, kEpiNone>), dim3(n_blocks, batch.n), dim3(kEllBlock), 0,
+                                   stream, batch, idx, w, n_items, C, src_pitch, out_pitch, n_blocks, 1, uniform, nullptr, nullptr, 0, n_lev, nullptr);
+                ATX_LAUNCH_CHECK("regrid_cols_ell_direct");
+                return ATX_OK;
+            }
+            if (ATX_EPI_DIRECT && uniform_program<T>(epi, n_lev, VEC, uniform)) {
+                hipLaunchKernelGGL((regrid_cols_ell_direct_kernel<T, VEC, K, WEIGHTED, PAD, kEpiUniform>), dim3(n_blocks, batch.n), dim3(kEllBlock),
+                                   0, stream, batch, idx, w, n_items, C, src_pitch, out_pitch, n_blocks, 1, uniform, nullptr, nullptr, n_stage, n_lev,
+                                   tgt_mask);
+                ATX_LAUNCH_CHECK("regrid_cols_ell_direct_uniform");
+                return ATX_OK;
+            }
+            if (ATX_EPI_DIRECT && VEC == Vec16<T>::N && madd_family_program(epi, n_lev)) {  // the table is built for 16-byte vectors
+                hipLaunchKernelGGL((regrid_cols_ell_direct_kernel<T, VEC, K, WEIGHTED, PAD, kEpiTable>), dim3(n_blocks, batch.n), dim3(kEllBlock), 0,
+                                   stream, batch, idx, w, n_items, C, src_pitch, out_pitch, n_blocks, 1, uniform, epi.vec_prog, prog, n_stage, n_lev,
+                                   tgt_mask);
+                ATX_LAUNCH_CHECK("regrid_cols_ell_direct_table");
+                return ATX_OK;
+            }
         }
     }
     int tile = g_tile_override > 0 ? g_tile_override : pick_tile(n_tgt, C, prog != nullptr);
@@ -559,22 +727,21 @@ static int launch_cols_ell(const EllBatch& batch, const int32_t* idx, const T* w
 
 template <typename T, int VEC>
 static int dispatch_cols_ell(const EllBatch& batch, const int32_t* idx, const T* w, int64_t n_tgt, int k,
-                             int n_lev, int64_t sp, int64_t op, bool pad, const atx_level_op* prog, int n_stage,
-                             const uint8_t* m, hipStream_t st) {
-    if (!w) return launch_cols_ell<T, VEC, 1, false>(batch, idx, w, n_tgt, k, n_lev, sp, op, prog, n_stage, m, st);
+                             int n_lev, int64_t sp, int64_t op, bool pad, const Epilogue& e, hipStream_t st) {
+    if (!w) return launch_cols_ell<T, VEC, 1, false>(batch, idx, w, n_tgt, k, n_lev, sp, op, e, st);
     if (pad) {  // padded ragged rows: the common widths compile-time, the rest runtime
         switch (k) {
-            case 3: return launch_cols_ell<T, VEC, 3, true, true>(batch, idx, w, n_tgt, k, n_lev, sp, op, prog, n_stage, m, st);
-            case 4: return launch_cols_ell<T, VEC, 4, true, true>(batch, idx, w, n_tgt, k, n_lev, sp, op, prog, n_stage, m, st);
-            default: return launch_cols_ell<T, VEC, 0, true, true>(batch, idx, w, n_tgt, k, n_lev, sp, op, prog, n_stage, m, st);
+            case 3: return launch_cols_ell<T, VEC, 3, true, true>(batch, idx, w, n_tgt, k, n_lev, sp, op, e, st);
+            case 4: return launch_cols_ell<T, VEC, 4, true, true>(batch, idx, w, n_tgt, k, n_lev, sp, op, e, st);
+            default: return launch_cols_ell<T, VEC, 0, true, true>(batch, idx, w, n_tgt, k, n_lev, sp, op, e, st);
         }
     }
     switch (k) {
-        case 1: return launch_cols_ell<T, VEC, 1, true>(batch, idx, w, n_tgt, k, n_lev, sp, op, prog, n_stage, m, st);
-        case 2: return launch_cols_ell<T, VEC, 2, true>(batch, idx, w, n_tgt, k, n_lev, sp, op, prog, n_stage, m, st);
-        case 3: return launch_cols_ell<T, VEC, 3, true>(batch, idx, w, n_tgt, k, n_lev, sp, op, prog, n_stage, m, st);
-        case 4: return launch_cols_ell<T, VEC, 4, true>(batch, idx, w, n_tgt, k, n_lev, sp, op, prog, n_stage, m, st);
-        default: return launch_cols_ell<T, VEC, 0, true>(batch, idx, w, n_tgt, k, n_lev, sp, op, prog, n_stage, m, st);
+        case 1: return launch_cols_ell<T, VEC, 1, true>(batch, idx, w, n_tgt, k, n_lev, sp, op, e, st);
+        case 2: return launch_cols_ell<T, VEC, 2, true>(batch, idx, w, n_tgt, k, n_lev, sp, op, e, st);
+        case 3: return launch_cols_ell<T, VEC, 3, true>(batch, idx, w, n_tgt, k, n_lev, sp, op, e, st);
+        case 4: return launch_cols_ell<T, VEC, 4, true>(batch, idx, w, n_tgt, k, n_lev, sp, op, e, st);
+        default: return launch_cols_ell<T, VEC, 0, true>(batch, idx, w, n_tgt, k, n_lev, sp, op, e, st);
     }
 }
 
@@ -632,9 +799,11 @@ static bool cols_vector_ok(const void* src, const void* out, int64_t sp, int64_t
 
 template <typename T>
 static int regrid_ell_typed(const EllBatch& batch, const int32_t* idx, const void* w_, int64_t n_tgt, int k,
-                            int n_lev, int64_t sp, int64_t op, int layout, bool pad, const atx_level_op* prog, int n_stage,
-                            const uint8_t* m, hipStream_t st) {
+                            int n_lev, int64_t sp, int64_t op, int layout, bool pad, const Epilogue& e, hipStream_t st) {
     const T* w = static_cast<const T*>(w_);
+    const atx_level_op* prog = e.prog;
+    const int n_stage = e.n_stage;
+    const uint8_t* m = e.mask;
     if (layout == ATX_COLUMNS) {
         constexpr int VEC = Vec16<T>::N;
         // the vector path needs every row start 16-byte aligned and room for the
@@ -642,8 +811,8 @@ static int regrid_ell_typed(const EllBatch& batch, const int32_t* idx, const voi
         const int64_t covered = ((int64_t)(n_lev + VEC - 1) / VEC) * VEC;
         bool vector_ok = covered <= sp && covered <= op;
         for (int i = 0; i < batch.n; ++i) vector_ok = vector_ok && cols_vector_ok<T>(batch.src[i], batch.out[i], sp, op);
-        if (vector_ok) return dispatch_cols_ell<T, VEC>(batch, idx, w, n_tgt, k, n_lev, sp, op, pad, prog, n_stage, m, st);
-        return dispatch_cols_ell<T, 1>(batch, idx, w, n_tgt, k, n_lev, sp, op, pad, prog, n_stage, m, st);
+        if (vector_ok) return dispatch_cols_ell<T, VEC>(batch, idx, w, n_tgt, k, n_lev, sp, op, pad, e, st);
+        return dispatch_cols_ell<T, 1>(batch, idx, w, n_tgt, k, n_lev, sp, op, pad, e, st);
     }
     for (int i = 0; i < batch.n; ++i) {  // field-major stacks: lanes keep indices / weights in registers, one launch per stack
         const int rc = dispatch_fields_ell<T>(static_cast<const T*>(batch.src[i]), static_cast<T*>(batch.out[i]), idx, w, n_tgt, k,
@@ -741,7 +910,8 @@ extern "C" int atx_set_tuning(int tile) {
 static int regrid_ell_common(const char* fn, const void* const* srcs, void* const* outs, int32_t n_stack, const int32_t* idx,
                              const void* w, int64_t n_src, int64_t n_tgt, int32_t k, int64_t n_lev, int64_t src_pitch,
                              int64_t out_pitch, int dtype, int layout, int32_t flags, const atx_level_op* prog,
-                             int32_t n_stage, const uint8_t* tgt_mask, void* stream) {
+                             const atx_level_op* vec_prog, const atx_level_op* host_prog, int32_t n_stage, const uint8_t* tgt_mask,
+                             void* stream) {
     ATX_REQUIRE(srcs && outs && n_stack >= 1, ATX_EINVAL, "%s: needs at least one stack", fn);
     for (int32_t i = 0; i < n_stack; ++i) {
         int st = check_stack_args(fn, srcs[i], outs[i], n_src, n_tgt, n_lev, src_pitch, out_pitch, dtype, layout);
@@ -755,8 +925,15 @@ static int regrid_ell_common(const char* fn, const void* const* srcs, void* cons
     const bool pad = (flags & ATX_ELL_PADDED) != 0;
     ATX_REQUIRE((prog == nullptr) == (n_stage == 0) && n_stage >= 0 && n_stage <= 8, ATX_EINVAL,
                 "%s: prog/n_stage mismatch (n_stage=%d)", fn, n_stage);
+    ATX_REQUIRE(prog || (!vec_prog && !host_prog), ATX_EINVAL, "%s: vec_prog / host_prog accompany prog, which is NULL", fn);
     if (n_tgt == 0) return ATX_OK;
     hipStream_t s = static_cast<hipStream_t>(stream);
+    Epilogue epi;
+    epi.prog = prog;
+    epi.vec_prog = vec_prog;
+    epi.host_prog = host_prog;
+    epi.n_stage = n_stage;
+    epi.mask = tgt_mask;
     for (int32_t first = 0; first < n_stack; first += kMaxBatch) {
         EllBatch batch;
         batch.n = n_stack - first < kMaxBatch ? n_stack - first : kMaxBatch;
@@ -765,8 +942,8 @@ static int regrid_ell_common(const char* fn, const void* const* srcs, void* cons
             batch.out[i] = i < batch.n ? outs[first + i] : nullptr;
         }
         const int rc = dtype == ATX_F32
-            ? regrid_ell_typed<float>(batch, idx, w, n_tgt, k, (int)n_lev, src_pitch, out_pitch, layout, pad, prog, n_stage, tgt_mask, s)
-            : regrid_ell_typed<double>(batch, idx, w, n_tgt, k, (int)n_lev, src_pitch, out_pitch, layout, pad, prog, n_stage, tgt_mask, s);
+            ? regrid_ell_typed<float>(batch, idx, w, n_tgt, k, (int)n_lev, src_pitch, out_pitch, layout, pad, epi, s)
+            : regrid_ell_typed<double>(batch, idx, w, n_tgt, k, (int)n_lev, src_pitch, out_pitch, layout, pad, epi, s);
         if (rc != ATX_OK) return rc;
     }
     return ATX_OK;
@@ -774,18 +951,19 @@ static int regrid_ell_common(const char* fn, const void* const* srcs, void* cons
 
 extern "C" int atx_regrid_ell(const void* src, void* out, const int32_t* idx, const void* w, int64_t n_src,
                               int64_t n_tgt, int32_t k, int64_t n_lev, int64_t src_pitch, int64_t out_pitch,
-                              int dtype, int layout, int32_t flags, const atx_level_op* prog, int32_t n_stage,
-                              const uint8_t* tgt_mask, void* stream) {
+                              int dtype, int layout, int32_t flags, const atx_level_op* prog, const atx_level_op* vec_prog,
+                              const atx_level_op* host_prog, int32_t n_stage, const uint8_t* tgt_mask, void* stream) {
     return regrid_ell_common("atx_regrid_ell", &src, &out, 1, idx, w, n_src, n_tgt, k, n_lev, src_pitch, out_pitch, dtype,
-                             layout, flags, prog, n_stage, tgt_mask, stream);
+                             layout, flags, prog, vec_prog, host_prog, n_stage, tgt_mask, stream);
 }
 
 extern "C" int atx_regrid_ell_batch(const void* const* srcs, void* const* outs, int32_t n_stack, const int32_t* idx,
                                     const void* w, int64_t n_src, int64_t n_tgt, int32_t k, int64_t n_lev,
                                     int64_t src_pitch, int64_t out_pitch, int dtype, int layout, int32_t flags,
-                                    const atx_level_op* prog, int32_t n_stage, const uint8_t* tgt_mask, void* stream) {
+                                    const atx_level_op* prog, const atx_level_op* vec_prog, const atx_level_op* host_prog,
+                                    int32_t n_stage, const uint8_t* tgt_mask, void* stream) {
     return regrid_ell_common("atx_regrid_ell_batch", srcs, outs, n_stack, idx, w, n_src, n_tgt, k, n_lev, src_pitch, out_pitch,
-                             dtype, layout, flags, prog, n_stage, tgt_mask, stream);
+                             dtype, layout, flags, prog, vec_prog, host_prog, n_stage, tgt_mask, stream);
 }
 
 extern "C" int atx_regrid_csr(const void* src, void* out, const int32_t* indptr, const int32_t* indices,

@@ -58,12 +58,12 @@ SIGNATURES: dict[str, tuple[Any, list[Any]]] = {
     "atx_regrid_ell": (
         c_int,
         [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int32, c_int64, c_int64, c_int64, c_int, c_int, c_int32,
-         c_void_p, c_int32, c_void_p, c_void_p],
+         c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_void_p],
     ),
     "atx_regrid_ell_batch": (
         c_int,
         [c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_int64, c_int64, c_int32, c_int64, c_int64, c_int64, c_int, c_int,
-         c_int32, c_void_p, c_int32, c_void_p, c_void_p],
+         c_int32, c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_void_p],
     ),
     "atx_regrid_csr": (
         c_int,
@@ -195,6 +195,15 @@ def set_tuning(tile: int) -> None:
 ELL_PADDED = 1
 
 
+def _program_companions(prog, dtype) -> tuple[int | None, int | None]:
+    """``(vec_prog device pointer, host_prog host pointer)`` that ``level_program`` attached to a program tensor, if any."""
+    if prog is None:
+        return None, None
+    vec = getattr(prog, "vec_prog", {}).get(dtype)
+    host = getattr(prog, "host_prog", None)
+    return _ptr(vec), (None if host is None else host.ctypes.data)
+
+
 def regrid_ell(src, out, idx, w, *, n_src, n_tgt, k, n_lev, src_pitch, out_pitch, layout, prog=None, n_stage=0,
                tgt_mask=None, padded: bool = False) -> None:
     """out[t, l] = sum_j w[t, j] * src[idx[t, j], l]; ``w is None`` -> pure k = 1 gather;
@@ -203,9 +212,10 @@ def regrid_ell(src, out, idx, w, *, n_src, n_tgt, k, n_lev, src_pitch, out_pitch
     assert idx.dtype == torch.int32
     if w is not None:
         assert w.dtype == src.dtype, (w.dtype, src.dtype)
+    vec, host = _program_companions(prog, src.dtype)
     _call(
         "atx_regrid_ell", _ptr(src), _ptr(out), _ptr(idx), _ptr(w), n_src, n_tgt, k, n_lev, src_pitch, out_pitch,
-        dtype_code(src.dtype), layout, ELL_PADDED if padded else 0, _ptr(prog), n_stage, _ptr(tgt_mask), _stream(),
+        dtype_code(src.dtype), layout, ELL_PADDED if padded else 0, _ptr(prog), vec, host, n_stage, _ptr(tgt_mask), _stream(),
     )
 
 
@@ -220,9 +230,10 @@ def regrid_ell_batch(srcs, outs, idx, w, *, n_src, n_tgt, k, n_lev, src_pitch, o
     n = len(srcs)
     src_ptrs = (c_void_p * n)(*[_ptr(t) for t in srcs])
     out_ptrs = (c_void_p * n)(*[_ptr(t) for t in outs])
+    vec, host = _program_companions(prog, dtype)
     _call(
         "atx_regrid_ell_batch", ctypes.cast(src_ptrs, c_void_p), ctypes.cast(out_ptrs, c_void_p), n, _ptr(idx), _ptr(w), n_src,
-        n_tgt, k, n_lev, src_pitch, out_pitch, dtype_code(dtype), layout, ELL_PADDED if padded else 0, _ptr(prog), n_stage,
+        n_tgt, k, n_lev, src_pitch, out_pitch, dtype_code(dtype), layout, ELL_PADDED if padded else 0, _ptr(prog), vec, host, n_stage,
         _ptr(tgt_mask), _stream(),
     )
 
@@ -255,7 +266,9 @@ def level_program(stages: list[list[tuple[int, int, float, float]]], device) -> 
         for l, (op, use_mask, p0, p1) in enumerate(stage):
             host[s * n_lev + l] = (op, use_mask, p0, p1)
     raw = torch.from_numpy(host.view(np.uint8).copy()).to(device)
-    # per-vector forms (atx_vector_program, host side) ride along: kernels given them need no per-workgroup set-up
+    # the host copy and the per-vector forms (atx_vector_program, host side) ride along: kernels given them need no
+    # per-workgroup set-up (atx_regrid_ell: host_prog / vec_prog; atx_pointwise_stack: vec_prog)
+    raw.host_prog = host
     raw.vec_prog = {}
     if raw.is_cuda:
         lib = load()

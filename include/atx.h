@@ -112,7 +112,8 @@ const char* atx_strerror(int code);        /* host string, static */
 int atx_device_count(void);
 /* Tuning hook for benchmarks and tests: tile > 0 runs the ATX_COLUMNS regrid through the TILED kernels with that
  * many targets per workgroup; 0 = built-in choice (the direct kernel where it applies, else the tile heuristic).
- * Process-wide; results never depend on it. */
+ * PROCESS-WIDE and unsynchronised — the one exception to "no state": set it before other threads launch, not while
+ * they do (a racing launch may pick either kernel; results never depend on it, only speed). */
 int atx_set_tuning(int tile);
 
 /* ---- regrid: precomputed index(+weight) gather ---------------------------- */
@@ -136,6 +137,13 @@ int atx_set_tuning(int tile);
  *   the interpolated value before it is stored (the fused regrid -> per-point
  *   chain, R: workflows/pipeline.py:46-48 without materialising intermediates);
  *   tgt_mask (optional, uint8 [n_tgt]) is the point mask used by `use_mask`.
+ *   Two optional companions of prog (NULL is always valid; results never depend on them) keep the epilogue on the
+ *   fastest kernel, which has no per-workgroup set-up:
+ *     host_prog (HOST)   the same n_stage*n_lev entries as prog, readable by the library: when, per stage, the levels
+ *               run one operator — or one up to a level and another from there on (a stack "136 levels of t, then orog"),
+ *               the change on a 16-byte boundary — the operators (<= 4 stages) are passed to the kernel by value;
+ *     vec_prog  (device) atx_vector_program(prog) of the stack's dtype — the per-16-byte-vector operator table, used
+ *               (together with host_prog) for programs made of COPY / AFFINE / MUL with or without the mask, <= 4 stages.
  * Requirements: ATX_COLUMNS with 16-byte aligned bases and pitches that are
  *   multiples of 16 bytes take the vector path; anything else a scalar path.
  */
@@ -143,8 +151,8 @@ int atx_set_tuning(int tile);
 int atx_regrid_ell(const void* src, void* out, const int32_t* idx, const void* w,
                    int64_t n_src, int64_t n_tgt, int32_t k, int64_t n_lev,
                    int64_t src_pitch, int64_t out_pitch, int dtype, int layout, int32_t flags,
-                   const atx_level_op* prog, int32_t n_stage, const uint8_t* tgt_mask,
-                   void* stream);
+                   const atx_level_op* prog, const atx_level_op* vec_prog, const atx_level_op* host_prog,
+                   int32_t n_stage, const uint8_t* tgt_mask, void* stream);
 
 /* atx_regrid_ell applied to n_stack source stacks of identical shape, dtype and pitch with ONE launch per 16 stacks
  * (ATX_COLUMNS: grid.y = stack, no launch gaps or per-launch tails; field-major stacks are launched one after the
@@ -153,8 +161,8 @@ int atx_regrid_ell(const void* src, void* out, const int32_t* idx, const void* w
  *      pair (BASELINE config 4), or the N source stacks of a target-sharded multi-GPU step. */
 int atx_regrid_ell_batch(const void* const* srcs, void* const* outs, int32_t n_stack, const int32_t* idx, const void* w,
                          int64_t n_src, int64_t n_tgt, int32_t k, int64_t n_lev, int64_t src_pitch, int64_t out_pitch,
-                         int dtype, int layout, int32_t flags, const atx_level_op* prog, int32_t n_stage,
-                         const uint8_t* tgt_mask, void* stream);
+                         int dtype, int layout, int32_t flags, const atx_level_op* prog, const atx_level_op* vec_prog,
+                         const atx_level_op* host_prog, int32_t n_stage, const uint8_t* tgt_mask, void* stream);
 
 /*
  * General CSR interpolation: out[t, l] = sum_{jj in [indptr[t], indptr[t+1])} data[jj] * src[indices[jj], l]

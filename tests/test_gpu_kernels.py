@@ -177,6 +177,86 @@ def test_regrid_fused_epilogue(dev):
         assert np.array_equal(out.numpy(), want, equal_nan=True)
 
 
+@pytest.mark.parametrize("tdtype,np_dtype", DTYPES)
+@pytest.mark.parametrize("k,padded", [(1, False), (4, False), (3, True)])
+@pytest.mark.parametrize("program", ["uniform", "per_vector", "three_pieces", "mixed_madd", "mixed_vectors", "two_pieces_general", "masked",
+                                     "masked_uniform", "masked_3_stages"])
+def test_fused_epilogue_kernel_variants_agree(dev, tdtype, np_dtype, k, padded, program):
+    """The epilogue reaches the gather by three routes — operators by value in the kernel arguments (uniform programs seen
+    through host_prog), the host-built per-vector table (vec_prog), the tiled kernel's LDS table (neither companion) — and
+    all three must give the bits of the oracle's chain `csr @ x` then the per-level statements."""
+    rng = np.random.default_rng(31)
+    n_src, n_tgt, n_lev = 3000, 2111, 21  # 21 levels: a ragged last vector for both dtypes
+    x = make_fields(rng, n_lev, n_src, np_dtype)
+    idx, w = random_ell(rng, n_src, n_tgt, k, np_dtype)
+    if padded:
+        drop = rng.random(idx.shape) < 0.2
+        drop[:, 0] = False
+        idx = np.where(drop, -1, idx).astype(np.int32)
+        w = np.where(drop, 0.0, w).astype(np_dtype)
+    mul, aff, cp = (native.OP_MUL, 0, oracle.G, 0.0), (native.OP_AFFINE, 0, 1.0, -273.15), (native.OP_COPY, 0, 0.0, 0.0)
+    if program == "uniform":  # every level the same two operators: eligible for the by-value kernel
+        stages = [[mul] * n_lev, [aff] * n_lev]
+    elif program == "per_vector":  # operators change at vector boundaries of BOTH dtypes (multiples of 4 levels)
+        stages = [[mul if l < 8 else cp for l in range(n_lev)], [aff if l >= 12 else cp for l in range(n_lev)]]
+    elif program == "three_pieces":  # three runs of levels: beyond the two pieces that travel by value -> per-vector table
+        stages = [[mul if l < 4 else (cp if l < 12 else aff) for l in range(n_lev)]]
+    elif program == "two_pieces_general":  # two pieces, operators outside the multiply-add family (by value: both evaluated, one kept)
+        stages = [[(native.OP_CLIP, 0, 250.0, 300.0) if l < 16 else (native.OP_AFFINE_INV, 0, 2.0, 1.0) for l in range(n_lev)],
+                  [(native.OP_LOG, 0, 0.0, 0.0) if l < 4 else (native.OP_DIV, 0, 3.0, 0.0) for l in range(n_lev)]]
+    elif program == "masked_uniform":  # convert everywhere, then apply_mask everywhere: by value, with the mask
+        stages = [[aff] * n_lev, [(native.OP_COPY, 1, 0.0, 0.0)] * n_lev]
+    elif program == "mixed_madd":  # operators differ inside a vector, all of the multiply-add family (direct kernel, per-level path)
+        stages = [[mul if l % 3 == 0 else cp for l in range(n_lev)], [aff if l % 2 else cp for l in range(n_lev)]]
+    elif program == "masked_3_stages":  # BASELINE config 5 with apply_mask: orog_to_z on one level, convert on the others, mask on some
+        stages = [[cp] * (n_lev - 1) + [mul], [aff] * (n_lev - 1) + [cp], [(native.OP_COPY, 1 if l % 5 else 0, 0.0, 0.0) for l in range(n_lev)]]
+    elif program == "mixed_vectors":  # operators differ inside a vector, general operators (tiled kernel)
+        stages = [[mul if l % 3 == 0 else cp for l in range(n_lev)], [aff if l % 2 else (native.OP_CLIP, 0, 250.0, 300.0) for l in range(n_lev)]]
+    else:
+        stages = [[(native.OP_AFFINE, 1 if l in (2, 20) else 0, 2.0, 1.0) for l in range(n_lev)]]
+    tmask = rng.random(n_tgt) < 0.3
+    tmask_d = to_dev(tmask.astype(np.uint8), dev) if program.startswith("masked") else None
+    src = Stack.from_fields(x, dev=dev)
+    idx_d, w_d = to_dev(idx, dev), (to_dev(w, dev) if (k > 1 or padded) else None)
+
+    def run(strip):
+        prog = native.level_program(stages, dev)
+        for name in strip:
+            if name == "vec_prog":
+                prog.vec_prog = {}
+            else:
+                prog.host_prog = None
+        out = src.new_like(n_pts=n_tgt)
+        native.regrid_ell(src.data, out.data, idx_d, w_d, n_src=n_src, n_tgt=n_tgt, k=k, n_lev=n_lev, src_pitch=src.pitch,
+                          out_pitch=out.pitch, layout=COLUMNS, prog=prog, n_stage=len(stages), tgt_mask=tmask_d, padded=padded)
+        return out.numpy()
+
+    full, table_only, tiled = run(()), run(("host_prog",)), run(("host_prog", "vec_prog"))
+    # oracle chain
+    if k == 1 and not padded:
+        want = np.stack([oracle.gather_nn(f, idx[:, 0]) for f in x])
+    else:
+        present = idx >= 0
+        lengths = present.sum(axis=1)
+        indptr = np.concatenate([[0], np.cumsum(lengths)])
+        want = np.stack([oracle.csr_apply(w[present], idx[present], indptr, (n_tgt, n_src), f) for f in x])
+    table = native.LEVEL_OP_DTYPE
+    for stage in stages:
+        for l, (op, use_mask, p0, p1) in enumerate(stage):
+            entry = np.zeros((), dtype=table)
+            entry["op"], entry["use_mask"], entry["p0"], entry["p1"] = op, use_mask, p0, p1
+            import native_double
+
+            want[l] = native_double._apply_op(entry, want[l], tmask if use_mask else None)
+    libm = any(op in (native.OP_LOG, native.OP_EXP) for stage in stages for (op, _, _, _) in stage)  # ocml vs libm: a few ulp
+    for got in (full, table_only, tiled):
+        if (np_dtype == np.float64 or (k == 1 and not padded)) and not libm:
+            assert np.array_equal(got, want, equal_nan=True)
+        else:
+            np.testing.assert_allclose(got, want, rtol=RTOL_F32 if np_dtype == np.float32 else 1e-14, atol=1e-4, equal_nan=True)
+    assert np.array_equal(full, tiled, equal_nan=True) and np.array_equal(table_only, tiled, equal_nan=True)  # same arithmetic, same bits
+
+
 def test_check_indices(dev):
     idx = np.array([0, 5, 9, 10, -1, 3], dtype=np.int32)
     assert native.check_indices(to_dev(idx, dev), 10) == 2

@@ -425,14 +425,15 @@ def test_abi_argument_validation_without_a_gpu():
     lib = native.load()
     assert lib.atx_version() == 200
     assert lib.atx_strerror(native.ESHAPE) == b"shape mismatch"
-    assert lib.atx_regrid_ell(None, None, None, None, 1, 1, 1, 1, 1, 1, 0, 0, 0, None, 0, None, None) == native.EINVAL
+    assert lib.atx_regrid_ell(None, None, None, None, 1, 1, 1, 1, 1, 1, 0, 0, 0, None, None, None, 0, None, None) == native.EINVAL
     assert b"null" in lib.atx_last_error()
     one = ctypes.c_void_p(16)  # never dereferenced: validation fails first
-    assert lib.atx_regrid_ell(one, one, one, None, 8, 8, 1, 4, 2, 4, 0, 0, 0, None, 0, None, None) == native.ESHAPE
-    assert lib.atx_regrid_ell(one, one, one, None, 8, 8, 3, 4, 4, 4, 0, 0, 0, None, 0, None, None) == native.EINVAL
-    assert lib.atx_regrid_ell(one, one, one, one, 8, 8, 99, 4, 4, 4, 0, 0, 0, None, 0, None, None) == native.EINVAL
-    assert lib.atx_regrid_ell(one, one, one, None, 8, 8, 1, 4, 4, 4, 7, 0, 0, None, 0, None, None) == native.EINVAL
-    assert lib.atx_regrid_ell(one, one, one, None, 8, 8, 1, 4, 4, 4, 0, 0, 1, None, 0, None, None) == native.EINVAL  # padded needs weights
+    assert lib.atx_regrid_ell(one, one, one, None, 8, 8, 1, 4, 2, 4, 0, 0, 0, None, None, None, 0, None, None) == native.ESHAPE
+    assert lib.atx_regrid_ell(one, one, one, None, 8, 8, 3, 4, 4, 4, 0, 0, 0, None, None, None, 0, None, None) == native.EINVAL
+    assert lib.atx_regrid_ell(one, one, one, one, 8, 8, 99, 4, 4, 4, 0, 0, 0, None, None, None, 0, None, None) == native.EINVAL
+    assert lib.atx_regrid_ell(one, one, one, None, 8, 8, 1, 4, 4, 4, 7, 0, 0, None, None, None, 0, None, None) == native.EINVAL
+    assert lib.atx_regrid_ell(one, one, one, None, 8, 8, 1, 4, 4, 4, 0, 0, 1, None, None, None, 0, None, None) == native.EINVAL  # padded needs weights
+    assert lib.atx_regrid_ell(one, one, one, None, 8, 8, 1, 4, 4, 4, 0, 0, 0, None, one, None, 0, None, None) == native.EINVAL  # vec_prog without prog
     assert lib.atx_pointwise_stack(one, one, 8, 4, 4, 4, 0, 0, one, None, 0, None, None) == native.EINVAL
     assert lib.atx_mask_build(one, 1, one, 8, 99, 0.0, 0, None) == native.EINVAL
     assert lib.atx_relayout(one, one, 8, 4, 4, 8, 0, 1, 0, None) == native.EINVAL  # in place
