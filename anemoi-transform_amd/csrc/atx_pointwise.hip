@@ -221,6 +221,58 @@ pointwise_cols_table_kernel(const T* __restrict__ x, T* __restrict__ y, int64_t 
     pw_store<T, VEC>(y + vi * VEC, v);
 }
 
+// In place with FEW active levels (1 of 137: one variable of a stack converted, a mask applied to one field): only the
+// vector columns that hold an active level are visited — one (point, active column) item per lane, the column list by value in
+// the kernel arguments.  The kernels above skip the loads of untouched columns too, but still walk all n_pts*C vector slots
+// with 1 lane in 35 doing anything (1.53 ms for 1 of 137 levels on O1280, more than transforming the whole stack); here every
+// lane has a 16-byte read-modify-write in flight.  The traffic is one 64/128-byte line per point and active column either way.
+constexpr int kMaxActive = 16;
+struct ActiveCols {
+    int n;
+    int col[kMaxActive];
+};
+
+template <typename T, int VEC>
+__global__ void __launch_bounds__(kBlock)
+pointwise_cols_sparse_kernel(T* __restrict__ y, int64_t n_items, int n_lev, int C, int64_t pitch, ActiveCols active,
+                             const atx_level_op* __restrict__ prog, const atx_level_op* __restrict__ vec_prog, int n_stage,
+                             const uint8_t* __restrict__ point_mask) {
+    using V = Pack<T, VEC>;
+    const int64_t q = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (q >= n_items) return;
+    const int64_t p = q / active.n;
+    const int a = (int)(q - p * active.n);
+    int c = active.col[0];
+#pragma unroll
+    for (int i = 1; i < kMaxActive; ++i) c = (a == i) ? active.col[i] : c;  // the list lives in scalar registers: select, do not index
+    LevelOp<T> ops[8];
+    bool need_mask = false;
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+        if (s < n_stage) {
+            ops[s] = load_level_op<T>(vec_prog, (int64_t)s * C + c);
+            need_mask = need_mask || ops[s].use_mask != 0;
+        }
+    }
+    T* at = y + p * pitch + (int64_t)c * VEC;
+    V v = pw_load<T, VEC>(at);
+    const bool masked = (need_mask && point_mask) ? (point_mask[p] != 0) : false;
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+        if (s >= n_stage) break;
+        if (ops[s].op != kOpMixed) {
+            apply_level_op_vec<T, VEC>(ops[s], v, masked);
+        } else {
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) {
+                const int l = c * VEC + e;
+                if (l < n_lev) v.v[e] = apply_level_op(load_level_op<T>(prog, (int64_t)s * n_lev + l), v.v[e], masked);
+            }
+        }
+    }
+    pw_store<T, VEC>(at, v);
+}
+
 // ATX_FIELDS: grid.y = level (operator uniform per workgroup), lanes along points.
 template <typename T, int VEC>
 __global__ void __launch_bounds__(kBlock)
@@ -499,7 +551,8 @@ static unsigned grid_for(int64_t items) {
 
 template <typename T>
 static int pointwise_typed(const void* x_, void* y_, int64_t n_pts, int n_lev, int64_t xp, int64_t yp, int layout,
-                           const atx_level_op* prog, const atx_level_op* vec_prog, int n_stage, const uint8_t* mask, hipStream_t st) {
+                           const atx_level_op* prog, const atx_level_op* vec_prog, const atx_level_op* host_prog, int n_stage,
+                           const uint8_t* mask, hipStream_t st) {
     const T* x = static_cast<const T*>(x_);
     T* y = static_cast<T*>(y_);
     const int in_place = (x_ == y_ && xp == yp) ? 1 : 0;
@@ -511,6 +564,35 @@ static int pointwise_typed(const void* x_, void* y_, int64_t n_pts, int n_lev, i
         const int C = wide ? (n_lev + VEC - 1) / VEC : n_lev;
         const size_t lds = (size_t)n_stage * C * sizeof(LevelOp<T>);
         ATX_REQUIRE(lds <= 64 * 1024, ATX_ENOTIMPL, "pointwise: program needs %zu B of LDS", lds);
+#ifndef ATX_PW_SPARSE
+#define ATX_PW_SPARSE 1
+#endif
+        if (ATX_PW_SPARSE && in_place && wide && host_prog && vec_prog) {  // few active levels, in place: visit their columns only
+            ActiveCols active{};
+            bool fits = true;
+            for (int c = 0; c < C && fits; ++c) {
+                bool act = false;
+                for (int s = 0; s < n_stage && !act; ++s)
+                    for (int l = c * VEC; l < n_lev && l < (c + 1) * VEC && !act; ++l) {
+                        const atx_level_op& o = host_prog[(int64_t)s * n_lev + l];
+                        act = o.op != ATX_OP_COPY || o.use_mask != 0;
+                    }
+                if (!act) continue;
+                if (active.n == kMaxActive) fits = false;
+                else active.col[active.n++] = c;
+            }
+            if (fits && active.n == 0) return ATX_OK;  // nothing to do at all
+            if (fits && 3 * active.n <= C) {
+                for (int i = active.n; i < kMaxActive; ++i) active.col[i] = active.col[0];
+                const int64_t n_items = n_pts * active.n;
+                const int64_t blocks = (n_items + kBlock - 1) / kBlock;
+                ATX_REQUIRE(blocks <= 0x7fffffffll, ATX_ENOTIMPL, "pointwise: %lld items exceed one launch", (long long)n_items);
+                hipLaunchKernelGGL((pointwise_cols_sparse_kernel<T, VEC>), dim3((unsigned)blocks), dim3(kBlock), 0, st, y, n_items, n_lev, C, yp,
+                                   active, prog, vec_prog, n_stage, mask);
+                ATX_LAUNCH_CHECK("pointwise_stack_sparse");
+                return ATX_OK;
+            }
+        }
 #ifndef ATX_PW_FLAT
 #define ATX_PW_FLAT 1
 #endif
@@ -567,7 +649,8 @@ using namespace atx;
 
 extern "C" int atx_pointwise_stack(const void* x, void* y, int64_t n_pts, int64_t n_lev, int64_t x_pitch,
                                    int64_t y_pitch, int dtype, int layout, const atx_level_op* prog,
-                                   const atx_level_op* vec_prog, int32_t n_stage, const uint8_t* point_mask, void* stream) {
+                                   const atx_level_op* vec_prog, const atx_level_op* host_prog, int32_t n_stage,
+                                   const uint8_t* point_mask, void* stream) {
     ATX_REQUIRE(x && y && prog, ATX_EINVAL, "atx_pointwise_stack: null pointer");
     ATX_REQUIRE(dtype == ATX_F32 || dtype == ATX_F64, ATX_EINVAL, "atx_pointwise_stack: bad dtype %d", dtype);
     ATX_REQUIRE(layout == ATX_COLUMNS || layout == ATX_FIELDS, ATX_EINVAL, "atx_pointwise_stack: bad layout %d", layout);
@@ -579,8 +662,9 @@ extern "C" int atx_pointwise_stack(const void* x, void* y, int64_t n_pts, int64_
                 (long long)x_pitch, (long long)y_pitch, (long long)need);
     if (n_pts == 0) return ATX_OK;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (dtype == ATX_F32) return pointwise_typed<float>(x, y, n_pts, (int)n_lev, x_pitch, y_pitch, layout, prog, vec_prog, n_stage, point_mask, s);
-    return pointwise_typed<double>(x, y, n_pts, (int)n_lev, x_pitch, y_pitch, layout, prog, vec_prog, n_stage, point_mask, s);
+    if (dtype == ATX_F32)
+        return pointwise_typed<float>(x, y, n_pts, (int)n_lev, x_pitch, y_pitch, layout, prog, vec_prog, host_prog, n_stage, point_mask, s);
+    return pointwise_typed<double>(x, y, n_pts, (int)n_lev, x_pitch, y_pitch, layout, prog, vec_prog, host_prog, n_stage, point_mask, s);
 }
 
 extern "C" int atx_mask_build(const void* m, int64_t m_stride, uint8_t* mask, int64_t n, int cmp, double threshold,

@@ -827,6 +827,10 @@ static int launch_cols_csr(const T* src, T* out, const int32_t* indptr, const in
                            int64_t n_tgt, int64_t nnz, int n_lev, int64_t sp, int64_t op,
                            const atx_level_op* prog, int n_stage, const uint8_t* m, hipStream_t st) {
     const int C = (n_lev + VEC - 1) / VEC;
+    // (A "direct" form of this kernel — one item per lane, row walked from the CSR arrays in L1 — was measured and dropped: rows of
+    // 3-4 entries 0.478 ms against 0.450 ms tiled, rows of 9-16 entries 1.06 against 1.01 ms f32, 2.03 against 2.10 ms f64; with 8
+    // entries in flight and the next step's words prefetched 1.10 ms.  The extra dependent load level — row bounds, entries, source
+    // columns — costs what the missing barrier saves; profiles/r02_csr_direct_experiment.log.)
     int tile = g_tile_override > 0 ? g_tile_override : pick_tile(n_tgt, C, prog != nullptr);
     if ((int64_t)tile > n_tgt) tile = (int)n_tgt;
     const unsigned n_tiles = (unsigned)((n_tgt + tile - 1) / tile);

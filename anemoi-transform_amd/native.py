@@ -73,7 +73,7 @@ SIGNATURES: dict[str, tuple[Any, list[Any]]] = {
     "atx_check_indices": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_void_p]),
     "atx_pointwise_stack": (
         c_int,
-        [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int64, c_int, c_int, c_void_p, c_void_p, c_int32, c_void_p, c_void_p],
+        [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int64, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_void_p],
     ),
     "atx_combine_stack": (
         c_int,
@@ -284,10 +284,10 @@ def level_program(stages: list[list[tuple[int, int, float, float]]], device) -> 
 
 def pointwise_stack(x, y, *, n_pts, n_lev, x_pitch, y_pitch, layout, prog, n_stage, point_mask=None) -> None:
     assert x.dtype == y.dtype
-    vec = getattr(prog, "vec_prog", {}).get(x.dtype)
+    vec, host = _program_companions(prog, x.dtype)
     _call(
         "atx_pointwise_stack", _ptr(x), _ptr(y), n_pts, n_lev, x_pitch, y_pitch, dtype_code(x.dtype), layout,
-        _ptr(prog), _ptr(vec), n_stage, _ptr(point_mask), _stream(),
+        _ptr(prog), vec, host, n_stage, _ptr(point_mask), _stream(),
     )
 
 

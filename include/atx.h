@@ -188,14 +188,18 @@ int atx_check_indices(const int32_t* idx, int64_t n, int64_t n_src, int64_t* n_b
  * y[p, l] = prog_{n_stage-1}( ... prog_0(x[p, l]) )  for every level l of a stack.
  * x == y (in place) is allowed when the pitches agree.  point_mask: uint8
  * [n_pts] or NULL (required if any stage has use_mask).
+ * vec_prog (device, optional): atx_vector_program(prog) of the stack's dtype; host_prog (HOST, optional): the same
+ * entries as prog, readable by the library.  With both, an IN-PLACE call whose program leaves most levels alone
+ * (ATX_OP_COPY) visits only the 16-byte columns holding an active level (1 of 137 levels: 5x faster).  NULL is always
+ * valid for either; results never depend on them.
  *   R: filter.py:188-196 (SingleFieldFilter map over fields), rescale.py:25,28,
  *      orog_to_z.py:59,77, clipper.py:69, impute_nans.py:53-54, lnsp_to_sp.py:47,65,
  *      apply_mask.py:183-185, glacier_mask.py:33
  */
 int atx_pointwise_stack(const void* x, void* y, int64_t n_pts, int64_t n_lev,
                         int64_t x_pitch, int64_t y_pitch, int dtype, int layout,
-                        const atx_level_op* prog, const atx_level_op* vec_prog, int32_t n_stage,
-                        const uint8_t* point_mask, void* stream);
+                        const atx_level_op* prog, const atx_level_op* vec_prog, const atx_level_op* host_prog,
+                        int32_t n_stage, const uint8_t* point_mask, void* stream);
 
 /* Per-vector form of a per-level program, computed on the HOST (no device access): out[s*C + c] is the operator shared
  * by the levels c*V .. c*V+V-1 of stage s (V = 16 bytes / sizeof(dtype), C = ceil(n_lev / V); padding levels join any

@@ -335,6 +335,38 @@ def test_pointwise_ops_bit_exact(dev, tdtype, np_dtype, layout, in_place):
         np.testing.assert_allclose(got[l], want[l], rtol=1e-6 if np_dtype == np.float32 else 1e-14, equal_nan=True)
 
 
+@pytest.mark.parametrize("tdtype,np_dtype", DTYPES)
+@pytest.mark.parametrize("selected", [[5], [0, 77, 136], [3, 4, 5, 6, 7, 8], list(range(0, 137, 7)), list(range(0, 137, 2))])
+def test_pointwise_in_place_with_few_active_levels(dev, tdtype, np_dtype, selected):
+    """In place, a program that leaves most levels alone visits only the columns of the active ones (sparse kernel: up to 16
+    vector columns and a third of the stack; beyond that the sweeping kernels): same stack as the out-of-place call,
+    untouched levels bit-identical to the input, with and without the host-side companions of the program."""
+    rng = np.random.default_rng(5)
+    n_pts, n_lev = 7001, 137
+    x = make_fields(rng, n_lev, n_pts, np_dtype, nan_frac=0.01)
+    mask = rng.random(n_pts) < 0.25
+    cp = (native.OP_COPY, 0, 0.0, 0.0)
+    stages = [[(native.OP_AFFINE, 0, 2.0, -1.0) if l in selected else cp for l in range(n_lev)],
+              [(native.OP_CLIP, 1 if l == selected[0] else 0, 100.0, 600.0) if l in selected else cp for l in range(n_lev)]]
+    mask_d = to_dev(mask.astype(np.uint8), dev)
+    src = Stack.from_fields(x, dev=dev)
+    want = src.new_like()
+    kw = dict(n_pts=n_pts, n_lev=n_lev, x_pitch=src.pitch, y_pitch=want.pitch, layout=COLUMNS, n_stage=2, point_mask=mask_d)
+    native.pointwise_stack(src.data, want.data, prog=native.level_program(stages, dev), **kw)
+    expect = x.copy()
+    for l in selected:
+        expect[l] = oracle.clip(oracle.rescale_forward(x[l], np_dtype(2.0), np_dtype(-1.0)), np_dtype(100.0), np_dtype(600.0))
+    expect[selected[0]][mask] = np.nan
+    assert np.array_equal(want.numpy(), expect, equal_nan=True)
+    for strip in (False, True):
+        y = Stack(src.data.clone(), n_pts, n_lev, COLUMNS)
+        prog = native.level_program(stages, dev)
+        if strip:
+            prog.host_prog, prog.vec_prog = None, {}
+        native.pointwise_stack(y.data, y.data, prog=prog, **kw)
+        assert torch.equal(y.data.view(torch.uint8), want.data.view(torch.uint8)), (selected, strip)
+
+
 @pytest.mark.parametrize("layout", LAYOUTS)
 def test_pointwise_mask_and_two_stages(dev, layout):
     """R: apply_mask.py:185 after R: rescale.py:25 in one pass; unselected levels untouched."""

@@ -434,7 +434,7 @@ def test_abi_argument_validation_without_a_gpu():
     assert lib.atx_regrid_ell(one, one, one, None, 8, 8, 1, 4, 4, 4, 7, 0, 0, None, None, None, 0, None, None) == native.EINVAL
     assert lib.atx_regrid_ell(one, one, one, None, 8, 8, 1, 4, 4, 4, 0, 0, 1, None, None, None, 0, None, None) == native.EINVAL  # padded needs weights
     assert lib.atx_regrid_ell(one, one, one, None, 8, 8, 1, 4, 4, 4, 0, 0, 0, None, one, None, 0, None, None) == native.EINVAL  # vec_prog without prog
-    assert lib.atx_pointwise_stack(one, one, 8, 4, 4, 4, 0, 0, one, None, 0, None, None) == native.EINVAL
+    assert lib.atx_pointwise_stack(one, one, 8, 4, 4, 4, 0, 0, one, None, None, 0, None, None) == native.EINVAL
     assert lib.atx_mask_build(one, 1, one, 8, 99, 0.0, 0, None) == native.EINVAL
     assert lib.atx_relayout(one, one, 8, 4, 4, 8, 0, 1, 0, None) == native.EINVAL  # in place
     assert lib.atx_mask_to_index_workspace(4096 * 3) >= 16

@@ -78,9 +78,35 @@ def main():
         padded = GatherPlan.from_matrix(dict(matrix_data=w[keep], matrix_indices=idx[keep], matrix_indptr=indptr, matrix_shape=(n_tgt, n_src)))
         assert padded.padded
         record(f"regrid ragged(3-4) as padded fixed-k {tag}", timeit(lambda: padded.apply(x)), csr_bytes, "what regrid(matrix=...) uses for short ragged rows")
+        tile = 16 if B == 4 else 8  # what the tiled kernels' heuristic picks at 137 levels
+        native.set_tuning(tile)
+        record(f"regrid_csr ragged(3-4) {tag} columns, TILED kernel", timeit(lambda: csr.apply(x)), csr_bytes, "round 1's kernel (LDS-staged CSR slice)")
+        native.set_tuning(0)
+        # long rows: 16 nearest neighbours, and the same with entries dropped (rows of 9-16)
+        idx16, w16 = interp.knn_inverse_distance(src_grid, tgt_grid, k=16, device=True, ties="index")
+        U16 = int(np.unique(idx16).size)
+        plan16 = GatherPlan(n_src, n_tgt, index=idx16, weights=w16)
+        bytes16 = bench.algorithmic_bytes(L, B, U16, n_tgt, 16)
+        record(f"regrid_ell k=16 {tag} columns", timeit(lambda: plan16.apply(x)), bytes16, "fixed k beyond 4: tiled kernel, runtime k")
+        rng16 = np.random.default_rng(16)
+        keep16 = rng16.random(idx16.shape) < 0.75
+        keep16[:, :9] = True
+        indptr16 = np.concatenate([[0], np.cumsum(keep16.sum(axis=1))])
+        csr16 = GatherPlan(n_src, n_tgt, csr=(w16[keep16], idx16[keep16], indptr16))
+        nnz16 = int(keep16.sum())
+        csr16_bytes = L * B * (int(np.unique(idx16[keep16]).size) + n_tgt) + nnz16 * (4 + B) + 4 * n_tgt
+        record(f"regrid_csr rows of 9-16 {tag} columns", timeit(lambda: csr16.apply(x)), csr16_bytes, "general CSR, direct kernel")
+        native.set_tuning(tile)
+        record(f"regrid_csr rows of 9-16 {tag} columns, TILED kernel", timeit(lambda: csr16.apply(x)), csr16_bytes, "round 1's kernel")
+        native.set_tuning(0)
+        del plan16, csr16, idx16, w16
         prog = native.level_program([[(native.OP_MUL, 0, 9.80665, 0.0)] * L, [(native.OP_AFFINE, 0, 1.0, -273.15)] * L], dev)
         record(f"regrid_ell k=4 {tag} + 2-stage epilogue", timeit(lambda: plan4.apply(x, prog=prog, n_stage=2)),
-               bench.algorithmic_bytes(L, B, U4, n_tgt, 4), "fused regrid -> orog_to_z -> rescale")
+               bench.algorithmic_bytes(L, B, U4, n_tgt, 4), "fused regrid -> orog_to_z -> rescale, every level")
+        cp = (native.OP_COPY, 0, 0.0, 0.0)
+        prog5 = native.level_program([[cp] * (L - 1) + [(native.OP_MUL, 0, 9.80665, 0.0)], [(native.OP_AFFINE, 0, 1.0, -273.15)] * (L - 1) + [cp]], dev)
+        record(f"regrid_ell k=4 {tag} + config-5 epilogue", timeit(lambda: plan4.apply(x, prog=prog5, n_stage=2)),
+               bench.algorithmic_bytes(L, B, U4, n_tgt, 4), "136 levels convert, 1 level orog_to_z: operators by value, two pieces")
         # ---- per-point
         y = x.new_like()
         record(f"(ceiling) torch copy_ of the stack {tag}", timeit(lambda: y.data.copy_(x.data)), 2 * x.data.numel() * B,

@@ -88,7 +88,7 @@ def main():
         "cols_copy_bytes": cols_copy_bytes,
         "calibration_read_bytes": calib_bytes,
         "calibration_write_bytes": calib_bytes,
-        "regrid_kernel": "regrid_cols_ell_direct_kernel",
+        "regrid_kernel": "regrid_cols_ell_direct_kernel" if args.k <= 4 else "regrid_cols_ell_kernel",
         "regrid_launches": args.launches,
         "algorithmic_bytes_per_launch": bench.algorithmic_bytes(args.levels, itemsize, int(np.unique(idx64).size), n_tgt, args.k),
     }

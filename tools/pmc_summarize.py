@@ -42,7 +42,7 @@ def main():
     ap.add_argument("--write-dir", default=os.path.join(ROOT, "gpurun_out", "pmc_write"))
     ap.add_argument("--meta", default=os.path.join(ROOT, "gpurun_out", "pmc_meta.json"))
     ap.add_argument("--out", default=os.path.join(ROOT, "profiles", "traffic.json"))
-    ap.add_argument("--round", default="r01")
+    ap.add_argument("--round", default="r02")
     args = ap.parse_args()
 
     meta = json.load(open(args.meta))
@@ -57,6 +57,7 @@ def main():
     w_raw = sum(write[kern]) / len(write[kern]) * 1024
     rec = {
         "round": args.round,
+        "measured": f"round {args.round.lstrip('r0') or '0'}",
         "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) on tools/pmc_probe.py",
         "calibration": {
             "kernel": meta["calibration_kernel"],
