@@ -59,6 +59,26 @@ def set_data_group(group) -> None:
     _data_group = group
 
 
+def warm_up_transport() -> None:
+    """One-element messages over every route the stack traffic will take on the data group — a broadcast from every rank and
+    a send/recv between every pair — so that the collective library's set-up (RCCL: communicator, rings, point-to-point
+    channels) is not billed to the first real exchange."""
+    rank, world = dist.get_rank(), dist.get_world_size()
+    device = torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else torch.device("cpu")
+    token = torch.zeros(1, dtype=torch.float32, device=device)
+    for r in range(world):
+        dist.broadcast(token, src=r, group=_data_group)
+    inbox = [torch.zeros(1, dtype=torch.float32, device=device) for _ in range(world)]
+    ops = []
+    for r in range(world):
+        if r != rank:
+            ops.append(dist.P2POp(dist.isend, token, r, group=_data_group))
+            ops.append(dist.P2POp(dist.irecv, inbox[r], r, group=_data_group))
+    if ops:
+        for work in dist.batch_isend_irecv(ops):
+            work.wait()
+
+
 def atx_comm_from_torch():
     """A ``native.Comm`` (RCCL through the C ABI) spanning the ranks of the initialised torch.distributed job: rank 0
     draws the unique id, the job's own transport (any backend) hands it round."""

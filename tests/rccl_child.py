@@ -60,6 +60,8 @@ def main() -> None:
     want = np.stack([oracle.csr_apply(w.astype(np.float32).reshape(-1), idx.reshape(-1), indptr, (n_tgt, n_src), f) for f in host])
     mine = Stack.from_fields(host, dev=dev)
 
+    if comm is None:
+        atxd.warm_up_transport()
     got = atxd.broadcast_stack(mine, 0, n_pts=n_src, n_lev=n_lev, dtype=mine.dtype, device=dev, comm=comm)
     checks["broadcast_stack"] = bool(np.array_equal(got.numpy(), host))
     stacks = atxd.exchange_stacks(mine, comm=comm)

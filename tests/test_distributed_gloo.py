@@ -69,6 +69,7 @@ def _worker(rank: int, world: int, port: int, kind: str, tmpdir: str) -> None:
     mine = Stack.from_fields(mine_host, dev=torch.device("cpu"))
 
     # 1. sources exchanged once, then every rank interpolates its target slice of every stack
+    atxd.warm_up_transport()  # what bench.py does before it times an exchange
     stacks = atxd.exchange_stacks(mine)
     assert len(stacks) == world
     for r, st in enumerate(stacks):
