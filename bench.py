@@ -70,6 +70,9 @@ def parse_args():
                     help="N > 1: backend of the group that carries the stacks (nccl = RCCL over xGMI); barriers always run on gloo")
     ap.add_argument("--secondary-seconds", type=float, default=240.0,
                     help="N > 1: wall-clock budget of the lines measured after `value`; when it runs out the JSON line is printed with what is there")
+    ap.add_argument("--rehearse-multi", action="store_true",
+                    help="REHEARSAL ONLY, with --gpus 1: run the N > 1 secondary sections (RCCL exchange through torch.distributed and through "
+                         "atx_comm_*, end to end, strong) at world size 1 — the whole multi-GPU code path on the real collective library")
     ap.add_argument("--share-device", action="store_true",
                     help="REHEARSAL ONLY: all ranks use cuda:0 (exercises the N > 1 code path on a 1-GPU box; needs --backend gloo)")
     return ap.parse_args()
@@ -146,19 +149,25 @@ def main():
     dev = torch.device("cuda", 0 if args.share_device else local_rank)
     torch.cuda.set_device(dev)
     dist = None
-    if world > 1:
+    multi = world > 1 or args.rehearse_multi
+    if multi:
         import torch.distributed as dist
 
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         assert not (args.share_device and args.backend == "nccl"), "RCCL needs one GPU per rank"
+        if world == 1:  # --rehearse-multi without a launcher
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29541")
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("gloo")  # host-side: barriers, the max-over-ranks of the elapsed time
 
     def barrier():
-        if world > 1:
+        if multi:
             dist.barrier()
 
     def max_over_ranks(seconds: float) -> float:
-        if world == 1:
+        if not multi:
             return seconds
         t = torch.tensor([seconds], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -263,8 +272,9 @@ def main():
                         if world > 1 else "single GPU",
             "launches_per_step_per_gpu": 1 if layout == COLUMNS else world,
             **({"collectives": f"stacks: {args.backend} group ({'RCCL over xGMI' if args.backend == 'nccl' else 'gloo'}); "
-                               "barriers and the max-over-ranks of the elapsed time: gloo group"} if world > 1 else {}),
+                               "barriers and the max-over-ranks of the elapsed time: gloo group"} if multi else {}),
             **({"rehearsal": "ranks share one GPU over gloo; not a scaling measurement"} if args.share_device else {}),
+            **({"rehearsal": "N > 1 sections at world size 1 (RCCL code path on one GPU); not a scaling measurement"} if args.rehearse_multi else {}),
         },
         "roofline": {
             "bound": "hbm",
@@ -283,17 +293,17 @@ def main():
         "precompute_s": precompute_s,
     }
 
-    if world > 1 and not args.no_extras:
+    if multi and not args.no_extras:
         multi_gpu_lines(args, result, dist, rank, world, dev, plan, stacks, outs, launch, units_per_step, barrier, max_over_ranks,
                         src_grid, n_src, n_tgt, tdtype, np_dtype, idx64, w64, layout)
 
-    if rank == 0 and world == 1:
+    if rank == 0 and world == 1 and not args.rehearse_multi:
         single_gpu_lines(args, result, dev, stacks, outs, launch, idx_d, w_d, idx64, w64, n_src, n_tgt, n_unique, alg, src_grid, tgt_grid,
                          tdtype, np_dtype, itemsize)
 
     if rank == 0:
         print(json.dumps(result), flush=True)
-    if world > 1:
+    if multi:
         barrier()
         dist.destroy_process_group()
 
@@ -304,6 +314,7 @@ def main():
 def multi_gpu_lines(args, result, dist, rank, world, dev, plan, stacks, outs, launch, units_per_step, barrier, max_over_ranks,
                     src_grid, n_src, n_tgt, tdtype, np_dtype, idx64, w64, layout):
     from anemoi_transform_amd import distributed as atxd
+    from anemoi_transform_amd import native
     from anemoi_transform_amd.stack import COLUMNS, Stack
 
     # A hung collective must not cost the line that is already measured: when the budget runs out every rank leaves, and
@@ -423,6 +434,44 @@ def multi_gpu_lines(args, result, dist, rank, world, dev, plan, stacks, outs, la
                 "note": "one step INCLUDING the exchange of the N source stacks: broadcast r+1 (RCCL) overlapped with launch r, two source buffers alive"}
 
     result["end_to_end"] = section("end_to_end", end_to_end)
+
+    # ---- the same exchanges through the library's own C-ABI communicator (atx_comm_*: RCCL bound directly)
+    if args.backend == "nccl":
+        c_abi = {}
+        detail["c_abi"] = c_abi
+        holder = {}
+
+        def c_abi_init():
+            holder["comm"] = atxd.atx_comm_from_torch()  # the 128-byte id travels over the gloo group; ncclCommInitRank on every rank
+            return {"rccl_version": native.Comm.rccl_version()}
+
+        def c_abi_broadcast():
+            comm = holder["comm"]
+            got, ms = timed(lambda: atxd.exchange_stacks(mine, comm=comm))
+            return {"ms": ms, "verified_bit_equal": all(torch.equal(g.data, s.data) for g, s in zip(got, stacks))}
+
+        def c_abi_bands():
+            comm = holder["comm"]
+            (got, local_plan), ms = timed(lambda: atxd.exchange_source_bands(mine, plan, comm=comm))
+            banded = local_plan.apply_many(got)
+            return {"ms": ms, "verified_bit_equal": all(torch.equal(b.data, o.data) for b, o in zip(banded, outs))}
+
+        def c_abi_end_to_end():
+            comm = holder["comm"]
+            reps = 3
+            (got, ms) = timed(lambda: [atxd.pipelined_sharded_regrid(plan, mine, comm=comm) for _ in range(reps)][-1])
+            return {"ms_per_step": ms / reps, "value": units_per_step / (ms / reps * 1e-3), "unit": "grid-points/s",
+                    "verified_bit_equal": all(torch.equal(g.data, o.data) for g, o in zip(got, outs))}
+
+        c_abi["init"] = section("c_abi init", c_abi_init)
+        if "error" not in c_abi["init"]:
+            c_abi["broadcast"] = section("c_abi broadcast", c_abi_broadcast)
+            c_abi["bands"] = section("c_abi bands", c_abi_bands)
+            c_abi["end_to_end"] = section("c_abi end_to_end", c_abi_end_to_end)
+            try:
+                holder["comm"].destroy()
+            except Exception as e:
+                c_abi["destroy"] = {"error": f"{type(e).__name__}: {e}"}
     watchdog.cancel()
 
 

@@ -79,6 +79,29 @@ def test_secondary_lines_cannot_cost_the_value():
     assert d["value"] > 0 and d["n_gpus"] == 2 and "secondary_timed_out_in" in d
 
 
+def test_multi_gpu_sections_on_real_rccl_at_world_1():
+    """Everything `bench.py --gpus N` does after `value` — the nccl data group, both exchanges, end to end, and the same through
+    the C-ABI communicator — on the real collective library, at the world size one GPU allows."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, MASTER_PORT=str(port), MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    run = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *SMALL, "--rehearse-multi"], capture_output=True, text=True,
+                         timeout=600, cwd=ROOT, env=env)
+    assert run.returncode == 0, run.stderr[-3000:]
+    d = last_json(run.stdout)
+    assert d["n_gpus"] == 1 and d["value"] > 0 and "secondary_timed_out_in" not in d and "nccl" in d["config"]["collectives"]
+    ex = d["source_exchange"]
+    assert ex["broadcast"]["verified_bit_equal"] is True and ex["bands"]["verified_bit_equal"] is True
+    assert d["end_to_end"]["verified_bit_equal"] is True and d["strong"]["value"] > 0
+    c = ex["c_abi"]
+    assert c["init"]["rccl_version"] >= 20000
+    for name in ("broadcast", "bands", "end_to_end"):
+        assert c[name]["verified_bit_equal"] is True, c
+
+
 def test_integration_md_ctypes_stub_runs(tmp_path):
     """The reference-side binding shown in INTEGRATION.md is executable as written (only the library path is substituted)
     and gives scipy's bits."""

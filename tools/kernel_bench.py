@@ -100,6 +100,19 @@ def main():
         record(f"regrid_csr rows of 9-16 {tag} columns, TILED kernel", timeit(lambda: csr16.apply(x)), csr16_bytes, "round 1's kernel")
         native.set_tuning(0)
         del plan16, csr16, idx16, w16
+        # coarsening by box averages (a conservative-style matrix): every 1-degree cell averages the ~200 O1280 points inside it
+        one = lookup([1.0, 1.0])
+        n_one = len(one["latitudes"])
+        cell = (np.rint(90.0 - src_grid["latitudes"]).astype(np.int64) * 360 + np.mod(np.rint(src_grid["longitudes"]).astype(np.int64), 360))
+        order_b = np.argsort(cell, kind="stable")
+        counts_b = np.bincount(cell, minlength=n_one)
+        indptr_b = np.concatenate([[0], np.cumsum(counts_b)])
+        data_b = (1.0 / np.maximum(counts_b, 1))[cell[order_b]]
+        box = GatherPlan(n_src, n_one, csr=(data_b, order_b.astype(np.int32), indptr_b))
+        box_bytes = L * B * (n_src + n_one) + n_src * (4 + B) + 4 * n_one
+        record(f"regrid_csr box average O1280->1deg {tag} (rows of ~{int(counts_b.mean())})", timeit(lambda: box.apply(x)), box_bytes,
+               "general CSR, every source column read once")
+        del box
         prog = native.level_program([[(native.OP_MUL, 0, 9.80665, 0.0)] * L, [(native.OP_AFFINE, 0, 1.0, -273.15)] * L], dev)
         record(f"regrid_ell k=4 {tag} + 2-stage epilogue", timeit(lambda: plan4.apply(x, prog=prog, n_stage=2)),
                bench.algorithmic_bytes(L, B, U4, n_tgt, 4), "fused regrid -> orog_to_z -> rescale, every level")
