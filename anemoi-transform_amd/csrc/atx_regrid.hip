@@ -830,7 +830,10 @@ static int launch_cols_csr(const T* src, T* out, const int32_t* indptr, const in
     // (A "direct" form of this kernel — one item per lane, row walked from the CSR arrays in L1 — was measured and dropped: rows of
     // 3-4 entries 0.478 ms against 0.450 ms tiled, rows of 9-16 entries 1.06 against 1.01 ms f32, 2.03 against 2.10 ms f64; with 8
     // entries in flight and the next step's words prefetched 1.10 ms.  The extra dependent load level — row bounds, entries, source
-    // columns — costs what the missing barrier saves; profiles/r02_csr_direct_experiment.log.)
+    // columns — costs what the missing barrier saves; profiles/r02_csr_direct_experiment.log.  Nor do long rows want more loads in
+    // flight: box-average coarsening O1280 -> 1 degree, ~100 entries per row, every source column read exactly once, runs at 0.86 ms
+    // = 4.3 TB/s with 4 entries per step and 0.85 ms with 8 (at 84 VGPRs, 5 waves per SIMD), whatever the tile size —
+    // profiles/r02_long_rows_experiment.log.)
     int tile = g_tile_override > 0 ? g_tile_override : pick_tile(n_tgt, C, prog != nullptr);
     if ((int64_t)tile > n_tgt) tile = (int)n_tgt;
     const unsigned n_tiles = (unsigned)((n_tgt + tile - 1) / tile);
