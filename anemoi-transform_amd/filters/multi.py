@@ -134,16 +134,16 @@ class MatchingFieldsFilter(Filter):
         self._prepare_matching()
 
     def _prepare_matching(self) -> None:
-        if hasattr(self, "return_inputs"):
-            self.MATCHING = self.MATCHING.update_return_inputs(self.return_inputs)
-        for direction in ("forward", "backward"):
-            params = getattr(self.MATCHING, direction)
-            inputs = self.MATCHING.inputs(direction=direction)
-            if inputs and params and not set(inputs).issubset(params):
-                LOG.warning(
-                    f"Some {direction} inputs will not be returned because they are not in the filter parameters: "
-                    f"{set(inputs) - set(params)}"
-                )
+        """Apply an instance-level ``return_inputs`` to the class's spec and warn about returned inputs that are not
+        operands of a direction (they could never be returned there)."""
+        wanted = getattr(self, "return_inputs", None)
+        if wanted is not None:
+            self.MATCHING = self.MATCHING.update_return_inputs(wanted)
+        spec = self.MATCHING
+        for direction, operands in (("forward", spec.forward), ("backward", spec.backward)):
+            unknown = set(spec.inputs(direction)) - set(operands)
+            if operands and unknown:
+                LOG.warning(f"Some {direction} inputs will not be returned because they are not in the filter parameters: {unknown}")
 
     def _check_metadata_match(self, data: set, args: Iterable[str]) -> None:
         if not set(args).issubset(data):

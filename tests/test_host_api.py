@@ -420,6 +420,24 @@ def test_library_exports_every_declared_symbol():
     assert set(declared) == set(native.SIGNATURES), "native.py must bind exactly the header's entry points"
 
 
+def test_header_is_plain_c_and_links(tmp_path):
+    """include/atx.h compiles as C99 with warnings as errors, and a C program linked against libatx.so runs (tests/c_abi/abi_check.c)."""
+    import shutil
+    import subprocess
+
+    gcc = shutil.which("gcc")
+    if gcc is None:
+        pytest.skip("no C compiler")
+    src = os.path.join(ROOT, "tests", "c_abi", "abi_check.c")
+    exe = str(tmp_path / "abi_check")
+    lib_dir = os.path.dirname(native.lib_path())
+    build = subprocess.run([gcc, "-std=c99", "-Wall", "-Wextra", "-Werror", "-pedantic", "-I", os.path.join(ROOT, "include"), src, "-o", exe,
+                            "-L", lib_dir, "-latx", f"-Wl,-rpath,{lib_dir}", "-Wl,-rpath,/opt/rocm/lib"], capture_output=True, text=True)
+    assert build.returncode == 0, build.stderr
+    run = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert run.returncode == 0 and run.stdout.strip().endswith("ok"), run.stdout + run.stderr
+
+
 def test_abi_argument_validation_without_a_gpu():
     """Bad arguments are rejected before anything touches HIP, with the reference's exception types."""
     lib = native.load()
