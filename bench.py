@@ -17,7 +17,8 @@ wall time of the K steps, with the N source stacks already resident on every ran
 HBM" means for a target-sharded job).  What it costs to GET them there is measured in the same run and reported next
 to `value`, never inside it: `source_exchange_ms.broadcast` (N RCCL broadcasts of 3.7 GB), `source_exchange_ms.bands`
 (band-limited RCCL send/recv), each verified bit-equal against the stacks the rank synthesised itself, and
-`end_to_end` — one step INCLUDING the exchange, broadcast r+1 overlapped with launch r.  `strong` is the fixed-total-
+`end_to_end` — one step INCLUDING the exchange, broadcast r+1 overlapped with launch r — and `end_to_end_bands`, the same step
+with the band-limited all-to-all in front of one batched launch.  `strong` is the fixed-total-
 work line (ONE stack split over the N ranks) and `field_axis_sharding` the exchange-free alternative.
 Host-side barriers and the max-over-ranks reduction run on a gloo group, stack traffic on an nccl (= RCCL) group.
 
@@ -434,6 +435,22 @@ def multi_gpu_lines(args, result, dist, rank, world, dev, plan, stacks, outs, la
                 "note": "one step INCLUDING the exchange of the N source stacks: broadcast r+1 (RCCL) overlapped with launch r, two source buffers alive"}
 
     result["end_to_end"] = section("end_to_end", end_to_end)
+
+    def end_to_end_bands():
+        # the xGMI-native form of the same step: ONE all-to-all of band slabs (every rank sends each peer only the source columns that
+        # peer's target slice references — 7 point-to-point transfers per GPU, all links at once), then the batched launch on the slabs
+        reps = 3
+
+        def once():
+            got, local_plan = atxd.exchange_source_bands(mine, plan)
+            return local_plan.apply_many(got)
+
+        (got, ms) = timed(lambda: [once() for _ in range(reps)][-1])
+        same = all(torch.equal(g.data, o.data) for g, o in zip(got, outs))
+        return {"ms_per_step": ms / reps, "value": units_per_step / (ms / reps * 1e-3), "unit": "grid-points/s", "verified_bit_equal": same,
+                "note": "one step INCLUDING the exchange, band-limited: all-to-all of the source slabs each target slice needs, then one batched launch"}
+
+    result["end_to_end_bands"] = section("end_to_end_bands", end_to_end_bands)
 
     # ---- the same exchanges through the library's own C-ABI communicator (atx_comm_*: RCCL bound directly)
     if args.backend == "nccl":

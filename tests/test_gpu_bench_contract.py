@@ -58,7 +58,7 @@ def test_two_ranks_rehearsal_over_gloo():
     for kind in ("broadcast", "bands"):
         assert d["source_exchange"][kind]["verified_bit_equal"] is True
     assert d["source_exchange"]["bands"]["bytes_received_per_gpu"] < d["source_exchange"]["broadcast"]["bytes_received_per_gpu"]
-    assert d["end_to_end"]["verified_bit_equal"] is True
+    assert d["end_to_end"]["verified_bit_equal"] is True and d["end_to_end_bands"]["verified_bit_equal"] is True
     assert d["end_to_end"]["value"] > 0 and d["end_to_end"]["value"] < d["value"]  # the exchange is inside that one
     assert d["strong"]["scaling"] == "strong" and d["strong"]["value"] > 0
     assert d["field_axis_sharding"]["value"] > 0  # the no-exchange comparison point rides along
@@ -96,6 +96,7 @@ def test_multi_gpu_sections_on_real_rccl_at_world_1():
     ex = d["source_exchange"]
     assert ex["broadcast"]["verified_bit_equal"] is True and ex["bands"]["verified_bit_equal"] is True
     assert d["end_to_end"]["verified_bit_equal"] is True and d["strong"]["value"] > 0
+    assert d["end_to_end_bands"]["verified_bit_equal"] is True
     c = ex["c_abi"]
     assert c["init"]["rccl_version"] >= 20000
     for name in ("broadcast", "bands", "end_to_end"):
