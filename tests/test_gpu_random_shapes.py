@@ -8,6 +8,8 @@ results must equal numpy / scipy bit for bit, float32 within the 1e-6 relative t
 
 from __future__ import annotations
 
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -19,6 +21,10 @@ from oracle import oracle
 pytestmark = pytest.mark.gpu
 
 POISON = float("nan")
+# ATX_RANDOM_SEEDS=first:count widens the sweep for a one-off soak run (default: the seeds of the suite)
+_FIRST, _COUNT = (int(v) for v in os.environ.get("ATX_RANDOM_SEEDS", "0:0").split(":"))
+REGRID_SEEDS = range(_FIRST, _FIRST + _COUNT) if _COUNT else range(30)
+POINTWISE_SEEDS = range(_FIRST, _FIRST + _COUNT) if _COUNT else range(15)
 
 
 class Loose:
@@ -52,23 +58,33 @@ class Loose:
         return bool(torch.isnan(pad).all().item()) if pad.numel() else True
 
 
+ENTRIES = [lambda m: (native.OP_COPY, m, 0.0, 0.0), lambda m: (native.OP_AFFINE, m, 1.5, -3.0), lambda m: (native.OP_MUL, m, 9.80665, 0.0),
+           lambda m: (native.OP_AFFINE_INV, m, 2.0, 1.0), lambda m: (native.OP_DIV, m, 9.80665, 0.0), lambda m: (native.OP_CLIP, m, 270.0, 300.0),
+           lambda m: (native.OP_IMPUTE_NAN, m, -1.0, 0.0)]
+
+
 def random_program(rng, n_stage, n_lev):
+    """Stages in the shapes the kernels tell apart: one operator for all levels; two runs of levels (split anywhere: on and off
+    16-byte boundaries); the multiply-add family level by level; a few active levels among COPY; anything goes."""
     ops = []
     for _ in range(n_stage):
-        stage = []
-        uniform = rng.random() < 0.5
-        base = None
-        for l in range(n_lev):
-            if uniform and base is not None:
-                stage.append(base)
-                continue
-            kind = rng.integers(0, 7)
-            use_mask = int(rng.random() < 0.3)
-            entry = [(native.OP_COPY, use_mask, 0.0, 0.0), (native.OP_AFFINE, use_mask, 1.5, -3.0), (native.OP_AFFINE_INV, use_mask, 2.0, 1.0),
-                     (native.OP_MUL, use_mask, 9.80665, 0.0), (native.OP_DIV, use_mask, 9.80665, 0.0),
-                     (native.OP_CLIP, use_mask, 270.0, 300.0), (native.OP_IMPUTE_NAN, use_mask, -1.0, 0.0)][kind]
-            stage.append(entry)
-            base = entry
+        style = rng.choice(["uniform", "two_pieces", "madd", "sparse", "random"])
+        pick = lambda family=7: ENTRIES[int(rng.integers(0, family))](int(rng.random() < 0.3))  # noqa: E731
+        if style == "uniform":
+            stage = [pick()] * n_lev
+        elif style == "two_pieces":
+            split = int(rng.integers(0, n_lev + 1))
+            if rng.random() < 0.5:
+                split = split // 4 * 4
+            first, second = pick(), pick()
+            stage = [first if l < split else second for l in range(n_lev)]
+        elif style == "madd":
+            stage = [pick(3) for _ in range(n_lev)]
+        elif style == "sparse":
+            active = set(int(v) for v in rng.integers(0, n_lev, int(rng.integers(1, 4))))
+            stage = [pick() if l in active else (native.OP_COPY, 0, 0.0, 0.0) for l in range(n_lev)]
+        else:
+            stage = [pick() for _ in range(n_lev)]
         ops.append(stage)
     return ops
 
@@ -105,7 +121,7 @@ def check(got: np.ndarray, want: np.ndarray, what: str):
         np.testing.assert_allclose(got, want, rtol=1e-6, atol=1e-4, err_msg=what)
 
 
-@pytest.mark.parametrize("seed", range(30))
+@pytest.mark.parametrize("seed", REGRID_SEEDS)
 def test_random_regrid_cases(dev, seed):
     rng = np.random.default_rng(1000 + seed)
     for case in range(10):
@@ -173,7 +189,7 @@ def test_random_regrid_cases(dev, seed):
         assert out.padding_untouched(), what + " (padding of the output written)"
 
 
-@pytest.mark.parametrize("seed", range(15))
+@pytest.mark.parametrize("seed", POINTWISE_SEEDS)
 def test_random_pointwise_and_level_gather_cases(dev, seed):
     rng = np.random.default_rng(2000 + seed)
     for case in range(10):
