@@ -161,6 +161,10 @@ class Field:
             return self._namespace(namespace)
         if len(keys) == 0:
             return _MetadataView(self)
+        if len(keys) == 1:  # the common call (`field.metadata("param")`): no closure, no list
+            value = self._lookup(keys[0])
+            if value is not MISSING:
+                return value
 
         def one(key: str) -> Any:
             value = self._lookup(key)
@@ -529,6 +533,13 @@ class FieldSelection:
 
     def match(self, field: Any) -> bool:
         if self._all:
+            return True
+        lookup = getattr(field, "_lookup", None)
+        if lookup is not None:  # this package's fields: the metadata table directly (a pipeline asks this per field and stage)
+            for key, values in self._spec.items():
+                value = lookup(key)
+                if value is MISSING or value not in values:
+                    return False
             return True
         try:
             return all(field.metadata(key) in values for key, values in self._spec.items())

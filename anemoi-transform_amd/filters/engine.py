@@ -88,7 +88,7 @@ def run_level_ops(
         stage: list[LevelOp] = [(native.OP_COPY, 0, 0.0, 0.0)] * src.n_lev  # levels outside the group: untouched
         for level, f in zip(group.levels, group.fields):
             stage[level] = level_op(f)
-        prog = native.level_program([stage], src.device)
+        prog = native.level_program([stage], src.device, cache=True)
         native.pointwise_stack(
             src.data, dst.data, n_pts=src.n_pts, n_lev=src.n_lev, x_pitch=src.pitch, y_pitch=dst.pitch,
             layout=src.layout, prog=prog, n_stage=1,

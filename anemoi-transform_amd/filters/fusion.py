@@ -109,7 +109,9 @@ def _run_segment(data: Any, head: RegridFilter | None, stages: list[Stage]) -> F
         for i in range(n):
             if st.select(proxies[i]):
                 op = st.level_op(proxies[i])
-                proxies[i] = DerivedField(proxies[i], metadata=st.new_metadata(proxies[i]))
+                relabel = st.new_metadata(proxies[i])
+                if relabel:  # a stage that changes no metadata needs no new view of the field
+                    proxies[i] = DerivedField(proxies[i], metadata=relabel)
                 touched[i] = touched[i] or op is not COPY  # a pure relabelling needs no launch
                 if op[1]:
                     m = st.mask()
@@ -138,7 +140,7 @@ def _run_segment(data: Any, head: RegridFilter | None, stages: list[Stage]) -> F
                 for level, p in zip(group.levels, group.positions):
                     stage[level] = row[p]
                 stages.append(stage)
-            prog = native.level_program(stages, src.device)
+            prog = native.level_program(stages, src.device, cache=True)
             native.pointwise_stack(src.data, dst.data, n_pts=src.n_pts, n_lev=src.n_lev, x_pitch=src.pitch, y_pitch=dst.pitch,
                                    layout=src.layout, prog=prog, n_stage=len(ops),
                                    point_mask=None if group_mask is None else group_mask.tensor)
@@ -163,7 +165,7 @@ def _run_segment(data: Any, head: RegridFilter | None, stages: list[Stage]) -> F
                 if window is None or mask.n_points != full_targets:
                     raise IndexError(f"boolean index did not match indexed array: mask has {mask.n_points} points, field has {plan.n_tgt}")
                 tgt_mask = mask.window(window[0], window[1])  # a full-grid mask on this rank's slice of the targets
-            kwargs = dict(prog=native.level_program([[row[p] for p in group.positions] for row in ops], group.stack.device),
+            kwargs = dict(prog=native.level_program([[row[p] for p in group.positions] for row in ops], group.stack.device, cache=True),
                           n_stage=len(ops), tgt_mask=None if tgt_mask is None else tgt_mask.tensor)
         regridded = plan.apply(group.stack, **kwargs)
         for level, pos in enumerate(group.positions):

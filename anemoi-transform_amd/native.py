@@ -256,8 +256,31 @@ def check_indices(idx, n_src: int) -> int:
     return int(n_bad.item())
 
 
-def level_program(stages: list[list[tuple[int, int, float, float]]], device) -> torch.Tensor:
-    """Device copy of a per-level program: ``stages[s][l] = (op, use_mask, p0, p1)``."""
+_PROGRAM_CACHE: dict[Any, torch.Tensor] = {}
+_PROGRAM_CACHE_SIZE = 64
+
+
+def level_program(stages: list[list[tuple[int, int, float, float]]], device, cache: bool = False) -> torch.Tensor:
+    """Device copy of a per-level program: ``stages[s][l] = (op, use_mask, p0, p1)``.
+
+    ``cache=True`` (the filters' call): programs are remembered by value — a pipeline applies the same program to every
+    FieldList of a job, and rebuilding it (three small host-to-device copies and the per-vector tables) costs about as
+    much host time as the launch it drives.  Cached programs are shared: treat them as read-only."""
+    key = None
+    if cache:
+        key = (tuple(tuple(tuple(entry) for entry in stage) for stage in stages), str(device))
+        hit = _PROGRAM_CACHE.get(key)
+        if hit is not None:
+            return hit
+    raw = _build_level_program(stages, device)
+    if key is not None:
+        if len(_PROGRAM_CACHE) >= _PROGRAM_CACHE_SIZE:
+            _PROGRAM_CACHE.pop(next(iter(_PROGRAM_CACHE)))
+        _PROGRAM_CACHE[key] = raw
+    return raw
+
+
+def _build_level_program(stages, device) -> torch.Tensor:
     n_stage = len(stages)
     n_lev = len(stages[0])
     host = np.zeros(n_stage * n_lev, dtype=LEVEL_OP_DTYPE)
