@@ -18,7 +18,8 @@ HBM" means for a target-sharded job).  What it costs to GET them there is measur
 to `value`, never inside it: `source_exchange_ms.broadcast` (N RCCL broadcasts of 3.7 GB), `source_exchange_ms.bands`
 (band-limited RCCL send/recv), each verified bit-equal against the stacks the rank synthesised itself, and
 `end_to_end` — one step INCLUDING the exchange, broadcast r+1 overlapped with launch r — and `end_to_end_bands`, the same step
-with the band-limited all-to-all in front of one batched launch.  `strong` is the fixed-total-
+with the band-limited all-to-all in front of one batched launch.  `config4` is BASELINE configs[3] on the N GPUs of the run
+(O1280 -> N320-sized, 24 stacks resident per rank, target points over the ranks).  `strong` is the fixed-total-
 work line (ONE stack split over the N ranks) and `field_axis_sharding` the exchange-free alternative.
 Host-side barriers and the max-over-ranks reduction run on a gloo group, stack traffic on an nccl (= RCCL) group.
 
@@ -386,6 +387,51 @@ def multi_gpu_lines(args, result, dist, rank, world, dev, plan, stacks, outs, la
                 "note": "each rank regrids its own stack to the full target grid; no source exchange"}
 
     result["field_axis_sharding"] = section("field_axis_sharding", field_axis)
+
+    # ---- BASELINE configs[3] as specified: O1280 -> N320-sized, 6 variables x 137 levels x 4 timesteps = 24 stacks, the target points
+    #      sharded over the N ranks (no exchange in the step: every rank holds the 24 source stacks, 88.7 GB f32)
+    def config4():
+        from anemoi_transform_amd.gather import GatherPlan
+        from anemoi_transform_amd.grids import lookup
+        from anemoi_transform_amd.interp import knn_inverse_distance
+
+        g_src, g_tgt = lookup("o1280"), lookup("n320-sized")
+        n4_src, n4_tgt, n_stack = len(g_src["latitudes"]), len(g_tgt["latitudes"]), 24
+        idx4, w4 = knn_inverse_distance(g_src, g_tgt, k=4)
+        b4 = GatherPlan(n4_src, n4_tgt, index=idx4, weights=w4).bounds(world)
+        lo4, hi4 = b4[rank], b4[rank + 1]
+        gen = torch.Generator(device=dev)
+        srcs = []
+        for i in range(n_stack):
+            gen.manual_seed(SEED + 7 * i)
+            st = Stack.empty(n4_src, args.levels, tdtype, dev, COLUMNS, zero=True)
+            st.data[:, : args.levels].normal_(250.0 + 5.0 * (i // 4), 20.0, generator=gen)
+            srcs.append(st)
+        dsts = [Stack.empty(hi4 - lo4, args.levels, tdtype, dev, COLUMNS) for _ in range(n_stack)]
+        idx_d4 = torch.from_numpy(idx4[lo4:hi4].astype(np.int32)).to(dev)
+        w_d4 = torch.from_numpy(w4[lo4:hi4].astype(np_dtype)).to(dev)
+
+        def go():
+            native.regrid_ell_batch([s.data for s in srcs], [d.data for d in dsts], idx_d4, w_d4, n_src=n4_src, n_tgt=hi4 - lo4, k=4,
+                                    n_lev=args.levels, src_pitch=srcs[0].pitch, out_pitch=dsts[0].pitch, layout=COLUMNS)
+
+        reps = max(3, min(args.steps, 20))
+        for _ in range(3):
+            go()
+        torch.cuda.synchronize()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            go()
+        torch.cuda.synchronize()
+        t = max_over_ranks(time.perf_counter() - t0)
+        return {"value": n4_tgt * args.levels * n_stack * reps / t, "unit": "grid-points/s", "ms_per_step": t / reps * 1e3, "fields": n_stack * args.levels,
+                "targets_of_this_rank": hi4 - lo4,
+                "workload": f"O1280 -> N320-sized ({n4_tgt} pts), k=4, 24 stacks x {args.levels} levels resident on every rank, target points over {world} ranks"}
+
+    if layout == COLUMNS:
+        result["config4"] = section("config4", config4)
+        torch.cuda.empty_cache()
     if layout != COLUMNS:
         watchdog.cancel()
         return
