@@ -429,8 +429,25 @@ def multi_gpu_lines(args, result, dist, rank, world, dev, plan, stacks, outs, la
                 "targets_of_this_rank": hi4 - lo4,
                 "workload": f"O1280 -> N320-sized ({n4_tgt} pts), k=4, 24 stacks x {args.levels} levels resident on every rank, target points over {world} ranks"}
 
+    def config5():
+        plain, fused, _, all_units, _, keep = config5_case(args, dev, tdtype, np_dtype, rank, world)
+        reps = max(3, min(args.steps, 20))
+        for _ in range(3):
+            fused()
+        torch.cuda.synchronize()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            fused()
+        torch.cuda.synchronize()
+        t = max_over_ranks(time.perf_counter() - t0)
+        return {"value": all_units * reps / t, "unit": "grid-points/s", "ms_per_step": t / reps * 1e3, "scaling": "strong",
+                "workload": f"O2560 -> 0.25 deg, k=4, 137 levels, regrid | orog_to_z | convert fused in one launch; one stack, target points over {world} ranks"}
+
     if layout == COLUMNS:
         result["config4"] = section("config4", config4)
+        torch.cuda.empty_cache()
+        result["config5"] = section("config5", config5)
         torch.cuda.empty_cache()
     if layout != COLUMNS:
         watchdog.cancel()
@@ -654,6 +671,18 @@ def single_gpu_lines(args, result, dev, stacks, outs, launch, idx_d, w_d, idx64,
         extras["config4"] = {"error": f"{type(e).__name__}: {e}"}
     torch.cuda.empty_cache()
 
+    # ---- BASELINE configs[4]: the chained filters on an ERA5-shape O2560 stack (14.4 GB), plain gather vs the fused launch
+    try:
+        plain, fused, units, _, alg5, keep = config5_case(args, dev, tdtype, np_dtype)
+        ms_plain, _ = time_launches(plain, 10, 2)
+        ms_fused, _ = time_launches(fused, 10, 2)
+        extras["config5"] = {"workload": "O2560 (26306560 pts) -> 0.25 deg, k=4, 137 levels: regrid | orog_to_z (1 level) | convert K->degC (136 levels)",
+                             "regrid_only": line(units, ms_plain, alg5), "fused_chain_one_launch": line(units, ms_fused, alg5)}
+        del plain, fused, keep
+    except Exception as e:
+        extras["config5"] = {"error": f"{type(e).__name__}: {e}"}
+    torch.cuda.empty_cache()
+
     # the CPU's best case (SURVEY.md §8d baseline B): the same statement on every core this process may use (os.cpu_count() capped
     # by the cgroup quota — 16 on the MI355X boxes, where 32-256 workers measured SLOWER, profiles/r02_cpu_workers_sweep.jsonl), run
     # as a child process that never touches the GPU; reported next to the one-thread "as the reference runs" baseline
@@ -668,6 +697,37 @@ def single_gpu_lines(args, result, dev, stacks, outs, launch, idx_d, w_d, idx64,
         except Exception as e:  # a baseline must never take the bench line down
             extras["cpu_all_cores"] = {"error": f"{type(e).__name__}: {e}"}
     result["extras"] = extras
+
+
+def config5_case(args, dev, tdtype, np_dtype, rank=0, world=1):
+    """BASELINE configs[4]: regrid + orography-adjust + unit-convert chained on ERA5-shape O2560 fields, as ONE fused launch per
+    137-level stack (136 levels of t -> degC, one level of orog -> z).  Returns (launch closures, units, algorithmic bytes) for
+    this rank's traffic-balanced slice of the 0.25 degree target grid.  The index table comes from the device k-NN search with
+    the kernel's own order among equidistant points (cKDTree needs about a minute for 26.3 M points; the timing does not depend
+    on that order)."""
+    from anemoi_transform_amd import native
+    from anemoi_transform_amd.gather import GatherPlan
+    from anemoi_transform_amd.grids import lookup
+    from anemoi_transform_amd.interp import knn_inverse_distance
+    from anemoi_transform_amd.stack import COLUMNS, Stack
+
+    g_src, g_tgt = lookup("o2560"), lookup("0.25")
+    n5_src, n5_tgt, L = len(g_src["latitudes"]), len(g_tgt["latitudes"]), args.levels
+    idx5, w5 = knn_inverse_distance(g_src, g_tgt, k=4, device=True, ties="index")
+    b5 = GatherPlan(n5_src, n5_tgt, index=idx5, weights=w5).bounds(world)
+    lo, hi = b5[rank], b5[rank + 1]
+    x = synth_stack(g_src, L, tdtype, dev, 0, COLUMNS)
+    out = Stack.empty(hi - lo, L, tdtype, dev, COLUMNS)
+    idx_d = torch.from_numpy(idx5[lo:hi].astype(np.int32)).to(dev)
+    w_d = torch.from_numpy(w5[lo:hi].astype(np_dtype)).to(dev)
+    cp = (native.OP_COPY, 0, 0.0, 0.0)
+    prog = native.level_program([[cp] * (L - 1) + [(native.OP_MUL, 0, 9.80665, 0.0)], [(native.OP_AFFINE, 0, 1.0, -273.15)] * (L - 1) + [cp]], dev)
+    kw = dict(n_src=n5_src, n_tgt=hi - lo, k=4, n_lev=L, src_pitch=x.pitch, out_pitch=out.pitch, layout=COLUMNS)
+    plain = lambda: native.regrid_ell(x.data, out.data, idx_d, w_d, **kw)  # noqa: E731
+    fused = lambda: native.regrid_ell(x.data, out.data, idx_d, w_d, prog=prog, n_stage=2, **kw)  # noqa: E731
+    itemsize = 4 if tdtype == torch.float32 else 8
+    alg = algorithmic_bytes(L, itemsize, int(np.unique(idx5[lo:hi]).size), hi - lo, 4)
+    return plain, fused, (hi - lo) * L, n5_tgt * L, alg, (x, out, idx_d, w_d, prog)
 
 
 def config4_lines(args, dev, tdtype, np_dtype, itemsize):

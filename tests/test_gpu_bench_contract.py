@@ -62,6 +62,7 @@ def test_two_ranks_rehearsal_over_gloo():
     assert d["end_to_end"]["value"] > 0 and d["end_to_end"]["value"] < d["value"]  # the exchange is inside that one
     assert d["strong"]["scaling"] == "strong" and d["strong"]["value"] > 0
     assert d["config4"]["value"] > 0 and d["config4"]["fields"] == 24 * 7
+    assert d["config5"]["value"] > 0 and d["config5"]["scaling"] == "strong"
     assert d["field_axis_sharding"]["value"] > 0  # the no-exchange comparison point rides along
     assert "cpu_baseline" not in d and "secondary_timed_out_in" not in d  # rank 0 at N = 1 only
 
