@@ -70,7 +70,7 @@ def parse_args():
                     help="worker processes of extras.cpu_all_cores (0 = all cores this process may use: os.cpu_count() capped by the cgroup quota)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="N > 1: backend of the group that carries the stacks (nccl = RCCL over xGMI); barriers always run on gloo")
-    ap.add_argument("--secondary-seconds", type=float, default=240.0,
+    ap.add_argument("--secondary-seconds", type=float, default=360.0,
                     help="N > 1: wall-clock budget of the lines measured after `value`; when it runs out the JSON line is printed with what is there")
     ap.add_argument("--rehearse-multi", action="store_true",
                     help="REHEARSAL ONLY, with --gpus 1: run the N > 1 secondary sections (RCCL exchange through torch.distributed and through "
