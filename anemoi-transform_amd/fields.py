@@ -424,6 +424,17 @@ def new_field_with_metadata(template: Field, **metadata: Any) -> DerivedField:
     return DerivedField(template, metadata=metadata)
 
 
+def new_field_with_units(template: Field, units: str) -> DerivedField:
+    """R: fields.py:701-716."""
+    return DerivedField(template, metadata={"units": units})
+
+
+def new_field_from_grid(template: Field, grid: Any) -> DerivedField:
+    """R: fields.py:741-759 — ``grid`` is any object whose ``latlon()`` gives ``(latitudes, longitudes)`` (R: fields.py:399-407)."""
+    latitudes, longitudes = grid.latlon()
+    return DerivedField(template, latitudes=np.asarray(latitudes), longitudes=np.asarray(longitudes))
+
+
 def to_datetime(value: Any) -> "datetime.datetime":
     """ISO string / date / datetime -> datetime (what ``earthkit.data.utils.dates.to_datetime`` is used for here)."""
     import datetime

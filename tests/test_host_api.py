@@ -533,6 +533,24 @@ def test_derived_field_forwards_unknown_attributes(caplog):
     assert derived.clone(param="v").metadata("param") == "v"
 
 
+def test_units_and_grid_field_factories():
+    """R: fields.py:701-716 (new_field_with_units), :741-759 / :384-466 (new_field_from_grid: anything with ``latlon()``)."""
+    from anemoi_transform_amd.fields import ArrayField, new_field_from_grid, new_field_with_units
+
+    base = ArrayField(np.arange(6.0), {"param": "t", "units": "K"}, np.arange(6.0), np.arange(6.0) * 2)
+    assert new_field_with_units(base, "degC").metadata("units") == "degC" and base.metadata("units") == "K"
+
+    class Grid:
+        def latlon(self):
+            return np.linspace(10, 60, 6), np.linspace(-20, 30, 6)
+
+    moved = new_field_from_grid(base, Grid())
+    lat, lon = moved.grid_points()
+    assert np.array_equal(lat, np.linspace(10, 60, 6)) and np.array_equal(lon, np.linspace(-20, 30, 6))
+    assert np.array_equal(moved.to_numpy(), base.to_numpy()) and moved.metadata("param") == "t"
+    assert moved.to_latlon()["lat"][0] == 10.0
+
+
 def test_vector_program_host_helper():
     """atx_vector_program (host only): per-vector view of a per-level program; levels that differ mark the vector MIXED,
     parameters are compared as the kernel will see them (rounded to the stack's dtype), padding levels join any operator."""
