@@ -85,9 +85,16 @@ def atx_comm_from_torch():
     from . import native
 
     rank, world = dist.get_rank(), dist.get_world_size()
-    box = [native.Comm.unique_id() if rank == 0 else None]
+    box: list = [None]
+    if rank == 0:
+        try:
+            box[0] = native.Comm.unique_id()
+        except Exception as e:  # every rank must learn of it, or the others would wait for the id forever
+            box[0] = f"{type(e).__name__}: {e}"
     if world > 1:
         dist.broadcast_object_list(box, src=0)
+    if not isinstance(box[0], bytes):
+        raise native.AtxError(f"rank 0 could not create an RCCL unique id: {box[0]}")
     return native.Comm(world, rank, box[0])
 
 
