@@ -35,6 +35,7 @@ def main():
     ap.add_argument("--dtype", default="f32")
     ap.add_argument("--k", type=int, default=4)
     ap.add_argument("--levels", type=int, default=137)
+    ap.add_argument("--layout", default="columns", choices=["columns", "fields"])
     ap.add_argument("--meta", default=os.path.join(ROOT, "gpurun_out", "pmc_meta.json"))
     args = ap.parse_args()
 
@@ -42,7 +43,7 @@ def main():
     from anemoi_transform_amd import native
     from anemoi_transform_amd.grids import lookup
     from anemoi_transform_amd.interp import knn_inverse_distance
-    from anemoi_transform_amd.stack import COLUMNS, Stack
+    from anemoi_transform_amd.stack import COLUMNS, FIELDS, Stack
 
     dev = torch.device("cuda", 0)
     torch.cuda.set_device(dev)
@@ -57,6 +58,10 @@ def main():
     w = torch.from_numpy(w64.astype(npdt)).to(dev) if args.k > 1 else None
     src = bench.synth_stack(src_grid, args.levels, tdtype, dev, 0, COLUMNS)
     out = Stack.empty(n_tgt, args.levels, tdtype, dev, COLUMNS)
+    regrid_src, regrid_out = src, out
+    if args.layout == "fields":
+        regrid_src = src.to_layout(FIELDS)
+        regrid_out = Stack.empty(n_tgt, args.levels, tdtype, dev, FIELDS)
     torch.cuda.synchronize()
 
     # 1. calibration: the library's fixed streaming copy (atx_stream_copy: one 16-byte vector per lane, aligned, known bytes) —
@@ -78,17 +83,17 @@ def main():
 
     # 2. the regrid launches
     for _ in range(args.launches):
-        native.regrid_ell(src.data, out.data, idx, w, n_src=n_src, n_tgt=n_tgt, k=args.k, n_lev=args.levels,
-                          src_pitch=src.pitch, out_pitch=out.pitch, layout=COLUMNS)
+        native.regrid_ell(regrid_src.data, regrid_out.data, idx, w, n_src=n_src, n_tgt=n_tgt, k=args.k, n_lev=args.levels,
+                          src_pitch=regrid_src.pitch, out_pitch=regrid_out.pitch, layout=regrid_src.layout)
     torch.cuda.synchronize()
 
     meta = {
-        "config": f"o1280->0.25 k={args.k} L={args.levels} {args.dtype} columns gpus=1",
+        "config": f"o1280->0.25 k={args.k} L={args.levels} {args.dtype} {args.layout} gpus=1",
         "calibration_kernel": "stream_copy_kernel",
         "cols_copy_bytes": cols_copy_bytes,
         "calibration_read_bytes": calib_bytes,
         "calibration_write_bytes": calib_bytes,
-        "regrid_kernel": "regrid_cols_ell_direct_kernel" if args.k <= 4 else "regrid_cols_ell_kernel",
+        "regrid_kernel": "regrid_fields_ell_kernel" if args.layout == "fields" else ("regrid_cols_ell_direct_kernel" if args.k <= 4 else "regrid_cols_ell_kernel"),
         "regrid_launches": args.launches,
         "algorithmic_bytes_per_launch": bench.algorithmic_bytes(args.levels, itemsize, int(np.unique(idx64).size), n_tgt, args.k),
     }

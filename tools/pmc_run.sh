@@ -1,10 +1,13 @@
+# rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE in separate runs, as the microarchitecture guide prescribes) over tools/pmc_probe.py.
+#   bash tools/pmc_run.sh "<probe args>" ["<probe args>" ...]     e.g.  bash tools/pmc_run.sh "--k 4" "--k 16" "--k 4 --layout fields"
 set -e
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-for K in 4 16; do
+for ARGS in "$@"; do
+  TAG=$(echo "$ARGS" | tr -d ' -')
   rm -rf $R/gpurun_out/pmc_fetch $R/gpurun_out/pmc_write
-  rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/pmc_fetch -- python3 $R/tools/pmc_probe.py --k $K > $R/gpurun_out/r02_pmc_fetch_k$K.log 2>&1
-  rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/pmc_write -- python3 $R/tools/pmc_probe.py --k $K > $R/gpurun_out/r02_pmc_write_k$K.log 2>&1
-  python3 $R/tools/pmc_summarize.py --round r02 --out $R/gpurun_out/r02_traffic.json > $R/gpurun_out/r02_pmc_summary_k$K.log 2>&1
-  tail -12 $R/gpurun_out/r02_pmc_summary_k$K.log
+  rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/pmc_fetch -- python3 $R/tools/pmc_probe.py $ARGS > $R/gpurun_out/r02_pmc_fetch_$TAG.log 2>&1
+  rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/pmc_write -- python3 $R/tools/pmc_probe.py $ARGS > $R/gpurun_out/r02_pmc_write_$TAG.log 2>&1
+  python3 $R/tools/pmc_summarize.py --round r02 --out $R/gpurun_out/r02_traffic.json > $R/gpurun_out/r02_pmc_summary_$TAG.log 2>&1
+  tail -12 $R/gpurun_out/r02_pmc_summary_$TAG.log
 done
