@@ -347,10 +347,9 @@ class SnowCover(StackMatchingFilter):
 def _range_check(name: str, stack: Any) -> None:
     """R: cos_sin_from_rad.py:73-76 — radians expected in [-2 pi, 2 pi]; min / max by ``atx_reduce``."""
     kw = dict(n_pts=stack.n_pts, n_lev=stack.n_lev, pitch=stack.pitch, layout=stack.layout)
-    lo = native.reduce_stack(stack.data, native.RED_MIN, **kw)
+    lo, hi = native.reduce_stack(stack.data, native.RED_MINMAX, **kw)  # one pass, one read-back
     if lo < -2 * np.pi:
         raise ValueError(f"Param {name} is expected in radians in the range [-2pi, pi], but min={lo}")
-    hi = native.reduce_stack(stack.data, native.RED_MAX, **kw)
     if hi > 2 * np.pi:
         raise ValueError(f"Param {name} is expected in radians in the range [-2pi, pi], but max={hi}")
 

@@ -37,7 +37,7 @@ CMP_GT, CMP_LT, CMP_EQ, CMP_NE, CMP_GE, CMP_LE, CMP_NOTNAN, CMP_ISNAN = range(8)
     OP_LOG,
     OP_SET_NAN,
 ) = range(10)
-RED_MIN, RED_MAX, RED_NANCOUNT = range(3)
+RED_MIN, RED_MAX, RED_NANCOUNT, RED_MINMAX = range(4)
 COMB_SNOW_DEPTH_M, COMB_SNOW_COVER, COMB_COS_SIN, COMB_ATAN2, COMB_W_TO_WZ, COMB_WZ_TO_W, COMB_SUM, COMB_SUB = range(8)
 COMB_DEGREES = 1
 COMB_MAX_INPUTS = 8
@@ -382,18 +382,26 @@ def cutout_inside(global_xyz: torch.Tensor, lam_xyz: torch.Tensor, neighbours: t
     return inside[:n]
 
 
-def reduce(x, red: int, n: int | None = None) -> float:
+def _reduction_result(result: torch.Tensor, red: int):
+    if red == RED_MINMAX:
+        lo, hi = result.tolist()  # one device-to-host read for both
+        return float(lo), float(hi)
+    return float(result[0].item())
+
+
+def reduce(x, red: int, n: int | None = None):
+    """``atx_reduce``; ``RED_MINMAX`` returns ``(minimum, maximum)`` from one pass."""
     n = x.numel() if n is None else n
-    result = torch.zeros(1, dtype=torch.float64, device=x.device)
+    result = torch.zeros(2, dtype=torch.float64, device=x.device)
     _call("atx_reduce", _ptr(x), n, red, _ptr(result), dtype_code(x.dtype), _stream())
-    return float(result.item())
+    return _reduction_result(result, red)
 
 
-def reduce_stack(x, red: int, *, n_pts: int, n_lev: int, pitch: int, layout: int) -> float:
-    """``atx_reduce`` over the elements of a pitched stack (padding excluded)."""
-    result = torch.zeros(1, dtype=torch.float64, device=x.device)
+def reduce_stack(x, red: int, *, n_pts: int, n_lev: int, pitch: int, layout: int):
+    """``atx_reduce`` over the elements of a pitched stack (padding excluded); ``RED_MINMAX``: ``(minimum, maximum)``."""
+    result = torch.zeros(2, dtype=torch.float64, device=x.device)
     _call("atx_reduce_stack", _ptr(x), n_pts, n_lev, pitch, red, _ptr(result), dtype_code(x.dtype), layout, _stream())
-    return float(result.item())
+    return _reduction_result(result, red)
 
 
 def select_levels(src, dst, level_map, *, n_pts, n_src_lev, src_pitch, dst_pitch, layout) -> None:

@@ -259,9 +259,9 @@ int atx_mask_to_index(const uint8_t* mask, int64_t n, int32_t* index, int64_t* c
                       void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---- reductions (range / validity checks) ---------------------------------- */
-typedef enum { ATX_RED_MIN = 0, ATX_RED_MAX = 1, ATX_RED_NANCOUNT = 2 } atx_red;
-/* result: device double[1]; min/max ignore nothing (NaN propagates like np.min);
- * NANCOUNT returns the count as a double.
+typedef enum { ATX_RED_MIN = 0, ATX_RED_MAX = 1, ATX_RED_NANCOUNT = 2, ATX_RED_MINMAX = 3 } atx_red;
+/* result: device double[1] (double[2] for ATX_RED_MINMAX: minimum, maximum — both from ONE pass over the data);
+ * min/max ignore nothing (NaN propagates like np.min); NANCOUNT returns the count as a double.
  *   R: filters/fields/cos_sin_from_rad.py:73-76 `data.min()/max()`;
  *      tests/field_filters/test_apply_mask.py:106 `np.sum(np.isnan(result))` */
 int atx_reduce(const void* x, int64_t n, int red, double* result, int dtype, void* stream);

@@ -172,6 +172,8 @@ def mask_to_index(mask, n=None):
 
 def reduce(x, red, n=None):
     a = x.numpy().reshape(-1)[: (x.numel() if n is None else n)]
+    if red == native.RED_MINMAX:
+        return float(a.min()), float(a.max())
     if red == native.RED_MIN:
         return float(a.min())
     if red == native.RED_MAX:
@@ -185,6 +187,8 @@ def relayout(src, dst, *, n_pts, n_lev, src_pitch, dst_pitch, src_layout, dst_la
 
 def reduce_stack(x, red, *, n_pts, n_lev, pitch, layout):
     a = _levels(x, n_pts, n_lev, layout)
+    if red == native.RED_MINMAX:
+        return float(a.min()), float(a.max())
     if red == native.RED_MIN:
         return float(a.min())
     if red == native.RED_MAX:

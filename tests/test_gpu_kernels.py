@@ -438,6 +438,26 @@ def test_reduce(dev, tdtype, np_dtype):
     assert np.isnan(native.reduce(xd, native.RED_MIN)) and np.isnan(x.min())
     assert np.isnan(native.reduce(xd, native.RED_MAX))
     assert native.reduce(xd, native.RED_NANCOUNT) == float(np.sum(np.isnan(x)))
+    assert all(np.isnan(v) for v in native.reduce(xd, native.RED_MINMAX))
+    # both extremes from ONE pass (the range check of cos_sin_from_rad): flat arrays of awkward lengths and alignments
+    # (an unaligned base takes the 4-byte kernels, twice), and pitched stacks in both layouts with poisoned padding
+    for n, shift in ((1, 0), (3, 0), (4, 0), (5, 1), (1027, 0), (100003, 3), (100000, 0)):
+        y = make_fields(rng, 1, n + shift, np_dtype)[0]
+        yd = to_dev(y, dev)[shift:]
+        assert native.reduce(yd, native.RED_MINMAX) == (float(y[shift:].min()), float(y[shift:].max())), (n, shift)
+        assert native.reduce(yd, native.RED_MIN) == float(y[shift:].min()) and native.reduce(yd, native.RED_NANCOUNT) == 0.0
+    for layout in LAYOUTS:
+        for n_lev, n_pts, pad in ((1, 50, 0), (3, 1001, 1), (137, 997, 3), (13, 4099, 4), (140, 513, 0)):
+            z = make_fields(rng, n_lev, n_pts, np_dtype)
+            rows, row_len = (n_pts, n_lev) if layout == COLUMNS else (n_lev, n_pts)
+            per16 = 16 // z.itemsize
+            for pitch in (row_len + pad, (row_len + pad + per16 - 1) // per16 * per16):
+                data = torch.full((rows, pitch), float("nan"), dtype=tdtype, device=dev)
+                data[:, :row_len] = to_dev(z.T if layout == COLUMNS else z, dev)
+                kw = dict(n_pts=n_pts, n_lev=n_lev, pitch=pitch, layout=layout)
+                assert native.reduce_stack(data, native.RED_MINMAX, **kw) == (float(z.min()), float(z.max())), (layout, n_lev, n_pts, pitch)
+                assert native.reduce_stack(data, native.RED_MAX, **kw) == float(z.max())
+                assert native.reduce_stack(data, native.RED_NANCOUNT, **kw) == 0.0
 
 
 # ---------------------------------------------------------------------------------

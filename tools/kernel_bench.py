@@ -135,6 +135,8 @@ def main():
         one = native.level_program([[(native.OP_AFFINE, 0, 2.0, 1.0)] + [(native.OP_COPY, 0, 0.0, 0.0)] * (L - 1)], dev)
         record(f"pointwise 1 of {L} levels selected {tag} in-place", timeit(lambda: native.pointwise_stack(y.data, y.data, prog=one, n_stage=1, **kw)),
                2 * n_src * B, "untouched levels are skipped; 16-B vector granularity")
+        record(f"reduce min+max of the stack {tag} (one pass)", timeit(lambda: native.reduce_stack(x.data, native.RED_MINMAX, n_pts=n_src, n_lev=L, pitch=x.pitch, layout=COLUMNS)),
+               stack_bytes, "the range check of cos_sin_from_rad; includes the device->host read (round 1: two passes of 0.79 ms)")
         # ---- multi-input
         z = x.new_like()
         record(f"combine snow_cover (2->1) {tag}", timeit(lambda: native.combine_stack(native.COMB_SNOW_COVER, [x.data, y.data], [z.data],
