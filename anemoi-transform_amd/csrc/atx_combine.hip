@@ -26,10 +26,22 @@ __device__ __forceinline__ void combine_one(int op, int flags, const T* x, int n
             T tmp2 = x[1];  // np.clip(rsn, 100, 400): NaN stays NaN
             tmp2 = (tmp2 < T(100)) ? T(100) : tmp2;
             tmp2 = (tmp2 > T(400)) ? T(400) : tmp2;
-            T sc = tanh((T(4000) * tmp1) / tmp2);
-            sc = (sc < T(0)) ? T(0) : sc;
-            sc = (sc > T(1)) ? T(1) : sc;
-            y0 = (sc > T(0.99)) ? T(1.0) : sc;
+            const T arg = (T(4000) * tmp1) / tmp2;
+            // The two common cases need no tanh and give the statement's bits exactly: deep snow — every arg > atanh(0.99) =
+            // 2.6467 has tanh(arg) > 0.99 (at 2.65: 0.990066, four orders above any rounding of tanh), which the last line
+            // sends to 1.0 — and no snow — tanh(+-0) = +-0, which the clip and the threshold leave alone.  float64 tanh
+            // costs ~100 operations; on real fields most points are one or the other.  NaN fails both tests and takes the
+            // full path.
+            if (arg > T(2.65)) {
+                y0 = T(1.0);
+            } else if (arg == T(0)) {
+                y0 = arg;
+            } else {
+                T sc = tanh(arg);
+                sc = (sc < T(0)) ? T(0) : sc;
+                sc = (sc > T(1)) ? T(1) : sc;
+                y0 = (sc > T(0.99)) ? T(1.0) : sc;
+            }
             break;
         }
         case ATX_COMB_COS_SIN: {

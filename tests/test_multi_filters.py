@@ -296,6 +296,39 @@ def test_combine_kernel_vs_oracle(dev, tdtype, np_dtype, rtol, layout):
         run(native.COMB_SNOW_COVER, [a], 1)
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("tdtype,np_dtype", [(torch.float64, np.float64), (torch.float32, np.float32)])
+def test_snow_cover_shortcuts_give_the_statements_values(dev, tdtype, np_dtype):
+    """R: filters/fields/snow_cover.py:34-39.  The kernel skips tanh for deep snow (argument beyond atanh(0.99): the statement's
+    threshold makes the result exactly 1.0) and for bare ground (tanh(+-0) = +-0): around both decisions, and for NaN / inf /
+    negative inputs, the result must be the statement's — exactly where no tanh is involved, to ocml-vs-libm rounding where it is."""
+    from anemoi_transform_amd.stack import Stack
+
+    rsn = np.array([50.0, 100.0, 250.0, 400.0, 900.0])
+    clipped = np.clip(rsn, 100, 400)
+    # snow depths placing 4000 * (1000 * sd / rsn) / clip(rsn) at chosen arguments, the decision points included
+    args = np.array([0.0, -0.0, 1e-300, 1e-8, 0.5, 2.0, 2.6, 2.6466, 2.6467, 2.649999, 2.65, 2.650001, 2.7, 5.0, 19.0, 40.0, 1e6, -1e-3, -3.0,
+                     np.inf, -np.inf, np.nan])
+    sd = (args[:, None] * clipped[None, :] * rsn[None, :] / 4.0e6).astype(np_dtype)
+    den = np.broadcast_to(rsn[None, :], sd.shape).astype(np_dtype)
+    n = sd.size
+    a = np.tile(sd.reshape(1, -1), (3, 1))
+    b = np.tile(den.reshape(1, -1), (3, 1))
+    b[2, ::7] = np.nan  # NaN density too
+    want = oracle.snow_cover(a.copy(), b.copy())
+    for layout in (native.COLUMNS, native.FIELDS):
+        sa, sb = Stack.from_fields(a, dev=dev, layout=layout), Stack.from_fields(b, dev=dev, layout=layout)
+        out = sa.new_like(zero=False)
+        native.combine_stack(native.COMB_SNOW_COVER, [sa.data, sb.data], [out.data], n_pts=n, n_lev=3, pitch=sa.pitch, layout=layout)
+        got = out.numpy()
+        assert np.array_equal(np.isnan(got), np.isnan(want))
+        ok = ~np.isnan(want)
+        exact = ok & ((want == 1.0) | (want == 0.0))  # saturated, bare or clipped: no tanh value survives
+        assert np.array_equal(got[exact], want[exact]) and np.array_equal(np.signbit(got[exact]), np.signbit(want[exact]))
+        np.testing.assert_allclose(got[ok], want[ok], rtol=1e-13 if np_dtype == np.float64 else 2e-6)
+        assert (want[ok] == 1.0).sum() > n // 4 and ((want[ok] > 0) & (want[ok] < 0.99)).sum() > n // 8  # both sides of the decision are exercised
+
+
 def test_accum_to_interval(engine):
     """R: tests/field_filters/test_accum_to_interval.py — differencing within (param, level) groups by valid time."""
     rng = np.random.default_rng(8)

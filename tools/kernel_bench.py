@@ -139,8 +139,20 @@ def main():
                stack_bytes, "the range check of cos_sin_from_rad; includes the device->host read (round 1: two passes of 0.79 ms)")
         # ---- multi-input
         z = x.new_like()
-        record(f"combine snow_cover (2->1) {tag}", timeit(lambda: native.combine_stack(native.COMB_SNOW_COVER, [x.data, y.data], [z.data],
-               n_pts=n_src, n_lev=L, pitch=x.pitch, layout=COLUMNS)), 3 * stack_bytes)
+        # snow depth (m of water equivalent) and density as they occur — in REGIONS, as on a real field (points are stored by
+        # latitude): ~55 % of the points bare (sd = 0), ~35 % deep snow, ~10 % a thin cover where tanh really has to be evaluated;
+        # density 100-400 kg/m3
+        sd, rsn = x.new_like(), x.new_like()
+        u = (torch.arange(n_src, device=dev, dtype=torch.float64) / n_src).unsqueeze(1).expand(n_src, L)
+        sd.data[:, :L] = torch.where(u < 0.55, torch.zeros_like(u), torch.where(u < 0.9, 0.05 + u, 1e-4 * u)).to(tdt)
+        rsn.data[:, :L] = (100.0 + 300.0 * torch.rand(n_src, L, device=dev)).to(tdt)
+        del u
+        record(f"combine snow_cover (2->1) {tag}", timeit(lambda: native.combine_stack(native.COMB_SNOW_COVER, [sd.data, rsn.data], [z.data],
+               n_pts=n_src, n_lev=L, pitch=x.pitch, layout=COLUMNS)), 3 * stack_bytes, "regions: 55 % bare, 35 % deep snow, 10 % thin cover (tanh evaluated)")
+        sd.data.fill_(1e-5)  # 4000 * (1000 * 1e-5 / rsn) / rsn < 2.65 everywhere: tanh on every element
+        record(f"combine snow_cover (2->1) {tag}, thin cover everywhere", timeit(lambda: native.combine_stack(native.COMB_SNOW_COVER, [sd.data, rsn.data], [z.data],
+               n_pts=n_src, n_lev=L, pitch=x.pitch, layout=COLUMNS)), 3 * stack_bytes, "worst case: tanh evaluated on every element")
+        del sd, rsn
         record(f"combine difference (2->1, accum_to_interval) {tag}", timeit(lambda: native.combine_stack(native.COMB_SUB, [x.data, y.data], [z.data],
                n_pts=n_src, n_lev=L, pitch=x.pitch, layout=COLUMNS)), 3 * stack_bytes)
         record(f"combine cos_sin (1->2) {tag}", timeit(lambda: native.combine_stack(native.COMB_COS_SIN, [x.data], [y.data, z.data],
