@@ -77,6 +77,8 @@ def test_n320_sized_reduced_grid():
     assert rows.shape == (640,) and rows.sum() == 542080
     assert np.array_equal(rows, rows[::-1]) and rows[0] == 18 and rows.max() == 1280 == rows[319]
     assert np.all(np.diff(rows[:320]) >= 0) and np.all(rows % 2 == 0)
+    pinned = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "n320_sized_rows.json")))
+    assert rows[:320].tolist() == pinned["north_rows"] and pinned["total"] == 542080  # the construction is pinned
     g = grids.lookup("n320-sized")
     assert len(g["latitudes"]) == 542080 == len(g["longitudes"])
     assert np.array_equal(np.unique(g["latitudes"])[::-1], grids.gaussian_latitudes(640))
