@@ -58,7 +58,7 @@ def test_two_ranks_rehearsal_over_gloo():
     for kind in ("broadcast", "bands"):
         assert d["source_exchange"][kind]["verified_bit_equal"] is True
     assert d["source_exchange"]["bands"]["bytes_received_per_gpu"] < d["source_exchange"]["broadcast"]["bytes_received_per_gpu"]
-    assert d["end_to_end"]["verified_bit_equal"] is True and d["end_to_end_bands"]["verified_bit_equal"] is True
+    assert d["end_to_end"]["verified_bit_equal"] is True and d["end_to_end_bands"]["verified_bit_equal"] is True  # (small grids: no section skipped)
     assert d["end_to_end"]["value"] > 0 and d["end_to_end"]["value"] < d["value"]  # the exchange is inside that one
     assert d["strong"]["scaling"] == "strong" and d["strong"]["value"] > 0
     assert d["config4"]["value"] > 0 and d["config4"]["fields"] == 24 * 7
