@@ -124,6 +124,22 @@ def time_launches(fn, steps, warmup):
     return float(np.mean(ms)), float(np.min(ms))
 
 
+class quiet_stdout:
+    """File descriptor 1 points at stderr inside the block: the collective libraries print connection notes to stdout
+    ("[Gloo] Rank 0 is connected to ..."), and stdout is reserved for the ONE JSON line."""
+
+    def __enter__(self):
+        sys.stdout.flush()
+        self.saved = os.dup(1)
+        os.dup2(2, 1)
+
+    def __exit__(self, *exc):
+        sys.stdout.flush()
+        os.dup2(self.saved, 1)
+        os.close(self.saved)
+        return False
+
+
 def line(n_units, ms, alg_bytes):
     gbs = alg_bytes / (ms * 1e-3) / 1e9
     return {"value": n_units / (ms * 1e-3), "avg_launch_ms": ms, "achieved_GBs": gbs, "frac": gbs / HBM_PEAK_GBS}
@@ -156,13 +172,16 @@ def main():
         import torch.distributed as dist
 
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")  # one node by contract: the host-side group talks over loopback, whatever the hostname resolves to
         assert not (args.share_device and args.backend == "nccl"), "RCCL needs one GPU per rank"
         if world == 1:  # --rehearse-multi without a launcher
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29541")
             os.environ.setdefault("RANK", "0")
             os.environ.setdefault("WORLD_SIZE", "1")
-        dist.init_process_group("gloo")  # host-side: barriers, the max-over-ranks of the elapsed time
+        with quiet_stdout():
+            dist.init_process_group("gloo")  # host-side: barriers, the max-over-ranks of the elapsed time
+            dist.barrier()
 
     def barrier():
         if multi:
@@ -296,8 +315,15 @@ def main():
     }
 
     if multi and not args.no_extras:
-        multi_gpu_lines(args, result, dist, rank, world, dev, plan, stacks, outs, launch, units_per_step, barrier, max_over_ranks,
-                        src_grid, n_src, n_tgt, tdtype, np_dtype, idx64, w64, layout)
+        # RCCL announces itself on stdout when its first communicator comes up (version, host, library path): the secondary sections
+        # run with file descriptor 1 pointing at stderr, stdout stays reserved for the ONE JSON line
+        quiet = quiet_stdout()
+        quiet.__enter__()
+        try:
+            multi_gpu_lines(args, result, dist, rank, world, dev, plan, stacks, outs, launch, units_per_step, barrier, max_over_ranks,
+                            src_grid, n_src, n_tgt, tdtype, np_dtype, idx64, w64, layout, quiet.saved)
+        finally:
+            quiet.__exit__()
 
     if rank == 0 and world == 1 and not args.rehearse_multi:
         single_gpu_lines(args, result, dev, stacks, outs, launch, idx_d, w_d, idx64, w64, n_src, n_tgt, n_unique, alg, src_grid, tgt_grid,
@@ -307,14 +333,15 @@ def main():
         print(json.dumps(result), flush=True)
     if multi:
         barrier()
-        dist.destroy_process_group()
+        with quiet_stdout():
+            dist.destroy_process_group()
 
 
 # ------------------------------------------------------------------------------------------------------------------------
 # N > 1: what is measured AFTER `value` — the exchange over RCCL, end to end, strong scaling, field-axis sharding
 # ------------------------------------------------------------------------------------------------------------------------
 def multi_gpu_lines(args, result, dist, rank, world, dev, plan, stacks, outs, launch, units_per_step, barrier, max_over_ranks,
-                    src_grid, n_src, n_tgt, tdtype, np_dtype, idx64, w64, layout):
+                    src_grid, n_src, n_tgt, tdtype, np_dtype, idx64, w64, layout, real_stdout_fd):
     from anemoi_transform_amd import distributed as atxd
     from anemoi_transform_amd import native
     from anemoi_transform_amd.stack import COLUMNS, Stack
@@ -326,7 +353,7 @@ def multi_gpu_lines(args, result, dist, rank, world, dev, plan, stacks, outs, la
     def give_up():
         if rank == 0:
             result["secondary_timed_out_in"] = state["section"]
-            print(json.dumps(result), flush=True)
+            os.write(real_stdout_fd, (json.dumps(result) + "\n").encode())  # fd 1 points at stderr in here
         os._exit(0)
 
     watchdog = threading.Timer(args.secondary_seconds, give_up)

@@ -20,8 +20,9 @@ KEYS = {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "
 
 
 def last_json(stdout: str) -> dict:
-    lines = [l for l in stdout.strip().splitlines() if l.startswith("{")]
-    assert len(lines) == 1, stdout  # exactly ONE JSON line
+    lines = [l for l in stdout.strip().splitlines() if l.strip()]
+    # stdout carries exactly ONE line, the JSON one: nothing else (the collective libraries' connection notes go to stderr)
+    assert len(lines) == 1 and lines[0].startswith("{"), stdout
     return json.loads(lines[0])
 
 
