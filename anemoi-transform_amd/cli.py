@@ -19,7 +19,6 @@ Grids are names understood by ``grids.lookup`` (O<N>, F<N>, lat-lon increments) 
 from __future__ import annotations
 
 import argparse
-import re
 import sys
 
 import numpy as np
@@ -31,11 +30,14 @@ def _grid(spec: str):
     return lookup(spec)
 
 
-def _octahedral_n(spec: str) -> int:
-    m = re.match(r"^[oO](\d+)$", spec)
-    if not m:
-        raise SystemExit(f"bilinear-matrix needs an octahedral source grid O<N>, got {spec!r}")
-    return int(m.group(1))
+def _rows(spec: str):
+    """Row structure of a formula source grid (O<N>, F<N>, N320-sized, regular lat-lon increments) for the bilinear builder."""
+    from .grids import row_structure
+
+    rows = row_structure(spec)
+    if rows is None:
+        raise SystemExit(f"bilinear-matrix needs a row-structured formula source grid (O<N>, F<N>, n320-sized, dlat/dlon), got {spec!r}")
+    return rows
 
 
 def main(argv: list[str] | None = None) -> int:
@@ -90,7 +92,7 @@ def main(argv: list[str] | None = None) -> int:
         interp.save_matrix_npz(args.output, interp.ell_to_csr(idx, w, len(src["latitudes"])), src, tgt)
     elif args.kind == "bilinear-matrix":
         src, tgt = _grid(args.source_grid), _grid(args.target_grid)
-        interp.save_matrix_npz(args.output, interp.bilinear_octahedral(_octahedral_n(args.source_grid), tgt), src, tgt)
+        interp.save_matrix_npz(args.output, interp.bilinear_rows(*_rows(args.source_grid), tgt), src, tgt)
     else:
         glob, lam = _grid(args.global_grid), _grid(args.lam_grid)
         mask = spatial.global_on_lam_mask(np.asarray(lam["latitudes"]), np.asarray(lam["longitudes"]), np.asarray(glob["latitudes"]),

@@ -505,6 +505,12 @@ def test_cli_writes_the_reference_file_formats(tmp_path, capsys):
     assert np.array_equal(m["matrix_indices"].reshape(-1, 3), idx) and np.array_equal(m["matrix_data"].reshape(-1, 3), w)
     assert main(["make-regrid-file", "bilinear-matrix", "o16", "20/20", "--output", bil_file]) == 0
     assert np.allclose(np.load(bil_file)["matrix_data"].reshape(-1, 4).sum(axis=1), 1.0)
+    for source in ("f8", "10/10"):  # any row-structured formula grid is a valid source of the bilinear builder
+        assert main(["make-regrid-file", "bilinear-matrix", source, "o8", "--output", bil_file]) == 0
+        b = np.load(bil_file)
+        assert tuple(b["matrix_shape"]) == (len(grids.lookup("o8")["latitudes"]), len(grids.lookup(source)["latitudes"]))
+    with pytest.raises(SystemExit):
+        main(["make-regrid-file", "bilinear-matrix", grid_file, "o8", "--output", bil_file])  # an npz has no row structure
     lam = str(tmp_path / "lam.npz")
     lat, lon = np.meshgrid(np.linspace(40, 50, 6), np.linspace(0, 10, 6))
     np.savez(lam, latitudes=lat.ravel(), longitudes=lon.ravel())
