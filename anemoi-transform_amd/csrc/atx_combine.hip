@@ -121,7 +121,20 @@ combine_kernel(CombArgs a, int op, int flags, int n_in, int n_out, int64_t n_row
     constexpr int U = comb_unroll(NIN, (int)sizeof(T));
     constexpr int64_t kChunk = (int64_t)kBlock * U;
     const bool small_rows = vec_per_row < (1 << 20);  // columns layout: (row, col) from 32-bit arithmetic
+    // a workgroup takes a contiguous run of chunks, not every gridDim.x-th one: under the 65536-workgroup cap the grid stride is a
+    // power of two (1 GiB for f64) and drifting workgroups alias onto the same HBM channels (atx_pointwise.hip, ATX_PW_ASSIGN)
+#ifndef ATX_COMB_ASSIGN
+#define ATX_COMB_ASSIGN 1
+#endif
+#if ATX_COMB_ASSIGN == 1
+    const int64_t n_chunks = (total + kChunk - 1) / kChunk;
+    const int64_t per = (n_chunks + gridDim.x - 1) / gridDim.x;
+    const int64_t first = (int64_t)blockIdx.x * per * kChunk;
+    const int64_t last = first + per * kChunk < total ? first + per * kChunk : total;
+    for (int64_t base = first; base < last; base += kChunk) {
+#else
     for (int64_t base = (int64_t)blockIdx.x * kChunk; base < total; base += (int64_t)gridDim.x * kChunk) {
+#endif
         const int64_t row_b = base / vec_per_row;  // uniform
         const int col_b = (int)(base - row_b * vec_per_row);
         V x[U][NIN];
@@ -180,7 +193,10 @@ static int combine_typed(const CombArgs& a, int op, int flags, int n_in, int n_o
     const int64_t row_len = layout == ATX_COLUMNS ? n_lev : n_pts;
     const int per_block = kBlock * comb_unroll(n_in <= 3 ? n_in : ATX_COMB_MAX_INPUTS, (int)sizeof(T));
     int64_t blocks = (n_rows * (pitch / (vec_ok ? VEC : 1)) + per_block - 1) / per_block;
-    if (blocks > comb_grid_cap((int)sizeof(T))) blocks = comb_grid_cap((int)sizeof(T));
+    if (blocks > comb_grid_cap((int)sizeof(T))) {
+        const int64_t n_chunks = blocks, per = (n_chunks + comb_grid_cap((int)sizeof(T)) - 1) / comb_grid_cap((int)sizeof(T));
+        blocks = (n_chunks + per - 1) / per;  // contiguous runs of `per` chunks per workgroup, none without work
+    }
     if (blocks < 1) blocks = 1;
 #define ATX_COMB_LAUNCH(V_, N_)                                                                                              \
     hipLaunchKernelGGL((combine_kernel<T, V_, N_>), dim3((unsigned)blocks), dim3(kBlock), 0, st, a, op, flags, n_in, n_out, n_rows, \

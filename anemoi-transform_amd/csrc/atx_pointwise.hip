@@ -136,7 +136,23 @@ pointwise_cols_flat_kernel(const T* __restrict__ x, T* __restrict__ y, int64_t n
 
     const int64_t n_vec = n_pts * C;
     constexpr int64_t kChunk = (int64_t)kBlock * kPwUnroll;
+    // A workgroup takes a CONTIGUOUS run of chunks (ATX_PW_ASSIGN 1), not every gridDim.x-th one: under the 65536-workgroup cap the
+    // grid stride is 65536 * 16 KB = exactly 1 GiB, and workgroups that drift apart then stream from addresses a power of two
+    // apart — on boxes whose allocations are physically contiguous these alias onto the same HBM channels / banks (the same kernel
+    // binary measured 2.37 ms on one box and 2.63 ms on another for 137 float64 levels of O1280 while atx_stream_copy stayed at
+    // 2.33 ms on both; profiles/r03_pointwise_ab.log, r03_pointwise_placement.log).
+#ifndef ATX_PW_ASSIGN
+#define ATX_PW_ASSIGN 1
+#endif
+#if ATX_PW_ASSIGN == 1
+    const int64_t n_chunks = (n_vec + kChunk - 1) / kChunk;
+    const int64_t per = (n_chunks + gridDim.x - 1) / gridDim.x;
+    const int64_t first = (int64_t)blockIdx.x * per * kChunk;
+    const int64_t last = first + per * kChunk < n_vec ? first + per * kChunk : n_vec;
+    for (int64_t base = first; base < last; base += kChunk) {
+#else
     for (int64_t base = (int64_t)blockIdx.x * kChunk; base < n_vec; base += (int64_t)gridDim.x * kChunk) {
+#endif
         const int64_t row_b = base / C;  // uniform: scalar unit
         const int col_b = (int)(base - row_b * C);
         V v[kPwUnroll];
@@ -681,17 +697,25 @@ static int pointwise_typed(const void* x_, void* y_, int64_t n_pts, int n_lev, i
 #endif
         if (ATX_PW_FLAT && wide && xp == (int64_t)C * VEC && yp == xp) {  // one contiguous run of vectors: line-aligned chunks
             const int64_t n_vec = n_pts * C;
-            // measured (137 levels of O1280): one stage, f32, out of place: table kernel 1.21 ms (6.1 TB/s) vs 1.31 ms for the chunked
-            // kernel below.  With a point mask (a byte gather per vector), in f64, with several stages (24 B of operators per stage
-            // and vector: 3 stages 1.88 vs 1.38 ms) or in place with few active levels the chunked kernel is as fast or faster.
-            if (vec_prog && !mask && sizeof(T) == 4 && n_stage == 1 && !in_place && (n_vec + kBlock - 1) / kBlock <= 0x7fffffffll) {
+            // measured (137 levels of O1280, profiles/r03_pointwise_ab.log): the table kernel (one vector per lane, no loop) wins for
+            // one-stage f32 programs without a mask, out of place (1.21 ms both) AND in place (1.22 vs 1.36 ms chunked); it loses in f64
+            // (2.48 vs 2.37 ms), with two stages (f32 1.56 vs 1.28, f64 3.38 vs 2.58 ms: 24-32 B of operators per stage and vector) and
+            // with a point mask in f64 (2.74 vs 2.43 ms).  ATX_PW_TABLE_RULE: 0 = round 2's rule (out of place only), 1 = this rule.
+#ifndef ATX_PW_TABLE_RULE
+#define ATX_PW_TABLE_RULE 1
+#endif
+            const bool table_narrow = !mask && sizeof(T) == 4 && n_stage == 1 && !in_place;
+            const bool table_wide = ATX_PW_TABLE_RULE == 1 && !mask && sizeof(T) == 4 && n_stage == 1;
+            if (vec_prog && (table_narrow || table_wide) && (n_vec + kBlock - 1) / kBlock <= 0x7fffffffll) {
                 hipLaunchKernelGGL((pointwise_cols_table_kernel<T, VEC>), dim3((unsigned)((n_vec + kBlock - 1) / kBlock)), dim3(kBlock), 0, st,
                                    x, y, n_vec, n_lev, C, prog, vec_prog, n_stage, mask, in_place);
                 ATX_LAUNCH_CHECK("pointwise_stack");
                 return ATX_OK;
             }
-            int64_t blocks = (n_vec + (int64_t)kBlock * kPwUnroll - 1) / ((int64_t)kBlock * kPwUnroll);
-            if (blocks > kMaxGrid) blocks = kMaxGrid;
+            const int64_t n_chunks = (n_vec + (int64_t)kBlock * kPwUnroll - 1) / ((int64_t)kBlock * kPwUnroll);
+            int64_t blocks = n_chunks > kMaxGrid ? kMaxGrid : n_chunks;
+            const int64_t per = (n_chunks + blocks - 1) / blocks;
+            blocks = (n_chunks + per - 1) / per;  // contiguous runs of `per` chunks: no workgroup without work
             const size_t lds_flat = lds + (size_t)C;
             hipLaunchKernelGGL((pointwise_cols_flat_kernel<T, VEC>), dim3((unsigned)blocks), dim3(kBlock), lds_flat, st, x, y, n_pts, n_lev,
                                C, prog, n_stage, mask, in_place);

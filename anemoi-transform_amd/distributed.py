@@ -192,6 +192,23 @@ def sharded_regrid(plan: GatherPlan, src: Stack, rank: int | None = None, world:
     return plan.shard(rank, world).apply(src)
 
 
+def _streams(device):
+    """(compute stream, a fresh side stream) — a seam the ordering test replaces with recording doubles."""
+    return torch.cuda.current_stream(), torch.cuda.Stream(device=device)
+
+
+def _on_stream(stream):
+    return torch.cuda.stream(stream)
+
+
+def _event():
+    return torch.cuda.Event()
+
+
+def _record_stream(tensor, stream) -> None:
+    tensor.record_stream(stream)
+
+
 def pipelined_sharded_regrid(plan: GatherPlan, mine: Stack, comm=None) -> list[Stack]:
     """End-to-end form of the target-sharded step: every rank contributes one source stack; the broadcast of stack
     ``r + 1`` runs (on the collective's own stream) while this rank interpolates its target slice of stack ``r``.
@@ -206,18 +223,24 @@ def pipelined_sharded_regrid(plan: GatherPlan, mine: Stack, comm=None) -> list[S
     outs: list[Stack] = []
     if comm is not None:
         # the same pipeline on explicit HIP streams: broadcasts are enqueued on a side stream, the launch of stack r waits
-        # (on the device, via an event) for broadcast r only, so broadcast r + 1 runs under it
-        compute = torch.cuda.current_stream()
-        side = torch.cuda.Stream(device=mine.device)
-        side.wait_stream(compute)  # `mine` may still be being written by the compute stream
+        # (on the device, via an event) for broadcast r only, so broadcast r + 1 runs under it.
+        #
+        # Ordering of the receive buffers.  Buffer r + 1 is ALLOCATED on the compute stream (torch's caching allocator) and first
+        # WRITTEN by the broadcast on the side stream.  From the third stack on the allocator may hand back the block of stack
+        # r - 1 — free for the side stream as soon as broadcast r - 1 is over, while `local.apply(r - 1)` may still be queued or
+        # reading it on the compute stream.  So before EVERY broadcast the side stream waits for what the compute stream holds
+        # at that moment (launches up to r - 1: broadcast r + 1 still runs under launch r, the overlap is kept).  torch's own nccl
+        # path below gets the same guarantee from ProcessGroupNCCL, which makes its stream wait for the current stream per collective.
+        compute, side = _streams(mine.device)
 
         def start(r: int):
             b = incoming(r)
-            with torch.cuda.stream(side):
+            side.wait_stream(compute)  # `mine` being written, and every launch still reading a block `b` may now occupy
+            with _on_stream(side):
                 comm.bcast(b.data, r)
-                done = torch.cuda.Event()
+                done = _event()
                 done.record(side)
-            b.data.record_stream(side)
+            _record_stream(b.data, side)
             return b, done
 
         buf, done = start(0)

@@ -4,6 +4,7 @@
     python bench.py --gpus 1 --steps 200 --warmup 20
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N ...        # no launcher: this process starts the N workers itself (launch_workers) and relays the line
 
 A *step* is one pass of the regrid hot path over one batch of synthetic input already resident in HBM: at N = 1 one
 137-level stack on the O1280 octahedral grid (6 599 680 points) is interpolated to the 0.25 degree lat-lon grid
@@ -60,11 +61,16 @@ def parse_args():
     ap.add_argument("--tgt-grid", default="0.25")
     ap.add_argument("--levels", type=int, default=137)
     ap.add_argument("--k", type=int, default=4)
-    ap.add_argument("--dtype", default="f32", choices=["f32", "f64"])
+    ap.add_argument("--dtype", default="f64", choices=["f32", "f64"],
+                    help="arithmetic of the headline: f64 is the reference's own (R: fields.py:178-202 hands float64 to numpy / scipy); "
+                         "the other width is reported in extras")
     ap.add_argument("--layout", default="columns", choices=["columns", "fields"])
     ap.add_argument("--tile", type=int, default=0, help="targets per workgroup (0 = library default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the secondary lines (N = 1: extras; N > 1: exchange / end-to-end / strong)")
+    ap.add_argument("--headline-shape-only", action="store_true",
+                    help="extras: keep the lines measured on the headline's own grids (k = 1, the other width, field-major, fused epilogue, k-NN "
+                         "build) and skip BASELINE configs 2 / 4 / 5 and the all-core CPU child, which run at their own full sizes")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline sample")
     ap.add_argument("--cpu-workers", type=int, default=0,
                     help="worker processes of extras.cpu_all_cores (0 = all cores this process may use: os.cpu_count() capped by the cgroup quota)")
@@ -75,6 +81,9 @@ def parse_args():
     ap.add_argument("--rehearse-multi", action="store_true",
                     help="REHEARSAL ONLY, with --gpus 1: run the N > 1 secondary sections (RCCL exchange through torch.distributed and through "
                          "atx_comm_*, end to end, strong) at world size 1 — the whole multi-GPU code path on the real collective library")
+    ap.add_argument("--launch-check", action="store_true",
+                    help="launcher check (runs without a GPU): every rank joins the host-side gloo group, one barrier and one max-reduction, "
+                         "rank 0 prints {\"launch_check\": true, ...} — what `python bench.py --gpus N` does before it touches the device")
     ap.add_argument("--share-device", action="store_true",
                     help="REHEARSAL ONLY: all ranks use cuda:0 (exercises the N > 1 code path on a 1-GPU box; needs --backend gloo)")
     return ap.parse_args()
@@ -145,15 +154,60 @@ def line(n_units, ms, alg_bytes):
     return {"value": n_units / (ms * 1e-3), "avg_launch_ms": ms, "achieved_GBs": gbs, "frac": gbs / HBM_PEAK_GBS}
 
 
+def launch_workers(args) -> int:
+    """`python bench.py --gpus N` without a launcher: this process — which has not touched the GPU and never will — starts N
+    FRESH worker processes through torch.distributed.run (one per GPU, rendezvous on 127.0.0.1 at a free port), passes rank 0's
+    single JSON line through on its own stdout and returns the launcher's exit status.  No process that has initialised HIP is
+    ever replaced by another program."""
+    import socket
+    import subprocess
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC only on this platform; must be set before a worker's HIP runtime starts
+    env.setdefault("GLOO_SOCKET_IFNAME", "lo")
+    env.setdefault("OMP_NUM_THREADS", "1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__), *sys.argv[1:]]
+    child = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)  # stderr passes straight through
+    lines = [l for l in child.stdout.splitlines() if l.strip().startswith("{")]
+    if lines:
+        print(lines[-1], flush=True)
+    if child.returncode != 0:
+        print(f"bench.py: the {args.gpus}-rank job ended with status {child.returncode}", file=sys.stderr)
+        return child.returncode
+    return 0 if lines else 4
+
+
 def main():
     args = parse_args()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:  # the driver's plain `python bench.py --gpus N`
+        raise SystemExit(launch_workers(args))
+    # before anything initialises the HIP runtime (it reads its environment once)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")  # one node by contract: the host-side group talks over loopback, whatever the hostname resolves to
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch N > 1 through torch.distributed.run (one process per GPU)")
         raise SystemExit(f"--gpus {args.gpus} does not match WORLD_SIZE {world}")
+    if args.launch_check:
+        import torch.distributed as dist
+
+        with quiet_stdout():
+            dist.init_process_group("gloo")
+            dist.barrier()
+            t = torch.tensor([float(rank)], dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        if rank == 0:
+            print(json.dumps({"launch_check": True, "n_gpus": world, "max_rank_seen": int(t.item()),
+                              "HSA_ENABLE_IPC_MODE_LEGACY": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY")}), flush=True)
+        with quiet_stdout():
+            dist.barrier()
+            dist.destroy_process_group()
+        return
 
     graft.load_package()
     from anemoi_transform_amd import native
@@ -171,8 +225,6 @@ def main():
     if multi:
         import torch.distributed as dist
 
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")  # one node by contract: the host-side group talks over loopback, whatever the hostname resolves to
         assert not (args.share_device and args.backend == "nccl"), "RCCL needs one GPU per rank"
         if world == 1:  # --rehearse-multi without a launcher
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -354,7 +406,7 @@ def multi_gpu_lines(args, result, dist, rank, world, dev, plan, stacks, outs, la
         if rank == 0:
             result["secondary_timed_out_in"] = state["section"]
             os.write(real_stdout_fd, (json.dumps(result) + "\n").encode())  # fd 1 points at stderr in here
-        os._exit(0)
+        os._exit(3)  # the measured line is out, but a collective that never returned is a FAILURE of the run: the launcher must see it
 
     watchdog = threading.Timer(args.secondary_seconds, give_up)
     watchdog.daemon = True
@@ -618,27 +670,47 @@ def single_gpu_lines(args, result, dev, stacks, outs, launch, idx_d, w_d, idx64,
 
     if not args.no_cpu_baseline:
         torch.set_num_threads(1)
-        # the reference's dtype is float64 (to_numpy default): time csr_array @ x per field, one thread
+        # SURVEY.md §8(d)(A) "as the reference runs": one process, one thread, a Python loop over fields executing the reference's
+        # two regrid statements — `csr_array @ x` (R: regrid.py:310) at the bench's k and `x[..., idx]` (R: regrid.py:380, k = 1) —
+        # in float64 (the reference's dtype, to_numpy default) and in float32.  `value` is the statement the headline replaces.
         from scipy.sparse import csr_array
 
-        matrix = csr_array((w64.reshape(-1), indices, indptr), shape=(n_tgt, n_src))
-        matrix @ sample64[0]
-        n_done, t0 = 0, time.perf_counter()
-        while time.perf_counter() - t0 < args.cpu_seconds:
-            for f in sample64:
-                _ = matrix @ f
-                n_done += 1
-        cpu_s = time.perf_counter() - t0
+        idx1_host = idx64[:, 0].astype(np.int64)  # cKDTree hands int64 indices to the fancy index
+        budget = max(args.cpu_seconds, 0.1)
+        share = {"csr_f64": 0.5, "csr_f32": 0.2, "k1_f64": 0.15, "k1_f32": 0.15}
+        variants = {}
+
+        def sample(name, statement, fields, what):
+            statement(fields[0])
+            n_done, t0 = 0, time.perf_counter()
+            while time.perf_counter() - t0 < budget * share[name]:
+                for f in fields:
+                    _ = statement(f)
+                    n_done += 1
+            s = time.perf_counter() - t0
+            variants[name] = {"value": n_done * n_tgt / s, "unit": "grid-points/s", "ms_per_field": s / n_done * 1e3, "fields": n_done,
+                              "seconds": s, "statement": what}
+
+        matrix64 = csr_array((w64.reshape(-1), indices, indptr), shape=(n_tgt, n_src))
+        matrix32 = csr_array((w64.astype(np.float32).reshape(-1), indices, indptr), shape=(n_tgt, n_src))
+        sample32 = sample64.astype(np.float32)
+        sample("csr_f64", lambda f: matrix64 @ f, sample64, f"scipy csr_array(k={args.k}) @ x, float64 (R: regrid.py:310)")
+        sample("csr_f32", lambda f: matrix32 @ f, sample32, f"scipy csr_array(k={args.k}) @ x, float32 matrix and field")
+        sample("k1_f64", lambda f: f[..., idx1_host], sample64, "x[..., nearest_grid_points], float64 (R: regrid.py:380)")
+        sample("k1_f32", lambda f: f[..., idx1_host], sample32, "x[..., nearest_grid_points], float32")
+        head = variants["csr_f64"]
         result["cpu_baseline"] = {
-            "value": n_done * n_tgt / cpu_s,
+            "value": head["value"],
             "unit": "grid-points/s",
             "cores": 1,
             "kind": "port",
             "dtype": "f64",
-            "sample": f"{n_done} fields ({n_sample} distinct levels of the same synthetic stack, float64 as in the "
-                      f"reference) x scipy csr_array(k={args.k}) @ x, {cpu_s:.1f} s on 1 thread; "
+            "sample": f"{head['fields']} fields ({n_sample} distinct levels of the same synthetic stack, float64 as in the "
+                      f"reference) x scipy csr_array(k={args.k}) @ x, {head['seconds']:.1f} s on 1 thread; the k = 1 statement and the "
+                      f"float32 forms of both in `variants` ({sum(v['seconds'] for v in variants.values()):.1f} s in all); "
                       f"host has {os.cpu_count()} logical cores",
-            "ms_per_field": cpu_s / n_done * 1e3,
+            "ms_per_field": head["ms_per_field"],
+            "variants": variants,
         }
 
     if args.no_extras:
@@ -673,17 +745,29 @@ def single_gpu_lines(args, result, dev, stacks, outs, launch, idx_d, w_d, idx64,
     stacks.clear()
     outs.clear()
     torch.cuda.empty_cache()
-    for name, dt, npdt, isz, lay in (("f64_columns", torch.float64, np.float64, 8, COLUMNS),
-                                     ("f32_fields", torch.float32, np.float32, 4, FIELDS)):
+    other = ("f32", torch.float32, np.float32, 4) if args.dtype == "f64" else ("f64", torch.float64, np.float64, 8)
+    for name, dt, npdt, isz, lay in ((f"{other[0]}_columns", *other[1:], COLUMNS),
+                                     (f"{args.dtype}_fields", tdtype, np_dtype, itemsize, FIELDS)):
         s = synth_stack(src_grid, n_lev, dt, dev, 0, lay)
         o = Stack.empty(n_tgt, n_lev, dt, dev, lay)
         wd = torch.from_numpy(w64.astype(npdt)).to(dev)
         ms, _ = time_launches(lambda: launch(s, o, w=wd), 10, 2)
         extras[name] = line(n_tgt * n_lev, ms, algorithmic_bytes(n_lev, isz, n_unique, n_tgt, args.k))
+        if name.endswith("_columns"):  # the k = 1 gather in the other width too
+            ms, _ = time_launches(lambda: launch(s, o, idx=idx1, w=None, k=1, n_t=n_tgt), 10, 2)
+            extras[f"nearest_k1_{other[0]}"] = line(n_tgt * n_lev, ms, algorithmic_bytes(n_lev, isz, int(np.unique(idx64[:, 0]).size), n_tgt, 1))
         del s, o, wd
         torch.cuda.empty_cache()
-    if "cpu_baseline" in result:  # the like-for-like ratio: the reference's own width on both sides
-        extras["f64_columns_over_cpu_f64_one_core"] = extras["f64_columns"]["value"] / result["cpu_baseline"]["value"]
+    if "cpu_baseline" in result:  # like-for-like ratios: the same statement in the same width on both sides (reported, not a target)
+        cpu = result["cpu_baseline"]["variants"]
+        gpu_k4 = {args.dtype: result["value"], other[0]: extras[f"{other[0]}_columns"]["value"]}
+        gpu_k1 = {args.dtype: extras["nearest_k1"]["value"], other[0]: extras[f"nearest_k1_{other[0]}"]["value"]}
+        extras["gpu_over_cpu_one_core"] = {f"k{args.k}_f64": gpu_k4["f64"] / cpu["csr_f64"]["value"], f"k{args.k}_f32": gpu_k4["f32"] / cpu["csr_f32"]["value"],
+                                           "k1_f64": gpu_k1["f64"] / cpu["k1_f64"]["value"], "k1_f32": gpu_k1["f32"] / cpu["k1_f32"]["value"]}
+
+    if args.headline_shape_only:
+        result["extras"] = extras
+        return
 
     # ---- BASELINE configs[1]: O96 -> 1 degree bilinear, ONE surface field (the thin-stack regime: a 1-level column stack)
     try:

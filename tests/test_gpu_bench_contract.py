@@ -33,12 +33,37 @@ def test_single_gpu_line():
     d = last_json(run.stdout)
     assert KEYS <= set(d) and d["n_gpus"] == 1 and d["steps"] == 3 and d["warmup"] == 1
     assert d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None and d["data"] == "synthetic"
-    assert d["unit"] == "grid-points/s" and d["value"] > 0 and d["dtype"] == "f32" and "workload" in d["config"]
+    assert d["unit"] == "grid-points/s" and d["value"] > 0 and d["dtype"] == "f64" and "workload" in d["config"]  # the reference's own arithmetic (R: fields.py:178-202)
     r = d["roofline"]
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] == 1 and c["value"] > 0 and "sample" in c
-    assert d["parity_max_rel_err"] <= 1e-6
+    # both reference statements (csr_array @ x, x[..., idx]) in both widths
+    assert set(c["variants"]) == {"csr_f64", "csr_f32", "k1_f64", "k1_f32"} and all(v["value"] > 0 for v in c["variants"].values())
+    assert c["value"] == c["variants"]["csr_f64"]["value"]
+    assert d["parity_max_rel_err"] == 0.0  # float64: scipy's bits
+
+
+def test_single_gpu_line_f32():
+    run = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *SMALL, "--dtype", "f32", "--cpu-seconds", "0.5", "--headline-shape-only"],
+                         capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert run.returncode == 0, run.stderr[-2000:]
+    d = last_json(run.stdout)
+    assert d["dtype"] == "f32" and d["parity_max_rel_err"] <= 1e-6
+    e = d["extras"]
+    assert e["f64_columns"]["value"] > 0 and e["nearest_k1"]["value"] > 0 and e["nearest_k1_f64"]["value"] > 0
+    assert set(e["gpu_over_cpu_one_core"]) == {"k4_f64", "k4_f32", "k1_f64", "k1_f32"}
+
+
+def test_two_ranks_without_a_launcher():
+    """`python bench.py --gpus 2` with no WORLD_SIZE in the environment — the shape of the driver's N = 1 command — starts its own
+    two workers (fresh processes; the parent never touches the GPU), relays rank 0's ONE line and exits 0."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    run = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", *SMALL, "--backend", "gloo", "--share-device",
+                          "--no-extras"], capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+    assert run.returncode == 0, run.stderr[-2000:]
+    d = last_json(run.stdout)
+    assert KEYS <= set(d) and d["n_gpus"] == 2 and d["value"] > 0 and d["config"]["stacks_per_step"] == 2
 
 
 def test_two_ranks_rehearsal_over_gloo():
@@ -77,7 +102,7 @@ def test_secondary_lines_cannot_cost_the_value():
            "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", *SMALL, "--backend", "gloo", "--share-device",
            "--secondary-seconds", "0"]
     run = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT)
-    assert run.returncode == 0, run.stderr[-2000:]
+    assert run.returncode != 0  # the line is out, but a collective that never returned is a failure the launcher must see
     d = last_json(run.stdout)
     assert d["value"] > 0 and d["n_gpus"] == 2 and "secondary_timed_out_in" in d
 
@@ -88,8 +113,8 @@ def test_multi_gpu_sections_on_real_rccl_at_world_1():
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
-    env = dict(os.environ, MASTER_PORT=str(port), MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+    env = dict(os.environ, MASTER_PORT=str(port), MASTER_ADDR="127.0.0.1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "HSA_ENABLE_IPC_MODE_LEGACY"):  # bench.py sets the IPC mode itself, before HIP starts
         env.pop(k, None)
     run = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *SMALL, "--rehearse-multi"], capture_output=True, text=True,
                          timeout=600, cwd=ROOT, env=env)
