@@ -124,7 +124,7 @@ combine_kernel(CombArgs a, int op, int flags, int n_in, int n_out, int64_t n_row
     // a workgroup takes a contiguous run of chunks, not every gridDim.x-th one: under the 65536-workgroup cap the grid stride is a
     // power of two (1 GiB for f64) and drifting workgroups alias onto the same HBM channels (atx_pointwise.hip, ATX_PW_ASSIGN)
 #ifndef ATX_COMB_ASSIGN
-#define ATX_COMB_ASSIGN 1
+#define ATX_COMB_ASSIGN 0
 #endif
 #if ATX_COMB_ASSIGN == 1
     const int64_t n_chunks = (total + kChunk - 1) / kChunk;

@@ -7,6 +7,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstring>
 
 #include "../../include/atx.h"
 
@@ -109,7 +110,12 @@ __device__ __forceinline__ LevelOp<T> load_level_op(const atx_level_op* prog, in
 
 // The reference statements, one rounding per numpy ufunc call (file compiled with
 // -ffp-contract=off so x*p0+p1 stays a multiply and an add).
-template <typename T>
+// TRANS = false: the instantiation for programs WITHOUT exp / log (the caller has checked the host copy of the program).  The
+// inlined float64 exp / log bodies cost every kernel that can reach them ~40 VGPRs — the chunked per-point kernel sat at 110
+// VGPRs = 4 waves per SIMD with them, on the edge of what hides HBM latency (its run time moved 2.34 <-> 2.65 ms from box to box
+// while the plain copy stayed at 2.34 ms, profiles/r03_pointwise_ab*.log) — and rescale / convert / orog_to_z / clip /
+// impute_nans / apply_mask never call them.
+template <typename T, bool TRANS = true>
 __device__ __forceinline__ T apply_level_op(const LevelOp<T>& o, T x, bool masked) {
     T y = x;
     switch (o.op) {
@@ -123,8 +129,12 @@ __device__ __forceinline__ T apply_level_op(const LevelOp<T>& o, T x, bool maske
             if (o.p1 == o.p1) y = (y > o.p1) ? o.p1 : y;
             break;
         case ATX_OP_IMPUTE_NAN: y = (x != x) ? o.p0 : x; break;
-        case ATX_OP_EXP: y = exp(x); break;
-        case ATX_OP_LOG: y = log(x); break;
+        case ATX_OP_EXP:
+            if constexpr (TRANS) y = exp(x);
+            break;
+        case ATX_OP_LOG:
+            if constexpr (TRANS) y = log(x);
+            break;
         case ATX_OP_SET_NAN: y = quiet_nan<T>(); break;
         default: break;
     }
@@ -136,7 +146,7 @@ __device__ __forceinline__ T apply_level_op(const LevelOp<T>& o, T x, bool maske
 // The same operator applied to a whole 16-byte vector: ONE dispatch on the operator instead of
 // one per element (the per-level programs of real pipelines are uniform over the levels a vector
 // spans almost always; kernels fall back to apply_level_op per element when they are not).
-template <typename T, int VEC>
+template <typename T, int VEC, bool TRANS = true>
 __device__ __forceinline__ void apply_level_op_vec(const LevelOp<T>& o, Pack<T, VEC>& v, bool masked) {
     switch (o.op) {
         case ATX_OP_COPY: break;
@@ -170,12 +180,16 @@ __device__ __forceinline__ void apply_level_op_vec(const LevelOp<T>& o, Pack<T, 
             for (int e = 0; e < VEC; ++e) v.v[e] = (v.v[e] != v.v[e]) ? o.p0 : v.v[e];
             break;
         case ATX_OP_EXP:
+            if constexpr (TRANS) {
 #pragma unroll
-            for (int e = 0; e < VEC; ++e) v.v[e] = exp(v.v[e]);
+                for (int e = 0; e < VEC; ++e) v.v[e] = exp(v.v[e]);
+            }
             break;
         case ATX_OP_LOG:
+            if constexpr (TRANS) {
 #pragma unroll
-            for (int e = 0; e < VEC; ++e) v.v[e] = log(v.v[e]);
+                for (int e = 0; e < VEC; ++e) v.v[e] = log(v.v[e]);
+            }
             break;
         case ATX_OP_SET_NAN:
 #pragma unroll
@@ -219,21 +233,79 @@ __device__ __forceinline__ void build_vector_ops(const atx_level_op* __restrict_
 
 // Apply all stages to one vector of column c: vector-uniform stages through ONE dispatch, mixed ones
 // per element straight from the global program (rare).
-template <typename T, int VEC>
+template <typename T, int VEC, bool TRANS = true>
 __device__ __forceinline__ void apply_program_vec(const LevelOp<T>* __restrict__ vec_ops, const atx_level_op* __restrict__ prog,
                                                   int n_stage, int n_lev, int C, int c, Pack<T, VEC>& v, bool masked) {
     for (int s = 0; s < n_stage; ++s) {
         const LevelOp<T> o = vec_ops[s * C + c];
         if (o.op != kOpMixed) {
-            apply_level_op_vec<T, VEC>(o, v, masked);
+            apply_level_op_vec<T, VEC, TRANS>(o, v, masked);
         } else {
 #pragma unroll
             for (int e = 0; e < VEC; ++e) {
                 const int l = c * VEC + e;
-                if (l < n_lev) v.v[e] = apply_level_op(load_level_op<T>(prog, (int64_t)s * n_lev + l), v.v[e], masked);
+                if (l < n_lev) v.v[e] = apply_level_op<T, TRANS>(load_level_op<T>(prog, (int64_t)s * n_lev + l), v.v[e], masked);
             }
         }
     }
+}
+
+// A per-level program whose operators can travel BY VALUE in the kernel arguments (scalar registers, scalar branch on the operator):
+// per stage the levels run ONE operator, or one operator up to a level that is a multiple of the vector width and another from
+// there on ("136 levels of t, then orog"), at most kMaxUniform stages.  Used by the fused regrid epilogue (atx_regrid.hip) and by
+// the per-point kernel (atx_pointwise.hip).
+constexpr int kMaxUniform = 4;
+template <typename T>
+struct UniformOps {
+    int n_stage;
+    int split[kMaxUniform];          // first vector column of the second piece of stage s (>= C: the stage has one piece)
+    LevelOp<T> stage[kMaxUniform];   // first piece
+    LevelOp<T> second[kMaxUniform];  // second piece
+};
+
+template <typename T>
+static inline bool uniform_level_program(const atx_level_op* host_prog, int n_stage, bool have_mask, int n_lev, int vec, UniformOps<T>& out) {
+    if (!host_prog || n_stage < 1 || n_stage > kMaxUniform) return false;
+    auto typed = [](const atx_level_op& o) {
+        LevelOp<T> r;
+        r.op = o.op;
+        r.use_mask = o.use_mask ? 1 : 0;
+        r.p0 = static_cast<T>(o.p0);
+        r.p1 = static_cast<T>(o.p1);
+        return r;
+    };
+    auto same = [](const LevelOp<T>& a, const LevelOp<T>& b) {
+        return a.op == b.op && a.use_mask == b.use_mask && std::memcmp(&a.p0, &b.p0, sizeof(T)) == 0 && std::memcmp(&a.p1, &b.p1, sizeof(T)) == 0;
+    };
+    const int C = (n_lev + vec - 1) / vec;
+    out.n_stage = n_stage;
+    for (int s = 0; s < kMaxUniform; ++s) out.split[s] = C;
+    for (int s = 0; s < n_stage; ++s) {
+        const atx_level_op* row = host_prog + (int64_t)s * n_lev;
+        const LevelOp<T> first = typed(row[0]);
+        int l = 1;
+        while (l < n_lev && same(typed(row[l]), first)) ++l;
+        out.stage[s] = out.second[s] = first;
+        if (l == n_lev) continue;  // one piece
+        if (l % vec != 0) return false;  // the change must fall on a vector boundary
+        const LevelOp<T> second = typed(row[l]);
+        for (int m = l + 1; m < n_lev; ++m)
+            if (!same(typed(row[m]), second)) return false;  // a third piece
+        out.second[s] = second;
+        out.split[s] = l / vec;
+    }
+    for (int s = 0; s < n_stage; ++s)
+        if ((out.stage[s].use_mask || out.second[s].use_mask) && !have_mask) return false;  // (rejected by validation anyway)
+    return true;
+}
+
+// Does a host copy of a program (n_stage * n_lev entries) hold an operator that needs the TRANS = true instantiation?  Without a
+// host copy the answer is "maybe".
+static inline bool program_has_transcendental(const atx_level_op* host_prog, int n_stage, int n_lev) {
+    if (!host_prog) return true;
+    for (int64_t i = 0; i < (int64_t)n_stage * n_lev; ++i)
+        if (host_prog[i].op == ATX_OP_EXP || host_prog[i].op == ATX_OP_LOG) return true;
+    return false;
 }
 
 }  // namespace atx

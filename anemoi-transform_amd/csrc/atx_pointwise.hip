@@ -57,6 +57,19 @@ __device__ __forceinline__ void pw_store(T* p, const Pack<T, N>& v) {
 #endif
 }
 
+// explicit non-temporal forms (whatever ATX_PW_NT says) for kernels that pick per launch
+template <typename T, int N>
+__device__ __forceinline__ Pack<T, N> pw_load_nt(const T* p) {
+    using NV = typename PwNative<T, N>::type;
+    NV v = __builtin_nontemporal_load(reinterpret_cast<const NV*>(p));
+    return *reinterpret_cast<Pack<T, N>*>(&v);
+}
+template <typename T, int N>
+__device__ __forceinline__ void pw_store_nt(T* p, const Pack<T, N>& v) {
+    using NV = typename PwNative<T, N>::type;
+    __builtin_nontemporal_store(*reinterpret_cast<const NV*>(&v), reinterpret_cast<NV*>(p));
+}
+
 template <typename T, int VEC>
 __global__ void __launch_bounds__(kBlock)
 pointwise_cols_kernel(const T* __restrict__ x, T* __restrict__ y, int64_t n_pts, int n_lev, int C,
@@ -112,7 +125,7 @@ pointwise_cols_kernel(const T* __restrict__ x, T* __restrict__ y, int64_t n_pts,
 // base is line aligned), so no line is shared between workgroups — the row-chunk kernel above fetched 4.4 % and wrote
 // 1.8 % more than the stack holds (boundary lines of its chunks, PMC counters in profiles/traffic.json) and idles
 // kBlock % C lanes.  A lane's column changes from pass to pass; its operators come from the LDS table either way.
-template <typename T, int VEC>
+template <typename T, int VEC, bool TRANS>
 __global__ void __launch_bounds__(kBlock)
 pointwise_cols_flat_kernel(const T* __restrict__ x, T* __restrict__ y, int64_t n_pts, int n_lev, int C,
                            const atx_level_op* __restrict__ prog, int n_stage,
@@ -142,7 +155,7 @@ pointwise_cols_flat_kernel(const T* __restrict__ x, T* __restrict__ y, int64_t n
     // binary measured 2.37 ms on one box and 2.63 ms on another for 137 float64 levels of O1280 while atx_stream_copy stayed at
     // 2.33 ms on both; profiles/r03_pointwise_ab.log, r03_pointwise_placement.log).
 #ifndef ATX_PW_ASSIGN
-#define ATX_PW_ASSIGN 1
+#define ATX_PW_ASSIGN 0
 #endif
 #if ATX_PW_ASSIGN == 1
     const int64_t n_chunks = (n_vec + kChunk - 1) / kChunk;
@@ -176,7 +189,7 @@ pointwise_cols_flat_kernel(const T* __restrict__ x, T* __restrict__ y, int64_t n
             if (!ok[u]) continue;
             if (act[u]) {
                 const bool masked = point_mask ? (point_mask[row[u]] != 0) : false;
-                apply_program_vec<T, VEC>(vec_ops, prog, n_stage, n_lev, C, col[u], v[u], masked);
+                apply_program_vec<T, VEC, TRANS>(vec_ops, prog, n_stage, n_lev, C, col[u], v[u], masked);
             }
             pw_store<T, VEC>(y + (base + u * kBlock + tid) * VEC, v[u]);
         }
@@ -235,6 +248,72 @@ pointwise_cols_table_kernel(const T* __restrict__ x, T* __restrict__ y, int64_t 
         }
     }
     pw_store<T, VEC>(y + vi * VEC, v);
+}
+
+// The same stacks when the program is UNIFORM over the levels (uniform_level_program: per stage one operator, or two pieces split
+// on a vector boundary — rescale / convert / orog_to_z / clip / impute_nans / apply_mask over a whole stack, or "136 levels of t and
+// one of orog"): the operators travel by value in the kernel arguments, so a lane's only memory traffic is its 16-byte vector (and
+// one mask byte when a stage uses the point mask) — the launch shape and the instruction stream of atx_stream_copy plus a scalar
+// branch per stage.  This is the shape whose speed does not move from box to box (atx_stream_copy: 2.33-2.35 ms for 137 float64
+// levels of O1280 on every box of round 3, the chunked kernel 2.34-2.68 ms).  NT: non-temporal loads AND stores — nothing this
+// kernel touches is touched again — measured 2.32 -> 2.22 ms f64 out of place, 2.43 -> 2.23 ms in place, f32 1.19 -> 1.13 and
+// 1.24 -> 1.12 ms (0.80-0.81 of the peak, above the plain copy); with a point mask they cost 2-6 % instead (the mask bytes, shared
+// by the ~35-69 lanes of a point, live in the same caches), so masked programs keep plain accesses; profiles/r03_pointwise_ab.log.
+template <typename T, int VEC, bool TRANS, int U, bool NT>
+__global__ void __launch_bounds__(kBlock)
+pointwise_cols_uniform_kernel(const T* __restrict__ x, T* __restrict__ y, int64_t n_vec, int C, UniformOps<T> u,
+                              const uint8_t* __restrict__ point_mask, int need_rc, int in_place, unsigned act_bits) {
+    using V = Pack<T, VEC>;
+    // U vectors per lane, kBlock apart: a workgroup covers kBlock * U consecutive vectors (no loop)
+    const int64_t base = (int64_t)blockIdx.x * (kBlock * U) + threadIdx.x;
+    V v[U];
+    int c[U];
+    bool masked[U], go[U];
+#pragma unroll
+    for (int k = 0; k < U; ++k) {
+        const int64_t vi = base + (int64_t)k * kBlock;
+        go[k] = vi < n_vec;
+        c[k] = 0;
+        masked[k] = false;
+        if (go[k] && need_rc) {  // uniform: a two-piece stage or the point mask — the lane needs its (row, vector column)
+            int64_t row;
+            if (n_vec <= 0xffffffffll) {
+                const unsigned r = (unsigned)vi / (unsigned)C;
+                row = r;
+                c[k] = (int)((unsigned)vi - r * (unsigned)C);
+            } else {
+                row = vi / C;
+                c[k] = (int)(vi - row * C);
+            }
+            if (in_place) {  // untouched columns of an in-place call: nothing to move.  `act_bits` (host-built): bit s = the first
+                // piece of stage s does something, bit 4 + s = its second piece.  (Selecting between u.stage[s].op and u.second[s].op
+                // here made the compiler select between their ADDRESSES and load per lane from the kernel-argument segment, two
+                // dependent loads per stage ahead of the data load: apply_mask in place 3.51 ms instead of 2.45.)
+                unsigned act = 0;
+#pragma unroll
+                for (int s = 0; s < kMaxUniform; ++s) act |= (c[k] >= u.split[s]) ? (act_bits >> (4 + s)) : (act_bits >> s);
+                go[k] = (act & 1u) != 0;
+            }
+            if (go[k] && point_mask) masked[k] = point_mask[row] != 0;
+        }
+        if (go[k]) v[k] = NT ? pw_load_nt<T, VEC>(x + vi * VEC) : pw_load<T, VEC>(x + vi * VEC);
+    }
+#pragma unroll
+    for (int k = 0; k < U; ++k) {
+        if (!go[k]) continue;
+        for (int s = 0; s < u.n_stage; ++s) {
+            if (u.split[s] >= C) {  // scalar condition: one piece
+                apply_level_op_vec<T, VEC, TRANS>(u.stage[s], v[k], masked[k]);
+            } else {
+                V other = v[k];
+                apply_level_op_vec<T, VEC, TRANS>(u.stage[s], v[k], masked[k]);
+                apply_level_op_vec<T, VEC, TRANS>(u.second[s], other, masked[k]);
+                if (c[k] >= u.split[s]) v[k] = other;
+            }
+        }
+        if (NT) pw_store_nt<T, VEC>(y + (base + (int64_t)k * kBlock) * VEC, v[k]);
+        else pw_store<T, VEC>(y + (base + (int64_t)k * kBlock) * VEC, v[k]);
+    }
 }
 
 // In place with FEW active levels (1 of 137: one variable of a stack converted, a mask applied to one field): only the
@@ -697,7 +776,50 @@ static int pointwise_typed(const void* x_, void* y_, int64_t n_pts, int n_lev, i
 #endif
         if (ATX_PW_FLAT && wide && xp == (int64_t)C * VEC && yp == xp) {  // one contiguous run of vectors: line-aligned chunks
             const int64_t n_vec = n_pts * C;
-            // measured (137 levels of O1280, profiles/r03_pointwise_ab.log): the table kernel (one vector per lane, no loop) wins for
+            // (1) programs uniform over the levels: operators by value, one vector per lane, no loop (pointwise_cols_uniform_kernel)
+#ifndef ATX_PW_UNIFORM
+#define ATX_PW_UNIFORM 1
+#endif
+            UniformOps<T> uni{};
+            if (ATX_PW_UNIFORM && (n_vec + kBlock - 1) / kBlock <= 0x7fffffffll && uniform_level_program<T>(host_prog, n_stage, mask != nullptr, n_lev, VEC, uni)) {
+                bool two_pieces = false, uses_mask = false;
+                unsigned act_bits = 0;
+                for (int s = 0; s < n_stage; ++s) {
+                    two_pieces = two_pieces || uni.split[s] < C;
+                    uses_mask = uses_mask || uni.stage[s].use_mask || uni.second[s].use_mask;
+                    if (uni.stage[s].op != ATX_OP_COPY || uni.stage[s].use_mask) act_bits |= 1u << s;
+                    if (uni.second[s].op != ATX_OP_COPY || uni.second[s].use_mask) act_bits |= 1u << (4 + s);
+                }
+                const int need_rc = (two_pieces || (uses_mask && mask)) ? 1 : 0;
+                const bool trans = program_has_transcendental(host_prog, n_stage, n_lev);
+#ifndef ATX_PW_UNIFORM_U_IN
+#define ATX_PW_UNIFORM_U_IN 1
+#endif
+#ifndef ATX_PW_UNIFORM_U_OUT
+#define ATX_PW_UNIFORM_U_OUT 1
+#endif
+#ifndef ATX_PW_UNIFORM_NT
+#define ATX_PW_UNIFORM_NT 1
+#endif
+#define ATX_PW_UNIFORM_LAUNCH(TR_, U_, NT_)                                                                                                \
+    hipLaunchKernelGGL((pointwise_cols_uniform_kernel<T, VEC, TR_, U_, NT_>), dim3((unsigned)((n_vec + kBlock * U_ - 1) / (kBlock * U_))), \
+                       dim3(kBlock), 0, st, x, y, n_vec, C, uni, uses_mask ? mask : nullptr, need_rc, in_place, act_bits)
+                const bool nt = ATX_PW_UNIFORM_NT && !(uses_mask && mask);
+                if (in_place) {
+                    if (trans) ATX_PW_UNIFORM_LAUNCH(true, ATX_PW_UNIFORM_U_IN, false);  // (exp / log: ALU time dominates)
+                    else if (nt) ATX_PW_UNIFORM_LAUNCH(false, ATX_PW_UNIFORM_U_IN, true);
+                    else ATX_PW_UNIFORM_LAUNCH(false, ATX_PW_UNIFORM_U_IN, false);
+                } else {
+                    if (trans) ATX_PW_UNIFORM_LAUNCH(true, ATX_PW_UNIFORM_U_OUT, false);
+                    else if (nt) ATX_PW_UNIFORM_LAUNCH(false, ATX_PW_UNIFORM_U_OUT, true);
+                    else ATX_PW_UNIFORM_LAUNCH(false, ATX_PW_UNIFORM_U_OUT, false);
+                }
+#undef ATX_PW_UNIFORM_LAUNCH
+                ATX_LAUNCH_CHECK("pointwise_stack_uniform");
+                return ATX_OK;
+            }
+            // (2) operators differing from level to level.  Measured (137 levels of O1280, profiles/r03_pointwise_ab.log): the table
+            // kernel (one vector per lane, no loop, operators from the host-built per-vector table) wins for
             // one-stage f32 programs without a mask, out of place (1.21 ms both) AND in place (1.22 vs 1.36 ms chunked); it loses in f64
             // (2.48 vs 2.37 ms), with two stages (f32 1.56 vs 1.28, f64 3.38 vs 2.58 ms: 24-32 B of operators per stage and vector) and
             // with a point mask in f64 (2.74 vs 2.43 ms).  ATX_PW_TABLE_RULE: 0 = round 2's rule (out of place only), 1 = this rule.
@@ -717,8 +839,12 @@ static int pointwise_typed(const void* x_, void* y_, int64_t n_pts, int n_lev, i
             const int64_t per = (n_chunks + blocks - 1) / blocks;
             blocks = (n_chunks + per - 1) / per;  // contiguous runs of `per` chunks: no workgroup without work
             const size_t lds_flat = lds + (size_t)C;
-            hipLaunchKernelGGL((pointwise_cols_flat_kernel<T, VEC>), dim3((unsigned)blocks), dim3(kBlock), lds_flat, st, x, y, n_pts, n_lev,
-                               C, prog, n_stage, mask, in_place);
+            if (program_has_transcendental(host_prog, n_stage, n_lev))
+                hipLaunchKernelGGL((pointwise_cols_flat_kernel<T, VEC, true>), dim3((unsigned)blocks), dim3(kBlock), lds_flat, st, x, y, n_pts, n_lev,
+                                   C, prog, n_stage, mask, in_place);
+            else  // no exp / log anywhere in the program: the low-register instantiation (8 instead of 4 waves per SIMD in float64)
+                hipLaunchKernelGGL((pointwise_cols_flat_kernel<T, VEC, false>), dim3((unsigned)blocks), dim3(kBlock), lds_flat, st, x, y, n_pts, n_lev,
+                                   C, prog, n_stage, mask, in_place);
             ATX_LAUNCH_CHECK("pointwise_stack");
             return ATX_OK;
         }

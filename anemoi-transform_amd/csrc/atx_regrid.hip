@@ -278,7 +278,6 @@ regrid_cols_ell_kernel(EllBatch batch,
 // Everything else (clip / impute / exp / log / divisions, more stages) stays on the tiled kernel: its general operator switch
 // costs registers (f64: 88 VGPRs, 5 waves per SIMD instead of 8) and time the gather cannot hide (profiles/r02_ab_epilogue_routes.log).
 constexpr int kEpiNone = 0, kEpiUniform = 1, kEpiTable = 2;
-constexpr int kMaxUniform = 4;
 constexpr int kMaxTable = 4;
 
 // COPY / AFFINE / MUL (+ mask) on one element, branch-free; bit-identical to apply_level_op for these operators.
@@ -289,13 +288,6 @@ __device__ __forceinline__ T apply_madd_family(const LevelOp<T>& o, T x, bool ma
     T y = o.op == ATX_OP_AFFINE ? a : (o.op == ATX_OP_MUL ? m : x);
     return (o.use_mask && masked) ? quiet_nan<T>() : y;
 }
-template <typename T>
-struct UniformOps {
-    int n_stage;
-    int split[kMaxUniform];          // first vector column of the second piece of stage s (>= C: the stage has one piece)
-    LevelOp<T> stage[kMaxUniform];   // first piece
-    LevelOp<T> second[kMaxUniform];  // second piece
-};
 
 template <typename T, int VEC, int K, bool WEIGHTED, bool PAD, int EPI>
 __global__ void __launch_bounds__(kEllBlock)
@@ -624,41 +616,10 @@ static bool madd_family_program(const Epilogue& e, int n_lev) {
 }
 
 // Per stage the levels run one operator, or one up to a level that is a multiple of `vec` and another from there on
-// (<= kMaxUniform stages): the operators can travel by value.
+// (<= kMaxUniform stages): the operators can travel by value (atx_common.hpp: uniform_level_program).
 template <typename T>
 static bool uniform_program(const Epilogue& e, int n_lev, int vec, UniformOps<T>& out) {
-    if (!e.host_prog || e.n_stage < 1 || e.n_stage > kMaxUniform) return false;
-    auto typed = [](const atx_level_op& o) {
-        LevelOp<T> r;
-        r.op = o.op;
-        r.use_mask = o.use_mask ? 1 : 0;
-        r.p0 = static_cast<T>(o.p0);
-        r.p1 = static_cast<T>(o.p1);
-        return r;
-    };
-    auto same = [](const LevelOp<T>& a, const LevelOp<T>& b) {
-        return a.op == b.op && a.use_mask == b.use_mask && std::memcmp(&a.p0, &b.p0, sizeof(T)) == 0 && std::memcmp(&a.p1, &b.p1, sizeof(T)) == 0;
-    };
-    const int C = (n_lev + vec - 1) / vec;
-    out.n_stage = e.n_stage;
-    for (int s = 0; s < kMaxUniform; ++s) out.split[s] = C;
-    for (int s = 0; s < e.n_stage; ++s) {
-        const atx_level_op* row = e.host_prog + (int64_t)s * n_lev;
-        const LevelOp<T> first = typed(row[0]);
-        int l = 1;
-        while (l < n_lev && same(typed(row[l]), first)) ++l;
-        out.stage[s] = out.second[s] = first;
-        if (l == n_lev) continue;  // one piece
-        if (l % vec != 0) return false;  // the change must fall on a vector boundary
-        const LevelOp<T> second = typed(row[l]);
-        for (int m = l + 1; m < n_lev; ++m)
-            if (!same(typed(row[m]), second)) return false;  // a third piece
-        out.second[s] = second;
-        out.split[s] = l / vec;
-    }
-    for (int s = 0; s < e.n_stage; ++s)
-        if ((out.stage[s].use_mask || out.second[s].use_mask) && !e.mask) return false;  // (rejected by validation anyway)
-    return true;
+    return uniform_level_program<T>(e.host_prog, e.n_stage, e.mask != nullptr, n_lev, vec, out);
 }
 
 template <typename T, int VEC, int K, bool WEIGHTED, bool PAD = false>

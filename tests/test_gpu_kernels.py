@@ -336,6 +336,73 @@ def test_pointwise_ops_bit_exact(dev, tdtype, np_dtype, layout, in_place):
 
 
 @pytest.mark.parametrize("tdtype,np_dtype", DTYPES)
+@pytest.mark.parametrize("in_place", [False, True])
+@pytest.mark.parametrize("program", ["uniform_1", "uniform_4", "uniform_5", "two_pieces", "two_pieces_one_idle", "masked_uniform", "masked_piece",
+                                     "transcendental", "per_level"])
+def test_pointwise_kernel_routes_agree(dev, tdtype, np_dtype, in_place, program):
+    """The per-point launch takes one of three kernels on a tight column stack — operators by value (programs uniform over the
+    levels, or two pieces split on a 16-byte boundary; needs the program's host copy), the per-vector table, the chunked kernel —
+    and all three must give the oracle's values and each other's bits.  n_lev = 24: vectors of 4 (f32) and 2 (f64) levels."""
+    import native_double
+
+    rng = np.random.default_rng(23)
+    n_lev, n_pts = 24, 5003
+    x = make_fields(rng, n_lev, n_pts, np_dtype, nan_frac=0.02)
+    x[:4] = np.abs(x[:4]) + 1.0  # log inputs
+    mul, aff, cp = (native.OP_MUL, 0, oracle.G, 0.0), (native.OP_AFFINE, 0, 1.0, -273.15), (native.OP_COPY, 0, 0.0, 0.0)
+    clip, inv, imp = (native.OP_CLIP, 0, -20.0, 40.0), (native.OP_AFFINE_INV, 0, 2.0, 1.0), (native.OP_IMPUTE_NAN, 0, -9.0, 0.0)
+    msk = (native.OP_COPY, 1, 0.0, 0.0)
+    if program == "uniform_1":
+        stages = [[aff] * n_lev]
+    elif program == "uniform_4":  # the most stages that travel by value
+        stages = [[mul] * n_lev, [aff] * n_lev, [clip] * n_lev, [imp] * n_lev]
+    elif program == "uniform_5":  # one stage more: chunked kernel whatever the companions
+        stages = [[mul] * n_lev, [aff] * n_lev, [clip] * n_lev, [imp] * n_lev, [inv] * n_lev]
+    elif program == "two_pieces":
+        stages = [[aff if l < 8 else mul for l in range(n_lev)], [clip if l < 16 else inv for l in range(n_lev)]]
+    elif program == "two_pieces_one_idle":  # in place the idle piece must not be touched (and out of place it must be copied)
+        stages = [[cp if l < 12 else aff for l in range(n_lev)], [cp if l < 12 else (native.OP_DIV, 0, 3.0, 0.0) for l in range(n_lev)]]
+    elif program == "masked_uniform":
+        stages = [[aff] * n_lev, [msk] * n_lev]
+    elif program == "masked_piece":  # the mask on the second piece only
+        stages = [[cp if l < 8 else msk for l in range(n_lev)]]
+    elif program == "transcendental":
+        stages = [[(native.OP_LOG, 0, 0.0, 0.0) if l < 4 else aff for l in range(n_lev)], [(native.OP_EXP, 0, 0.0, 0.0) if l < 4 else cp for l in range(n_lev)]]
+    else:  # operators differ inside a vector
+        stages = [[aff if l % 3 else mul for l in range(n_lev)]]
+    pmask = rng.random(n_pts) < 0.3
+    uses_mask = any(e[1] for st in stages for e in st)
+    pm_d = to_dev(pmask.astype(np.uint8), dev) if uses_mask else None
+
+    def run(strip):
+        prog = native.level_program(stages, dev)
+        for name in strip:
+            if name == "vec_prog":
+                prog.vec_prog = {}
+            else:
+                prog.host_prog = None
+        src = Stack.from_fields(x, dev=dev)
+        out = src if in_place else src.new_like()
+        native.pointwise_stack(src.data, out.data, n_pts=n_pts, n_lev=n_lev, x_pitch=src.pitch, y_pitch=out.pitch, layout=COLUMNS, prog=prog,
+                               n_stage=len(stages), point_mask=pm_d)
+        return out.numpy()
+
+    by_value, table, chunked = run(()), run(("host_prog",)), run(("host_prog", "vec_prog"))
+    want = x.copy()
+    for stage in stages:
+        for l, (op, use_mask, p0, p1) in enumerate(stage):
+            entry = np.zeros((), dtype=native.LEVEL_OP_DTYPE)
+            entry["op"], entry["use_mask"], entry["p0"], entry["p1"] = op, use_mask, p0, p1
+            want[l] = native_double._apply_op(entry, want[l], pmask if use_mask else None)
+    for got in (by_value, table, chunked):
+        if program == "transcendental":  # ocml vs libm: a few ulp per call, and exp(log(x)) chains two of them
+            np.testing.assert_allclose(got, want, rtol=4 * RTOL_F32 if np_dtype == np.float32 else 1e-14, equal_nan=True)
+        else:
+            assert np.array_equal(got, want, equal_nan=True)
+    assert np.array_equal(by_value, chunked, equal_nan=True) and np.array_equal(table, chunked, equal_nan=True)
+
+
+@pytest.mark.parametrize("tdtype,np_dtype", DTYPES)
 @pytest.mark.parametrize("selected", [[5], [0, 77, 136], [3, 4, 5, 6, 7, 8], list(range(0, 137, 7)), list(range(0, 137, 2))])
 def test_pointwise_in_place_with_few_active_levels(dev, tdtype, np_dtype, selected):
     """In place, a program that leaves most levels alone visits only the columns of the active ones (sparse kernel: up to 16
