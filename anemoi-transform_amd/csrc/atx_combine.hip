@@ -15,11 +15,14 @@ struct CombArgs {
 };
 
 // g = 9.80665 (R: constants.py:13, value pinned by filters/tabular/geopotential_to_height.py:51)
-template <typename T>
-__device__ __forceinline__ void combine_one(int op, int flags, const T* x, int n_in, T level, T& y0, T& y1) {
+// OP is a template parameter: every operator gets its own kernel.  With a runtime switch the float64 kernels carried the
+// inlined tanh, sincos and atan2 bodies for EVERY operator — 164-180 VGPRs, 2-3 waves per SIMD, even for `a - b` (round 2 called
+// the result "ALU-bound"; it was occupancy).
+template <typename T, int OP>
+__device__ __forceinline__ void combine_one(int flags, const T* x, int n_in, T level, T& y0, T& y1) {
     const T g = T(9.80665);
     y1 = T(0);
-    switch (op) {
+    switch (OP) {
         case ATX_COMB_SNOW_DEPTH_M: y0 = T(1000.0) * x[0] / x[1]; break;
         case ATX_COMB_SNOW_COVER: {
             const T tmp1 = (T(1000) * x[0]) / x[1];
@@ -84,17 +87,15 @@ __device__ __forceinline__ void combine_one(int op, int flags, const T* x, int n
 
 // The stacks are contiguous runs of vectors (pitch is a multiple of the vector): a workgroup sweeps line-aligned chunks
 // of kBlock * U vectors, U independent loads per operand and lane in flight (comb_unroll below; the n-ary sum keeps one:
-// 8 operands x 4 vectors would not fit the register file).  Non-temporal stores measured no better.
+// 8 operands x 4 vectors would not fit the register file).
 // Vectors per lane in flight and grid shape, measured on 137-level O1280 stacks (profiles/r01_kernel_bench.log):
 //   f32: 2 vectors per lane, one workgroup per chunk, no grid cap — difference 2->1 1.81 ms (4 per lane under a 65536-workgroup
 //        cap: 2.11 ms; 1 per lane uncapped: 1.78 ms but cos+sin 1->2 slower), snow_cover 2.66 -> 2.17 ms;
 //   f64: 4 vectors per lane under the 65536-workgroup cap — difference 3.63 ms (uncapped 1 / 2 per lane: 4.30 / 3.60 ms, the
 //        transcendental operators lose 10 % uncapped).
 #ifndef ATX_COMB_NT
-#define ATX_COMB_NT 0
+#define ATX_COMB_NT 1  // round 3: non-temporal stores AND loads (ATX_COMB_NT_LOAD) — nothing is touched twice; profiles/r03_combine_ab.log
 #endif
-constexpr int comb_unroll(int nin, int elem_bytes) { return nin > 3 ? 1 : (elem_bytes == 4 ? 2 : 4); }
-constexpr int64_t comb_grid_cap(int elem_bytes) { return elem_bytes == 4 ? 0x7fffffffll : kStreamGrid; }
 
 template <typename T, int N>
 __device__ __forceinline__ void comb_store(T* p, const Pack<T, N>& v) {
@@ -110,16 +111,48 @@ __device__ __forceinline__ void comb_store(T* p, const Pack<T, 1>& v) {
     *p = v.v[0];
 }
 
+// Launch shape knobs (A/B builds; tools/experiments/combine_ab.py): vectors per lane for 4- and 8-byte elements, the workgroup cap
+// for 8-byte elements (0 = none: one workgroup per chunk), non-temporal loads.
+#ifndef ATX_COMB_U_F32
+#define ATX_COMB_U_F32 2
+#endif
+// round 3: 2 per lane and NO cap for float64 too (was 4 under a 65536-workgroup cap): the no-loop shape runs the same on every
+// box, the capped sweep moved 3.46 <-> 3.82 ms (difference 2 -> 1) between two boxes of one afternoon
+#ifndef ATX_COMB_U_F64
+#define ATX_COMB_U_F64 2
+#endif
+#ifndef ATX_COMB_CAP_F64
+#define ATX_COMB_CAP_F64 0
+#endif
+#ifndef ATX_COMB_NT_LOAD
+#define ATX_COMB_NT_LOAD 1
+#endif
+constexpr int comb_unroll(int nin, int elem_bytes, int op) { return nin > 3 ? 1 : (elem_bytes == 4 ? ATX_COMB_U_F32 : ATX_COMB_U_F64); }
+constexpr int64_t comb_grid_cap(int elem_bytes, int op) { return (elem_bytes == 4 || ATX_COMB_CAP_F64 == 0) ? 0x7fffffffll : (int64_t)ATX_COMB_CAP_F64; }
+
+template <typename T, int N>
+__device__ __forceinline__ Pack<T, N> comb_load(const T* p) {
+#if ATX_COMB_NT_LOAD
+    if constexpr (N > 1) {
+        typedef T NV __attribute__((ext_vector_type(N)));
+        NV v = __builtin_nontemporal_load(reinterpret_cast<const NV*>(p));
+        return *reinterpret_cast<Pack<T, N>*>(&v);
+    }
+#endif
+    return *reinterpret_cast<const Pack<T, N>*>(p);
+}
+
 // NIN: compile-time bound of the operand count (1, 2, 3 or ATX_COMB_MAX_INPUTS) so the operand registers are exactly as many as needed
-template <typename T, int VEC, int NIN>
+template <typename T, int VEC, int NIN, int OP>
 __global__ void __launch_bounds__(kBlock)
-combine_kernel(CombArgs a, int op, int flags, int n_in, int n_out, int64_t n_rows, int64_t row_len, int64_t pitch,
+combine_kernel(CombArgs a, int flags, int n_in, int n_out, int64_t n_rows, int64_t row_len, int64_t pitch,
                int layout, int n_lev, const double* __restrict__ level_param) {
     using V = Pack<T, VEC>;
     const int vec_per_row = (int)(pitch / VEC);  // pitch % VEC == 0 on this path (else VEC == 1)
     const int64_t total = n_rows * vec_per_row;
-    constexpr int U = comb_unroll(NIN, (int)sizeof(T));
+    constexpr int U = comb_unroll(NIN, (int)sizeof(T), OP);
     constexpr int64_t kChunk = (int64_t)kBlock * U;
+    constexpr bool kLevels = OP == ATX_COMB_W_TO_WZ || OP == ATX_COMB_WZ_TO_W;  // the only operators that read level_param
     const bool small_rows = vec_per_row < (1 << 20);  // columns layout: (row, col) from 32-bit arithmetic
     // a workgroup takes a contiguous run of chunks, not every gridDim.x-th one: under the 65536-workgroup cap the grid stride is a
     // power of two (1 GiB for f64) and drifting workgroups alias onto the same HBM channels (atx_pointwise.hip, ATX_PW_ASSIGN)
@@ -146,7 +179,7 @@ combine_kernel(CombArgs a, int op, int flags, int n_in, int n_out, int64_t n_row
             ok[u] = vi[u] < total;
 #pragma unroll
             for (int k = 0; k < NIN; ++k)
-                if (k < n_in && ok[u]) x[u][k] = *reinterpret_cast<const V*>(static_cast<const T*>(a.in[k]) + vi[u] * VEC);
+                if (k < n_in && ok[u]) x[u][k] = comb_load<T, VEC>(static_cast<const T*>(a.in[k]) + vi[u] * VEC);
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -167,12 +200,14 @@ combine_kernel(CombArgs a, int op, int flags, int n_in, int n_out, int64_t n_row
                 T xe[ATX_COMB_MAX_INPUTS];
 #pragma unroll
                 for (int k = 0; k < ATX_COMB_MAX_INPUTS; ++k) xe[k] = (k < NIN && k < n_in) ? x[u][k < NIN ? k : 0].v[e] : T(0);
-                const int64_t level = layout == ATX_COLUMNS ? col + e : row;
                 const bool live = (col + e) < row_len;
                 T lv = T(0);
-                if (level_param && level < n_lev) lv = static_cast<T>(level_param[level]);
+                if constexpr (kLevels) {
+                    const int64_t level = layout == ATX_COLUMNS ? col + e : row;
+                    if (level_param && level < n_lev) lv = static_cast<T>(level_param[level]);
+                }
                 T r0, r1;
-                combine_one<T>(op, flags, xe, n_in, lv, r0, r1);
+                combine_one<T, OP>(flags, xe, n_in, lv, r0, r1);
                 y0.v[e] = live ? r0 : T(0);  // padding stays zero
                 y1.v[e] = live ? r1 : T(0);
             }
@@ -191,27 +226,41 @@ static int combine_typed(const CombArgs& a, int op, int flags, int n_in, int n_o
     for (int k = 0; k < n_out; ++k) vec_ok = vec_ok && aligned16(a.out[k]);
     const int64_t n_rows = layout == ATX_COLUMNS ? n_pts : n_lev;
     const int64_t row_len = layout == ATX_COLUMNS ? n_lev : n_pts;
-    const int per_block = kBlock * comb_unroll(n_in <= 3 ? n_in : ATX_COMB_MAX_INPUTS, (int)sizeof(T));
+    const int per_block = kBlock * comb_unroll(n_in <= 3 ? n_in : ATX_COMB_MAX_INPUTS, (int)sizeof(T), op);
     int64_t blocks = (n_rows * (pitch / (vec_ok ? VEC : 1)) + per_block - 1) / per_block;
-    if (blocks > comb_grid_cap((int)sizeof(T))) {
-        const int64_t n_chunks = blocks, per = (n_chunks + comb_grid_cap((int)sizeof(T)) - 1) / comb_grid_cap((int)sizeof(T));
-        blocks = (n_chunks + per - 1) / per;  // contiguous runs of `per` chunks per workgroup, none without work
-    }
+    if (blocks > comb_grid_cap((int)sizeof(T), op)) blocks = comb_grid_cap((int)sizeof(T), op);
     if (blocks < 1) blocks = 1;
-#define ATX_COMB_LAUNCH(V_, N_)                                                                                              \
-    hipLaunchKernelGGL((combine_kernel<T, V_, N_>), dim3((unsigned)blocks), dim3(kBlock), 0, st, a, op, flags, n_in, n_out, n_rows, \
+#define ATX_COMB_LAUNCH(V_, N_, OP_)                                                                                            \
+    hipLaunchKernelGGL((combine_kernel<T, V_, N_, OP_>), dim3((unsigned)blocks), dim3(kBlock), 0, st, a, flags, n_in, n_out, n_rows, \
                        row_len, pitch, layout, n_lev, level_param)
-    if (vec_ok) {
-        if (n_in <= 1) ATX_COMB_LAUNCH(VEC, 1);
-        else if (n_in == 2) ATX_COMB_LAUNCH(VEC, 2);
-        else if (n_in == 3) ATX_COMB_LAUNCH(VEC, 3);
-        else ATX_COMB_LAUNCH(VEC, ATX_COMB_MAX_INPUTS);
-    } else {
-        if (n_in <= 1) ATX_COMB_LAUNCH(1, 1);
-        else if (n_in == 2) ATX_COMB_LAUNCH(1, 2);
-        else if (n_in == 3) ATX_COMB_LAUNCH(1, 3);
-        else ATX_COMB_LAUNCH(1, ATX_COMB_MAX_INPUTS);
+#define ATX_COMB_CASE(OP_, N_)                 \
+    case OP_:                                  \
+        if (vec_ok) ATX_COMB_LAUNCH(VEC, N_, OP_); \
+        else ATX_COMB_LAUNCH(1, N_, OP_);      \
+        break
+    switch (op) {  // the operand count of every operator but the n-ary sum is fixed (validated by the caller)
+        ATX_COMB_CASE(ATX_COMB_SNOW_DEPTH_M, 2);
+        ATX_COMB_CASE(ATX_COMB_SNOW_COVER, 2);
+        ATX_COMB_CASE(ATX_COMB_COS_SIN, 1);
+        ATX_COMB_CASE(ATX_COMB_ATAN2, 2);
+        ATX_COMB_CASE(ATX_COMB_W_TO_WZ, 3);
+        ATX_COMB_CASE(ATX_COMB_WZ_TO_W, 3);
+        ATX_COMB_CASE(ATX_COMB_SUB, 2);
+        default:  // ATX_COMB_SUM
+            if (vec_ok) {
+                if (n_in <= 1) ATX_COMB_LAUNCH(VEC, 1, ATX_COMB_SUM);
+                else if (n_in == 2) ATX_COMB_LAUNCH(VEC, 2, ATX_COMB_SUM);
+                else if (n_in == 3) ATX_COMB_LAUNCH(VEC, 3, ATX_COMB_SUM);
+                else ATX_COMB_LAUNCH(VEC, ATX_COMB_MAX_INPUTS, ATX_COMB_SUM);
+            } else {
+                if (n_in <= 1) ATX_COMB_LAUNCH(1, 1, ATX_COMB_SUM);
+                else if (n_in == 2) ATX_COMB_LAUNCH(1, 2, ATX_COMB_SUM);
+                else if (n_in == 3) ATX_COMB_LAUNCH(1, 3, ATX_COMB_SUM);
+                else ATX_COMB_LAUNCH(1, ATX_COMB_MAX_INPUTS, ATX_COMB_SUM);
+            }
+            break;
     }
+#undef ATX_COMB_CASE
 #undef ATX_COMB_LAUNCH
     ATX_LAUNCH_CHECK("combine_stack");
     return ATX_OK;

@@ -513,6 +513,15 @@ def test_reduce(dev, tdtype, np_dtype):
         yd = to_dev(y, dev)[shift:]
         assert native.reduce(yd, native.RED_MINMAX) == (float(y[shift:].min()), float(y[shift:].max())), (n, shift)
         assert native.reduce(yd, native.RED_MIN) == float(y[shift:].min()) and native.reduce(yd, native.RED_NANCOUNT) == 0.0
+    # the <= 3 elements after the last whole vector of a flat array go through the scalar kernel (nothing is read past x[n)): the
+    # extremes and a NaN placed exactly there must be seen
+    for n in (5, 7, 1027, 100003):
+        y = make_fields(rng, 1, n, np_dtype)[0]
+        y[-1], y[-2] = 1e6, -1e6
+        assert native.reduce(to_dev(y, dev), native.RED_MINMAX) == (-1e6, 1e6), n
+        y[-1] = np.nan
+        yd = to_dev(y, dev)
+        assert all(np.isnan(v) for v in native.reduce(yd, native.RED_MINMAX)) and native.reduce(yd, native.RED_NANCOUNT) == 1.0, n
     for layout in LAYOUTS:
         for n_lev, n_pts, pad in ((1, 50, 0), (3, 1001, 1), (137, 997, 3), (13, 4099, 4), (140, 513, 0)):
             z = make_fields(rng, n_lev, n_pts, np_dtype)
