@@ -17,6 +17,16 @@ if not os.path.exists(graft.LIB):  # fresh checkout: build libatx.so (hipcc cros
     graft.build()
 graft.load_package()
 
+# the k-NN table files of interp.py go to a directory of this test session, not to the user's cache
+import atexit  # noqa: E402
+import shutil  # noqa: E402
+import tempfile  # noqa: E402
+
+if "ATX_CACHE_DIR" not in os.environ:
+    _cache = tempfile.mkdtemp(prefix="atx-test-cache-")
+    os.environ["ATX_CACHE_DIR"] = _cache
+    atexit.register(shutil.rmtree, _cache, True)
+
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")

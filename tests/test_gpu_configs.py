@@ -114,7 +114,7 @@ def test_config5_chained_filters_on_o2560(dev):
     src, tgt = lookup("o2560"), lookup("0.25")
     n_src, n_tgt, n_lev = len(src["latitudes"]), len(tgt["latitudes"]), 137
     assert n_src == 26306560
-    idx, w = interp.knn_inverse_distance(src, tgt, k=4, device=True, ties="index")  # cKDTree needs ~1 min here; the device build < 2 s
+    idx, w = interp.knn_inverse_distance(src, tgt, k=4, device=True)  # the table cKDTree would build (tools/knn_table_parity.py shows it row by row); cKDTree alone needs ~1 min here
     plan = GatherPlan(n_src, n_tgt, index=idx, weights=w)
     x = synth(src, n_lev, dev, 5)
     # levels 0..135: temperature -> degC; level 136: orography -> geopotential -> (no convert)
