@@ -586,7 +586,10 @@ __global__ void reduce_init_kernel(double* result, int red) {
 // One partial per lane over a grid-stride sweep (4 independent loads in flight), 64-lane shuffle, one LDS combine per
 // workgroup, ONE atomic per workgroup (a per-wave atomic on a single address serialised 100 k of them on large inputs).
 constexpr int kRedUnroll = 4;
-constexpr int64_t kRedGrid = 8192;
+#ifndef ATX_RED_GRID
+#define ATX_RED_GRID 8192
+#endif
+constexpr int64_t kRedGrid = ATX_RED_GRID;
 
 __device__ __forceinline__ double red_combine(double a, double b, int red) {
     if (red == ATX_RED_NANCOUNT) return a + b;
@@ -595,9 +598,60 @@ __device__ __forceinline__ double red_combine(double a, double b, int red) {
     return b > a ? b : a;
 }
 
+// Two-level finish WITHOUT one atomic per workgroup on the result (a CAS loop on one address: 1 600 workgroups over one 26 MB
+// field spent 10 us of a 43 us call in it, min AND max 57 us; the 8 192 workgroups of a 137-level stack more).  With a caller-provided
+// workspace every workgroup stores its partial(s), takes a ticket, and the LAST one to arrive combines all partials, writes
+// `result` with a plain store — `result` may then be a pinned HOST cell: no init launch, no copy back — and leaves the ticket at 0
+// for the next call on the stream.  Layout: [0] ticket (zeroed once by the caller), [8 ..] partial_a[kRedGrid], partial_b[kRedGrid].
+struct RedWorkspace {
+    unsigned long long ticket;
+    double a[kRedGrid];
+    double b[kRedGrid];
+};
+
+__device__ __forceinline__ void reduce_finish(RedWorkspace* ws, double ta, double tb, int ra, int red, double* result) {
+    __shared__ bool last;
+    __shared__ double fa[kBlock / kWave], fb[kBlock / kWave];
+    if (threadIdx.x == 0) {
+        __hip_atomic_store(&ws->a[blockIdx.x], ta, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&ws->b[blockIdx.x], tb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned long long t = __hip_atomic_fetch_add(&ws->ticket, 1ull, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        last = t == (unsigned long long)gridDim.x - 1;
+    }
+    __syncthreads();
+    if (!last) return;
+    const double id_a = ra == ATX_RED_MIN ? INFINITY : (ra == ATX_RED_MAX ? -INFINITY : 0.0);
+    double a = id_a, b = -INFINITY;
+    for (unsigned i = threadIdx.x; i < gridDim.x; i += kBlock) {
+        a = red_combine(a, __hip_atomic_load(&ws->a[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), ra);
+        if (red == ATX_RED_MINMAX) b = red_combine(b, __hip_atomic_load(&ws->b[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), ATX_RED_MAX);
+    }
+#pragma unroll
+    for (int off = kWave / 2; off > 0; off >>= 1) {
+        a = red_combine(a, __shfl_down(a, off, kWave), ra);
+        if (red == ATX_RED_MINMAX) b = red_combine(b, __shfl_down(b, off, kWave), ATX_RED_MAX);
+    }
+    if ((threadIdx.x & (kWave - 1)) == 0) {
+        fa[threadIdx.x / kWave] = a;
+        fb[threadIdx.x / kWave] = b;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double xa = fa[0], xb = fb[0];
+        for (int w = 1; w < kBlock / kWave; ++w) {
+            xa = red_combine(xa, fa[w], ra);
+            xb = red_combine(xb, fb[w], ATX_RED_MAX);
+        }
+        result[0] = xa;
+        if (red == ATX_RED_MINMAX) result[1] = xb;
+        __hip_atomic_store(&ws->ticket, 0ull, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        __threadfence_system();  // `result` may live in pinned host memory
+    }
+}
+
 template <typename T>
 __global__ void __launch_bounds__(kBlock)
-reduce_kernel(const T* __restrict__ x, int64_t n_rows, int64_t row_len, int64_t pitch, int red, double* result) {
+reduce_kernel(const T* __restrict__ x, int64_t n_rows, int64_t row_len, int64_t pitch, int red, double* result, RedWorkspace* ws) {
     const double identity = red == ATX_RED_MIN ? INFINITY : (red == ATX_RED_MAX ? -INFINITY : 0.0);
     double acc = identity;
     // rows of `row_len` elements `pitch` apart; (row, col) advances by the grid stride without a division per element
@@ -634,11 +688,17 @@ reduce_kernel(const T* __restrict__ x, int64_t n_rows, int64_t row_len, int64_t 
     if (threadIdx.x == 0) {
         double total = partial[0];
         for (int w = 1; w < kBlock / kWave; ++w) total = red_combine(total, partial[w], red);
-        if (red == ATX_RED_NANCOUNT) {
+        if (ws) {
+            partial[0] = total;
+        } else if (red == ATX_RED_NANCOUNT) {
             if (total != 0.0) atomicAdd(result, total);
         } else {
             atomic_minmax(result, total, red == ATX_RED_MAX);
         }
+    }
+    if (ws) {  // uniform
+        __syncthreads();
+        reduce_finish(ws, partial[0], -INFINITY, red, red, result);
     }
 }
 
@@ -647,7 +707,7 @@ reduce_kernel(const T* __restrict__ x, int64_t n_rows, int64_t row_len, int64_t 
 // `data.min()` then `data.max()`) read the stack twice at 4.7 TB/s (4-byte loads); this reads it once.
 template <typename T, int VEC>
 __global__ void __launch_bounds__(kBlock)
-reduce_vec_kernel(const T* __restrict__ x, int64_t n_rows, int64_t row_len, int C, int64_t pitch, int red, double* result) {
+reduce_vec_kernel(const T* __restrict__ x, int64_t n_rows, int64_t row_len, int C, int64_t pitch, int red, double* result, RedWorkspace* ws) {
     using V = Pack<T, VEC>;
     const bool want_min = red == ATX_RED_MIN || red == ATX_RED_MINMAX, want_max = red == ATX_RED_MAX || red == ATX_RED_MINMAX;
     double lo = INFINITY, hi = -INFINITY, count = 0.0;
@@ -710,12 +770,19 @@ reduce_vec_kernel(const T* __restrict__ x, int64_t n_rows, int64_t row_len, int 
             ta = red_combine(ta, pa[w], ra);
             tb = red_combine(tb, pb[w], ATX_RED_MAX);
         }
-        if (red == ATX_RED_NANCOUNT) {
+        if (ws) {
+            pa[0] = ta;
+            pb[0] = tb;
+        } else if (red == ATX_RED_NANCOUNT) {
             if (ta != 0.0) atomicAdd(result, ta);
         } else {
             atomic_minmax(result, ta, !want_min);
             if (red == ATX_RED_MINMAX) atomic_minmax(result + 1, tb, true);
         }
+    }
+    if (ws) {  // uniform
+        __syncthreads();
+        reduce_finish(ws, pa[0], pb[0], ra, red, result);
     }
     (void)want_max;
 }
@@ -957,16 +1024,16 @@ extern "C" int atx_mask_to_index(const uint8_t* mask, int64_t n, int32_t* index,
 }
 
 static int reduce_rows(const void* x, int64_t n_rows, int64_t row_len, int64_t pitch, int red, double* result, int dtype,
-                       void* stream, const char* who) {
+                       void* workspace, size_t workspace_bytes, void* stream, const char* who) {
     ATX_REQUIRE(x && result, ATX_EINVAL, "%s: null pointer", who);
     ATX_REQUIRE(n_rows >= 0 && row_len >= 0, ATX_EINVAL, "%s: negative size", who);
     ATX_REQUIRE(pitch >= row_len, ATX_ESHAPE, "%s: pitch %lld shorter than a row of %lld", who, (long long)pitch, (long long)row_len);
     ATX_REQUIRE(red >= ATX_RED_MIN && red <= ATX_RED_MINMAX, ATX_EINVAL, "%s: bad reduction %d", who, red);
     ATX_REQUIRE(dtype == ATX_F32 || dtype == ATX_F64, ATX_EINVAL, "%s: bad dtype %d", who, dtype);
+    ATX_REQUIRE(!workspace || workspace_bytes >= sizeof(RedWorkspace), ATX_EWORKSPACE, "%s: workspace %zu < %zu", who, workspace_bytes,
+                sizeof(RedWorkspace));
+    ATX_REQUIRE(!workspace || (reinterpret_cast<uintptr_t>(workspace) & 7u) == 0, ATX_EALIGN, "%s: workspace must be 8-byte aligned", who);
     hipStream_t s = static_cast<hipStream_t>(stream);
-    hipLaunchKernelGGL(reduce_init_kernel, dim3(1), dim3(1), 0, s, result, red);
-    ATX_LAUNCH_CHECK("reduce_init");
-    if (n_rows == 0 || row_len == 0) return ATX_OK;
     // 16-byte loads when every row starts on a 16-byte boundary and its last (partial) vector lies inside the pitch (a flat array is
     // one row: only the base must be aligned); MINMAX exists in this form only and falls back to two scalar passes otherwise
     const int vec = dtype == ATX_F32 ? 4 : 2;
@@ -976,14 +1043,24 @@ static int reduce_rows(const void* x, int64_t n_rows, int64_t row_len, int64_t p
     const int64_t vec_len = row_len - tail;
     const int64_t C = (vec_len + vec - 1) / vec;
     const bool vec_ok = aligned16(x) && (n_rows == 1 || (pitch % vec == 0 && C * vec <= pitch)) && C <= 0x7fffffff;
+    // the ticketed finish (no init launch, plain store of the result) serves the single-launch case; everything else — empty
+    // input, a tail after the last whole vector, the scalar fallback's two MINMAX passes — combines through atomics on `result`
+    RedWorkspace* ws = static_cast<RedWorkspace*>(workspace);
+    const bool single = n_rows > 0 && row_len > 0 && ((vec_ok && tail == 0 && C > 0) || (!vec_ok && red != ATX_RED_MINMAX));
+    if (!(ws && single)) {
+        ws = nullptr;
+        hipLaunchKernelGGL(reduce_init_kernel, dim3(1), dim3(1), 0, s, result, red);
+        ATX_LAUNCH_CHECK("reduce_init");
+    }
+    if (n_rows == 0 || row_len == 0) return ATX_OK;
     if (vec_ok) {
         if (C > 0) {
             int64_t blocks = (n_rows * C + (int64_t)kBlock * kRedUnroll - 1) / ((int64_t)kBlock * kRedUnroll);
             const unsigned grid = (unsigned)(blocks > kRedGrid ? kRedGrid : (blocks < 1 ? 1 : blocks));
             if (dtype == ATX_F32)
-                hipLaunchKernelGGL((reduce_vec_kernel<float, 4>), dim3(grid), dim3(kBlock), 0, s, static_cast<const float*>(x), n_rows, vec_len, (int)C, pitch, red, result);
+                hipLaunchKernelGGL((reduce_vec_kernel<float, 4>), dim3(grid), dim3(kBlock), 0, s, static_cast<const float*>(x), n_rows, vec_len, (int)C, pitch, red, result, ws);
             else
-                hipLaunchKernelGGL((reduce_vec_kernel<double, 2>), dim3(grid), dim3(kBlock), 0, s, static_cast<const double*>(x), n_rows, vec_len, (int)C, pitch, red, result);
+                hipLaunchKernelGGL((reduce_vec_kernel<double, 2>), dim3(grid), dim3(kBlock), 0, s, static_cast<const double*>(x), n_rows, vec_len, (int)C, pitch, red, result, ws);
             ATX_LAUNCH_CHECK("reduce_vec");
         }
         if (tail > 0) {  // combines into the same result cells (atomics): MINMAX as min -> result[0], max -> result[1]
@@ -992,9 +1069,9 @@ static int reduce_rows(const void* x, int64_t n_rows, int64_t row_len, int64_t p
             for (int pass = 0; pass < (red == ATX_RED_MINMAX ? 2 : 1); ++pass) {
                 const int r = red == ATX_RED_MINMAX ? (pass == 0 ? ATX_RED_MIN : ATX_RED_MAX) : red;
                 if (dtype == ATX_F32)
-                    hipLaunchKernelGGL(reduce_kernel<float>, dim3(1), dim3(kBlock), 0, s, static_cast<const float*>(xt), (int64_t)1, tail, tail, r, result + pass);
+                    hipLaunchKernelGGL(reduce_kernel<float>, dim3(1), dim3(kBlock), 0, s, static_cast<const float*>(xt), (int64_t)1, tail, tail, r, result + pass, (RedWorkspace*)nullptr);
                 else
-                    hipLaunchKernelGGL(reduce_kernel<double>, dim3(1), dim3(kBlock), 0, s, static_cast<const double*>(xt), (int64_t)1, tail, tail, r, result + pass);
+                    hipLaunchKernelGGL(reduce_kernel<double>, dim3(1), dim3(kBlock), 0, s, static_cast<const double*>(xt), (int64_t)1, tail, tail, r, result + pass, (RedWorkspace*)nullptr);
             }
             ATX_LAUNCH_CHECK("reduce_tail");
         }
@@ -1005,21 +1082,23 @@ static int reduce_rows(const void* x, int64_t n_rows, int64_t row_len, int64_t p
     for (int pass = 0; pass < (red == ATX_RED_MINMAX ? 2 : 1); ++pass) {
         const int r = red == ATX_RED_MINMAX ? (pass == 0 ? ATX_RED_MIN : ATX_RED_MAX) : red;
         if (dtype == ATX_F32)
-            hipLaunchKernelGGL(reduce_kernel<float>, dim3(grid), dim3(kBlock), 0, s, static_cast<const float*>(x), n_rows, row_len, pitch, r, result + pass);
+            hipLaunchKernelGGL(reduce_kernel<float>, dim3(grid), dim3(kBlock), 0, s, static_cast<const float*>(x), n_rows, row_len, pitch, r, result + pass, ws);
         else
-            hipLaunchKernelGGL(reduce_kernel<double>, dim3(grid), dim3(kBlock), 0, s, static_cast<const double*>(x), n_rows, row_len, pitch, r, result + pass);
+            hipLaunchKernelGGL(reduce_kernel<double>, dim3(grid), dim3(kBlock), 0, s, static_cast<const double*>(x), n_rows, row_len, pitch, r, result + pass, ws);
     }
     ATX_LAUNCH_CHECK("reduce");
     return ATX_OK;
 }
 
-extern "C" int atx_reduce(const void* x, int64_t n, int red, double* result, int dtype, void* stream) {
-    return reduce_rows(x, 1, n, n, red, result, dtype, stream, "atx_reduce");
+extern "C" size_t atx_reduce_workspace(void) { return sizeof(RedWorkspace); }
+
+extern "C" int atx_reduce(const void* x, int64_t n, int red, double* result, int dtype, void* workspace, size_t workspace_bytes, void* stream) {
+    return reduce_rows(x, 1, n, n, red, result, dtype, workspace, workspace_bytes, stream, "atx_reduce");
 }
 
 extern "C" int atx_reduce_stack(const void* x, int64_t n_pts, int64_t n_lev, int64_t pitch, int red, double* result,
-                                int dtype, int layout, void* stream) {
+                                int dtype, int layout, void* workspace, size_t workspace_bytes, void* stream) {
     ATX_REQUIRE(layout == ATX_COLUMNS || layout == ATX_FIELDS, ATX_EINVAL, "atx_reduce_stack: bad layout %d", layout);
-    if (layout == ATX_COLUMNS) return reduce_rows(x, n_pts, n_lev, pitch, red, result, dtype, stream, "atx_reduce_stack");
-    return reduce_rows(x, n_lev, n_pts, pitch, red, result, dtype, stream, "atx_reduce_stack");
+    if (layout == ATX_COLUMNS) return reduce_rows(x, n_pts, n_lev, pitch, red, result, dtype, workspace, workspace_bytes, stream, "atx_reduce_stack");
+    return reduce_rows(x, n_lev, n_pts, pitch, red, result, dtype, workspace, workspace_bytes, stream, "atx_reduce_stack");
 }

@@ -90,9 +90,10 @@ SIGNATURES: dict[str, tuple[Any, list[Any]]] = {
     "atx_cutout_inside": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int32, c_void_p, c_void_p]),
     "atx_stream_copy": (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),
     "atx_vector_program": (c_int64, [c_void_p, c_int32, c_int64, c_int, c_void_p]),
-    "atx_reduce": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_int, c_void_p]),
+    "atx_reduce_workspace": (c_size_t, []),
+    "atx_reduce": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_int, c_void_p, c_size_t, c_void_p]),
     "atx_relayout": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int64, c_int, c_int, c_int, c_void_p]),
-    "atx_reduce_stack": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_int, c_void_p, c_int, c_int, c_void_p]),
+    "atx_reduce_stack": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_int, c_void_p, c_int, c_int, c_void_p, c_size_t, c_void_p]),
     "atx_select_levels": (c_int, [c_void_p, c_void_p, c_void_p, c_int32, c_int64, c_int64, c_int64, c_int64, c_int, c_int, c_void_p]),
     "atx_comm_version": (c_int, []),
     "atx_comm_unique_id": (c_int, [c_void_p]),
@@ -341,12 +342,13 @@ def mask_count(mask, n: int | None = None) -> int:
 def mask_to_index(mask, n: int | None = None) -> torch.Tensor:
     """Ascending int32 positions of the set mask bytes (stable compaction; synchronises)."""
     n = mask.numel() if n is None else n
-    ws_bytes = load().atx_mask_to_index_workspace(n)
-    workspace = torch.empty(max(ws_bytes, 16), dtype=torch.uint8, device=mask.device)
-    index = torch.empty(max(n, 1), dtype=torch.int32, device=mask.device)
-    count = torch.zeros(1, dtype=torch.int64, device=mask.device)
-    _call("atx_mask_to_index", _ptr(mask), n, _ptr(index), _ptr(count), _ptr(workspace), workspace.numel(), _stream())
-    return index[: int(count.item())]
+    slot = _Scratch.of(mask.device)
+    workspace = slot.room(max(load().atx_mask_to_index_workspace(n), 16))
+    index = torch.empty(max(n, 1), dtype=torch.int32, device=mask.device)  # the caller keeps (a view of) this one
+    # the count lands in the pinned host cell straight from the scan kernel
+    _call("atx_mask_to_index", _ptr(mask), n, _ptr(index), slot.host_count.data_ptr(), _ptr(workspace), workspace.numel(), _stream())
+    slot.wait()
+    return index[: int(slot.host_count[0])]
 
 
 class KnnIndex:
@@ -382,26 +384,79 @@ def cutout_inside(global_xyz: torch.Tensor, lam_xyz: torch.Tensor, neighbours: t
     return inside[:n]
 
 
-def _reduction_result(result: torch.Tensor, red: int):
+class _Scratch:
+    """Per-(device, stream) slots for the small synchronous calls (``reduce``, ``reduce_stack``, ``mask_to_index``): pinned HOST
+    cells the kernels write their result into directly (pinned memory is device-visible at the same address), the zeroed
+    workspace of the ticketed reduction, the event the host waits on and a growing scratch buffer.  Such a call is then its
+    launch(es) and ONE event wait — no allocation, no fill, no initialisation launch, no copy back, no blocking ``.item()``
+    (``reduce`` of one 26 MB field: 45 us -> see tools/small_case_bench.py).  One host thread per stream."""
+
+    _slots: dict = {}
+
+    def __init__(self, device) -> None:
+        self.result = torch.zeros(2, dtype=torch.float64, device=device)
+        self.host = torch.zeros(2, dtype=torch.float64).pin_memory()
+        self.host_count = torch.zeros(1, dtype=torch.int64).pin_memory()
+        self.reduce_ws = torch.zeros(load().atx_reduce_workspace() // 8 + 1, dtype=torch.int64, device=device)  # zeroed ONCE
+        self.event = torch.cuda.Event()
+        self.workspace = torch.empty(4096, dtype=torch.uint8, device=device)
+
+    @classmethod
+    def of(cls, device) -> "_Scratch":
+        key = (device.index if device.index is not None else torch.cuda.current_device(), _stream())
+        slot = cls._slots.get(key)
+        if slot is None:
+            if len(cls._slots) >= 64:  # streams come and go
+                cls._slots.clear()
+            slot = cls._slots[key] = cls(device)
+        return slot
+
+    def wait(self) -> None:
+        self.event.record()
+        self.event.synchronize()
+
+    def room(self, n_bytes: int) -> torch.Tensor:
+        if self.workspace.numel() < n_bytes:
+            self.workspace = torch.empty(max(n_bytes, 2 * self.workspace.numel()), dtype=torch.uint8, device=self.workspace.device)
+        return self.workspace
+
+
+# ATX_REDUCE_TICKET=1: the single-launch ticketed finish of atx_reduce (workspace given).  Measured SLOWER on MI355X than the
+# per-workgroup atomics it avoids — its device-scope release per workgroup writes the XCD's L2 back (one 26 MB field 43 -> 60 us,
+# a 137-level stack 0.66 -> 1.0 ms; profiles/r03_small_calls.log) — so the default passes no workspace.
+_REDUCE_TICKET = os.environ.get("ATX_REDUCE_TICKET", "0") == "1"
+
+
+def _reduce_ws(slot: "_Scratch"):
+    if _REDUCE_TICKET:
+        return _ptr(slot.reduce_ws), slot.reduce_ws.numel() * 8, slot.host.data_ptr()
+    return None, 0, _ptr(slot.result)
+
+
+def _reduction_result(slot: _Scratch, red: int):
+    if not _REDUCE_TICKET:
+        slot.host.copy_(slot.result, non_blocking=True)
+    slot.wait()
     if red == RED_MINMAX:
-        lo, hi = result.tolist()  # one device-to-host read for both
-        return float(lo), float(hi)
-    return float(result[0].item())
+        return float(slot.host[0]), float(slot.host[1])  # both from one pass, one wait
+    return float(slot.host[0])
 
 
 def reduce(x, red: int, n: int | None = None):
     """``atx_reduce``; ``RED_MINMAX`` returns ``(minimum, maximum)`` from one pass."""
     n = x.numel() if n is None else n
-    result = torch.zeros(2, dtype=torch.float64, device=x.device)
-    _call("atx_reduce", _ptr(x), n, red, _ptr(result), dtype_code(x.dtype), _stream())
-    return _reduction_result(result, red)
+    slot = _Scratch.of(x.device)
+    ws, ws_bytes, result = _reduce_ws(slot)
+    _call("atx_reduce", _ptr(x), n, red, result, dtype_code(x.dtype), ws, ws_bytes, _stream())
+    return _reduction_result(slot, red)
 
 
 def reduce_stack(x, red: int, *, n_pts: int, n_lev: int, pitch: int, layout: int):
     """``atx_reduce`` over the elements of a pitched stack (padding excluded); ``RED_MINMAX``: ``(minimum, maximum)``."""
-    result = torch.zeros(2, dtype=torch.float64, device=x.device)
-    _call("atx_reduce_stack", _ptr(x), n_pts, n_lev, pitch, red, _ptr(result), dtype_code(x.dtype), layout, _stream())
-    return _reduction_result(result, red)
+    slot = _Scratch.of(x.device)
+    ws, ws_bytes, result = _reduce_ws(slot)
+    _call("atx_reduce_stack", _ptr(x), n_pts, n_lev, pitch, red, result, dtype_code(x.dtype), layout, ws, ws_bytes, _stream())
+    return _reduction_result(slot, red)
 
 
 def select_levels(src, dst, level_map, *, n_pts, n_src_lev, src_pitch, dst_pitch, layout) -> None:

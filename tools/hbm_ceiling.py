@@ -33,7 +33,7 @@ def main():
         ("torch copy_ (1 read : 1 write)", lambda: y.copy_(x), 2 * gb),
         ("torch add out= (1 read : 1 write)", lambda: torch.add(x, 1.0, out=y), 2 * gb),
         ("libatx stream_copy (1 read : 1 write)", lambda: native.stream_copy(x, y), 2 * gb),
-        ("libatx reduce max (read only)", lambda: native.load().atx_reduce(x.data_ptr(), n, native.RED_MAX, red.data_ptr(), 0, torch.cuda.current_stream().cuda_stream), gb),
+        ("libatx reduce max (read only)", lambda: native.load().atx_reduce(x.data_ptr(), n, native.RED_MAX, red.data_ptr(), 0, None, 0, torch.cuda.current_stream().cuda_stream), gb),
     ]
     red = torch.zeros(1, dtype=torch.float64, device=dev)
     prog = native.level_program([[(native.OP_AFFINE, 0, 2.0, 1.0)] * 137], dev)

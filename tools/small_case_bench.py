@@ -48,6 +48,36 @@ def main():
             run()
         dt = (time.perf_counter() - t0) / n
         print(f"{n_fields:3d} host field(s) O96 -> 1 deg, regrid | rescale, back to host: {dt * 1e3:.3f} ms per call", flush=True)
+    # the small synchronous calls (one launch or three, one 16-byte read back): wall time per call on one 6.6 M-point field
+    from anemoi_transform_amd import native
+
+    dev = torch.device("cuda", 0)
+    n = 6_599_680
+    for tdt in (torch.float32, torch.float64):
+        x = torch.randn(n, dtype=tdt, device=dev)
+        for name, fn in (("reduce min", lambda: native.reduce(x, native.RED_MIN)), ("reduce min+max", lambda: native.reduce(x, native.RED_MINMAX)),
+                         ("reduce nan-count", lambda: native.reduce(x, native.RED_NANCOUNT))):
+            for _ in range(20):
+                fn()
+            t0 = time.perf_counter()
+            for _ in range(500):
+                fn()
+            print(f"{name:18s} {str(tdt)[6:]:8s} one {n}-point field, result on the host: {(time.perf_counter() - t0) / 500 * 1e6:7.1f} us per call", flush=True)
+    m = (torch.rand(n, device=dev) < 0.7).to(torch.uint8)
+    for _ in range(20):
+        native.mask_to_index(m, n)
+    t0 = time.perf_counter()
+    for _ in range(500):
+        native.mask_to_index(m, n)
+    print(f"mask_to_index      uint8    {n} points, 70 % kept, count on the host:        {(time.perf_counter() - t0) / 500 * 1e6:7.1f} us per call", flush=True)
+    small = (torch.rand(65_160, device=dev) < 0.7).to(torch.uint8)
+    for _ in range(20):
+        native.mask_to_index(small)
+    t0 = time.perf_counter()
+    for _ in range(500):
+        native.mask_to_index(small)
+    print(f"mask_to_index      uint8    65160 points (1 degree grid):                      {(time.perf_counter() - t0) / 500 * 1e6:7.1f} us per call", flush=True)
+
     pr = cProfile.Profile()
     pr.enable()
     for _ in range(20):
