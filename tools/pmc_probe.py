@@ -36,6 +36,9 @@ def main():
     ap.add_argument("--k", type=int, default=4)
     ap.add_argument("--levels", type=int, default=137)
     ap.add_argument("--layout", default="columns", choices=["columns", "fields"])
+    ap.add_argument("--case", default="ell", choices=["ell", "csr34", "csr916", "box"],
+                    help="ell: fixed k (--k); csr34 / csr916: general CSR with ragged rows of 3-4 / 9-16 entries; box: O1280 -> 1 degree box averages (~100 per row)")
+    ap.add_argument("--chunk", type=int, default=0, help="ell only: one launch per chunk of this many levels (the level-chunk-major traversal, emulated)")
     ap.add_argument("--meta", default=os.path.join(ROOT, "gpurun_out", "pmc_meta.json"))
     args = ap.parse_args()
 
@@ -82,20 +85,63 @@ def main():
     cols_copy_bytes = n_src * covered * itemsize
 
     # 2. the regrid launches
-    for _ in range(args.launches):
-        native.regrid_ell(regrid_src.data, regrid_out.data, idx, w, n_src=n_src, n_tgt=n_tgt, k=args.k, n_lev=args.levels,
-                          src_pitch=regrid_src.pitch, out_pitch=regrid_out.pitch, layout=regrid_src.layout)
+    from anemoi_transform_amd import interp
+
+    kernel = "regrid_fields_ell_kernel" if args.layout == "fields" else ("regrid_cols_ell_direct_kernel" if args.k <= 4 else "regrid_cols_ell_kernel")
+    alg = bench.algorithmic_bytes(args.levels, itemsize, int(np.unique(idx64).size), n_tgt, args.k)
+    config = f"o1280->0.25 k={args.k} L={args.levels} {args.dtype} {args.layout} gpus=1"
+    if args.case == "ell":
+        per16 = 16 // itemsize
+        chunk = args.levels if args.chunk <= 0 else (args.chunk + per16 - 1) // per16 * per16
+        cuts = list(range(0, args.levels, chunk)) + [args.levels]
+        if len(cuts) > 2:
+            config += f" level-chunks={chunk}"
+        for _ in range(args.launches):
+            for a, b in zip(cuts[:-1], cuts[1:]):
+                s_, o_ = (regrid_src.data[:, a:], regrid_out.data[:, a:]) if len(cuts) > 2 else (regrid_src.data, regrid_out.data)
+                native.regrid_ell(s_, o_, idx, w, n_src=n_src, n_tgt=n_tgt, k=args.k, n_lev=b - a,
+                                  src_pitch=regrid_src.pitch, out_pitch=regrid_out.pitch, layout=regrid_src.layout)
+    else:
+        kernel = "regrid_cols_csr_kernel"
+        if args.case == "box":  # every 1-degree cell averages the O1280 points inside it: each source column is read exactly once
+            one = lookup([1.0, 1.0])
+            n_rows = len(one["latitudes"])
+            cell = (np.rint(90.0 - src_grid["latitudes"]).astype(np.int64) * 360 + np.mod(np.rint(src_grid["longitudes"]).astype(np.int64), 360))
+            order = np.argsort(cell, kind="stable")
+            counts = np.bincount(cell, minlength=n_rows)
+            indptr = np.concatenate([[0], np.cumsum(counts)])
+            data, indices = (1.0 / np.maximum(counts, 1))[cell[order]], order
+        else:
+            kk = 4 if args.case == "csr34" else 16
+            i64, w64k = knn_inverse_distance(src_grid, tgt_grid, k=kk, device=kk > 4, **({"ties": "index"} if kk > 4 else {}))
+            if args.case == "csr34":
+                keep = (np.arange(i64.size) % 9 != 0).reshape(i64.shape)
+            else:
+                keep = np.random.default_rng(16).random(i64.shape) < 0.75
+                keep[:, :9] = True
+            n_rows = n_tgt
+            indptr = np.concatenate([[0], np.cumsum(keep.sum(axis=1))])
+            data, indices = w64k[keep], i64[keep]
+        nnz = int(len(indices))
+        alg = args.levels * itemsize * (int(np.unique(indices).size) + n_rows) + nnz * (4 + itemsize) + 4 * n_rows
+        config = f"o1280 {args.case} L={args.levels} {args.dtype} columns gpus=1"
+        csr_out = Stack.empty(n_rows, args.levels, tdtype, dev, COLUMNS)
+        d_ptr, d_idx, d_w = (torch.from_numpy(indptr.astype(np.int32)).to(dev), torch.from_numpy(indices.astype(np.int32)).to(dev),
+                             torch.from_numpy(data.astype(npdt)).to(dev))
+        for _ in range(args.launches):
+            native.regrid_csr(src.data, csr_out.data, d_ptr, d_idx, d_w, n_src=n_src, n_tgt=n_rows, nnz=nnz, n_lev=args.levels,
+                              src_pitch=src.pitch, out_pitch=csr_out.pitch, layout=COLUMNS)
     torch.cuda.synchronize()
 
     meta = {
-        "config": f"o1280->0.25 k={args.k} L={args.levels} {args.dtype} {args.layout} gpus=1",
+        "config": config,
         "calibration_kernel": "stream_copy_kernel",
         "cols_copy_bytes": cols_copy_bytes,
         "calibration_read_bytes": calib_bytes,
         "calibration_write_bytes": calib_bytes,
-        "regrid_kernel": "regrid_fields_ell_kernel" if args.layout == "fields" else ("regrid_cols_ell_direct_kernel" if args.k <= 4 else "regrid_cols_ell_kernel"),
+        "regrid_kernel": kernel,
         "regrid_launches": args.launches,
-        "algorithmic_bytes_per_launch": bench.algorithmic_bytes(args.levels, itemsize, int(np.unique(idx64).size), n_tgt, args.k),
+        "algorithmic_bytes_per_launch": alg,
     }
     os.makedirs(os.path.dirname(args.meta), exist_ok=True)
     json.dump(meta, open(args.meta, "w"), indent=1)

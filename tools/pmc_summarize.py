@@ -30,7 +30,8 @@ def counters(directory: str, counter: str) -> dict[str, list[float]]:
                     continue
                 name = row["Kernel_Name"]
                 for key in ("stream_copy_kernel", "pointwise_cols_kernel", "pointwise_cols_flat_kernel", "pointwise_cols_table_kernel", "pointwise_fields_kernel",
-                            "regrid_cols_ell_direct_kernel", "regrid_cols_ell_kernel", "regrid_fields_ell_kernel"):
+                            "pointwise_cols_uniform_kernel", "regrid_cols_ell_direct_kernel", "regrid_cols_ell_kernel", "regrid_fields_ell_kernel",
+                            "regrid_cols_csr_kernel"):
                     if key in name:
                         out.setdefault(key, []).append(float(row["Counter_Value"]))
     return out
@@ -53,8 +54,10 @@ def main():
     read_corr = meta["calibration_read_bytes"] / cal_f
     write_corr = meta["calibration_write_bytes"] / cal_w
     kern = meta["regrid_kernel"]
-    f_raw = sum(fetch[kern]) / len(fetch[kern]) * 1024
-    w_raw = sum(write[kern]) / len(write[kern]) * 1024
+    # per repetition of the workload: a repetition may be several dispatches (level-chunk launches)
+    reps = meta.get("regrid_launches") or len(fetch[kern])
+    f_raw = sum(fetch[kern]) / reps * 1024
+    w_raw = sum(write[kern]) / reps * 1024
     rec = {
         "round": args.round,
         "measured": f"round {args.round.lstrip('r0') or '0'}",
@@ -69,7 +72,8 @@ def main():
             "write_correction": write_corr,
         },
         "kernel": kern,
-        "launches_averaged": len(fetch[kern]),
+        "launches_averaged": reps,
+        "dispatches_per_launch": len(fetch[kern]) / reps,
         "FETCH_SIZE_bytes_raw": f_raw,
         "WRITE_SIZE_bytes_raw": w_raw,
         "fetch_bytes_corrected": f_raw * read_corr,
@@ -78,7 +82,7 @@ def main():
         "algorithmic_bytes_per_launch": meta["algorithmic_bytes_per_launch"],
     }
     rec["traffic_over_algorithmic"] = rec["hbm_bytes_per_launch"] / rec["algorithmic_bytes_per_launch"]
-    cols = next((k for k in ("pointwise_cols_table_kernel", "pointwise_cols_flat_kernel", "pointwise_cols_kernel") if k in fetch), None)
+    cols = next((k for k in ("pointwise_cols_uniform_kernel", "pointwise_cols_table_kernel", "pointwise_cols_flat_kernel", "pointwise_cols_kernel") if k in fetch), None)
     if cols and "cols_copy_bytes" in meta:  # the column-stack per-point copy, same correction
         rec["pointwise_cols_copy"] = {
             "kernel": cols,
