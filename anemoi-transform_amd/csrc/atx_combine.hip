@@ -14,6 +14,65 @@ struct CombArgs {
     void* out[2];
 };
 
+// cos and sin of a float64 angle of moderate size (|x| < 1e5: a wave direction, a phase in [-2 pi, 2 pi]) WITHOUT the general
+// argument reduction of the device maths library.  SQ counters (profiles/r03_pmc_sq_combine.txt) show the float64 cos+sin operator
+// VALU-bound with OCML's sincos: 537 VALU instructions per wave of 4 elements per lane, 66 % of wave time issuing or stalled on
+// issue, against 7 % for a plain difference.  This is the classic fdlibm scheme — n = rint(x * 2/pi), a Cody-Waite subtraction of
+// n * pi/2 in two (rarely three, four) pieces that is EXACT for |n| < 2^17, then the degree-13 / degree-14 kernels on [-pi/4, pi/4]
+// with the reduction's tail — no fused multiply-add needed.  Checked on the host against numpy (glibc): at most 1 ulp apart on
+// 4 M random angles in [-2 pi, 2 pi] and in [-1e5, 1e5], identical next to multiples of pi/2
+// (tests/test_multi_filters.py::test_fast_sincos_*).  Anything else — larger, infinite, NaN — takes OCML's sincos.
+__device__ __forceinline__ bool sincos_moderate(double x, double& sn, double& cs) {
+    if (!(fabs(x) < 1.0e5)) return false;
+    if (fabs(x) < 7.450580596923828125e-09) {  // |x| < 2^-27: sin x = x (keeps the sign of zero), cos x = 1, both correctly rounded
+        sn = x;
+        cs = 1.0;
+        return true;
+    }
+    const double fn = rint(x * 6.36619772367581382433e-01);
+    double r = x - fn * 1.57079632673412561417e+00;  // 33 bits of pi/2: the product is exact
+    double w = fn * 6.07710050650619224932e-11;
+    double y0 = r - w;
+    const int ex = (__double2hiint(x) >> 20) & 0x7ff;
+    if (ex - ((__double2hiint(y0) >> 20) & 0x7ff) > 16) {  // cancellation: x is close to a multiple of pi/2 — a second piece
+        double t = r;
+        w = fn * 6.07710050630396597660e-11;
+        r = t - w;
+        w = fn * 2.02226624879595063154e-21 - ((t - r) - w);
+        y0 = r - w;
+        if (ex - ((__double2hiint(y0) >> 20) & 0x7ff) > 49) {  // and a third
+            t = r;
+            w = fn * 2.02226624871116645580e-21;
+            r = t - w;
+            w = fn * 8.47842766036889956997e-32 - ((t - r) - w);
+            y0 = r - w;
+        }
+    }
+    const double y1 = (r - y0) - w;
+    const double z = y0 * y0;
+    // sin on [-pi/4, pi/4]
+    const double v = z * y0;
+    const double rs = 8.33333333332248946124e-03 + z * (-1.98412698298579493134e-04 + z * (2.75573137070700676789e-06 + z * (-2.50507602534068634195e-08 + z * 1.58969099521155010221e-10)));
+    const double s = y0 - ((z * (0.5 * y1 - v * rs) - y1) - v * -1.66666666666666324348e-01);
+    // cos on [-pi/4, pi/4]
+    const double rc = z * (4.16666666666666019037e-02 + z * (-1.38888888888741095749e-03 + z * (2.48015872894767294178e-05 + z * (-2.75573143513906633035e-07 + z * (2.08757232129817482790e-09 + z * -1.13596475577881948265e-11)))));
+    const int iy = __double2hiint(y0) & 0x7fffffff;
+    double c;
+    if (iy < 0x3FD33333) {  // |y0| < 0.3
+        c = 1.0 - (0.5 * z - (z * rc - y0 * y1));
+    } else {
+        const double qx = iy > 0x3fe90000 ? 0.28125 : __hiloint2double(iy - 0x00200000, 0);  // ~|y0| / 4
+        const double hz = 0.5 * z - qx;
+        c = (1.0 - qx) - (hz - (z * rc - y0 * y1));
+    }
+    const int q = ((int)fn) & 3;
+    sn = (q & 1) ? c : s;
+    cs = (q & 1) ? s : c;
+    if (q == 2 || q == 3) sn = -sn;
+    if (q == 1 || q == 2) cs = -cs;
+    return true;
+}
+
 // g = 9.80665 (R: constants.py:13, value pinned by filters/tabular/geopotential_to_height.py:51)
 // OP is a template parameter: every operator gets its own kernel.  With a runtime switch the float64 kernels carried the
 // inlined tanh, sincos and atan2 bodies for EVERY operator — 164-180 VGPRs, 2-3 waves per SIMD, even for `a - b` (round 2 called
@@ -50,6 +109,17 @@ __device__ __forceinline__ void combine_one(int flags, const T* x, int n_in, T l
         case ATX_COMB_COS_SIN: {
             T a = x[0];
             if (flags & ATX_COMB_DEGREES) a = a * T(0.017453292519943295);  // np.deg2rad: x * (pi/180)
+#ifndef ATX_FAST_SINCOS
+#define ATX_FAST_SINCOS 1
+#endif
+            if constexpr (ATX_FAST_SINCOS && sizeof(T) == 8) {
+                double sn, cs;
+                if (sincos_moderate((double)a, sn, cs)) {
+                    y0 = (T)cs;
+                    y1 = (T)sn;
+                    break;
+                }
+            }
             y0 = cos(a);
             y1 = sin(a);
             break;

@@ -297,6 +297,50 @@ def test_combine_kernel_vs_oracle(dev, tdtype, np_dtype, rtol, layout):
 
 
 @pytest.mark.gpu
+def test_fast_sincos_float64_within_ulps_of_numpy(dev):
+    """The float64 cos+sin operator reduces moderate arguments itself (atx_combine.hip: sincos_moderate) instead of calling the
+    device library's general routine: at most 2 ulp from numpy (each side is within 1 ulp of the true value) on the ranges the
+    filters see, exact signs and zeros next to multiples of pi/2, the library routine (same bound) beyond 1e5, NaN / inf -> NaN."""
+    from anemoi_transform_amd.stack import Stack
+
+    rng = np.random.default_rng(5)
+    n = 1 << 18
+    near = (np.arange(-200, 200)[:, None] * (np.pi / 2) + rng.uniform(-1e-9, 1e-9, (400, n // 400))).reshape(-1)
+    cases = {
+        "[-2 pi, 2 pi]": rng.uniform(-2 * np.pi, 2 * np.pi, n),
+        "[-1e5, 1e5]": rng.uniform(-1e5, 1e5, n),
+        "next to multiples of pi/2": np.resize(near, n),
+        "tiny": rng.uniform(-1e-8, 1e-8, n),
+        "beyond the fast path": rng.uniform(1e5, 1e15, n) * rng.choice([-1.0, 1.0], n),
+    }
+
+    def run(x, flags=0):
+        st = Stack.from_fields(x[None, :], dev=dev)
+        co, si = st.new_like(zero=False), st.new_like(zero=False)
+        native.combine_stack(native.COMB_COS_SIN, [st.data], [co.data, si.data], n_pts=x.size, n_lev=1, pitch=st.pitch, layout=native.COLUMNS, flags=flags)
+        return co.numpy()[0], si.numpy()[0]
+
+    def ulps(got, want):
+        return float(np.max(np.abs(got - want) / np.spacing(np.abs(want))))
+
+    for name, x in cases.items():
+        co, si = run(x)
+        assert ulps(co, np.cos(x)) <= 2.0 and ulps(si, np.sin(x)) <= 2.0, (name, ulps(co, np.cos(x)), ulps(si, np.sin(x)))
+    # degrees: the statement is cos(deg2rad(x)) (R: cos_sin_mean_wave_direction.py:72-76)
+    deg = rng.uniform(0.0, 360.0, n)
+    co, si = run(deg, flags=native.COMB_DEGREES)
+    assert ulps(co, np.cos(np.deg2rad(deg))) <= 2.0 and ulps(si, np.sin(np.deg2rad(deg))) <= 2.0
+    special = np.array([0.0, -0.0, np.pi / 2, np.pi, -np.pi, 2 * np.pi, np.inf, -np.inf, np.nan, 1e5, -1e5, 99999.999], dtype=np.float64)
+    co, si = run(special)
+    with np.errstate(invalid="ignore"):
+        wc, ws = np.cos(special), np.sin(special)
+    assert np.array_equal(np.isnan(co), np.isnan(wc)) and np.array_equal(np.isnan(si), np.isnan(ws))
+    ok = ~np.isnan(wc)
+    assert ulps(co[ok], wc[ok]) <= 2.0 and ulps(si[ok], ws[ok]) <= 2.0
+    assert si[0] == 0.0 and np.signbit(si[1]) and co[0] == 1.0  # sin(-0.0) = -0.0
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("tdtype,np_dtype", [(torch.float64, np.float64), (torch.float32, np.float32)])
 def test_snow_cover_shortcuts_give_the_statements_values(dev, tdtype, np_dtype):
     """R: filters/fields/snow_cover.py:34-39.  The kernel skips tanh for deep snow (argument beyond atanh(0.99): the statement's
