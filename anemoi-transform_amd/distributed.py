@@ -170,18 +170,32 @@ def exchange_source_bands(mine: Stack, plan: GatherPlan, comm=None) -> tuple[lis
                       [b.data if hi > lo else None for b in bands])
         return bands, rebase_plan(plan.shard(rank, world), lo, hi)
     bands[rank].data.copy_(mine.data[lo:hi])
-    ops = []
+    # Host-side backends (gloo: rehearsals, CPU tests) get the slabs through pinned host memory.  Handed a device tensor, gloo's
+    # point-to-point path lets its TCP transport read HBM through the PCIe BAR — uncached host reads of device memory — and
+    # the band exchange of two O1280 stacks took 150 s against 1.6 s for a broadcast of twice the bytes, which gloo stages itself
+    # (profiles/r02_bench_n2_rehearsal_shared_gpu.json).  RCCL (backend nccl) takes the device slabs as they are.
+    staged = mine.data.is_cuda and dist.get_backend(_data_group) != "nccl"
+    ops, landing = [], []
     for r in range(world):
         if r == rank:
             continue
         r_lo, r_hi = ranges[r]
         if r_hi > r_lo:
-            ops.append(dist.P2POp(dist.isend, mine.data[r_lo:r_hi], r, group=_data_group))
+            out = mine.data[r_lo:r_hi]
+            if staged:
+                out = torch.empty(out.shape, dtype=out.dtype, pin_memory=True).copy_(out)
+            ops.append(dist.P2POp(dist.isend, out, r, group=_data_group))
         if hi > lo:
-            ops.append(dist.P2POp(dist.irecv, bands[r].data, r, group=_data_group))
+            into = bands[r].data
+            if staged:
+                into = torch.empty(into.shape, dtype=into.dtype, pin_memory=True)
+                landing.append((bands[r].data, into))
+            ops.append(dist.P2POp(dist.irecv, into, r, group=_data_group))
     if ops:
         for work in dist.batch_isend_irecv(ops):
             work.wait()
+    for device_side, host_side in landing:
+        device_side.copy_(host_side, non_blocking=True)
     return bands, rebase_plan(plan.shard(rank, world), lo, hi)
 
 

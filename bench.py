@@ -481,14 +481,15 @@ def multi_gpu_lines(args, result, dist, rank, world, dev, plan, stacks, outs, la
         lo4, hi4 = b4[rank], b4[rank + 1]
         gen = torch.Generator(device=dev)
         srcs = []
+        t4, np4 = torch.float32, np.float32  # SURVEY.md §8d sizes config 4 in float32 (86.8 GB of sources per GPU; float64 would not leave room beside the N headline stacks)
         for i in range(n_stack):
             gen.manual_seed(SEED + 7 * i)
-            st = Stack.empty(n4_src, args.levels, tdtype, dev, COLUMNS, zero=True)
+            st = Stack.empty(n4_src, args.levels, t4, dev, COLUMNS, zero=True)
             st.data[:, : args.levels].normal_(250.0 + 5.0 * (i // 4), 20.0, generator=gen)
             srcs.append(st)
-        dsts = [Stack.empty(hi4 - lo4, args.levels, tdtype, dev, COLUMNS) for _ in range(n_stack)]
+        dsts = [Stack.empty(hi4 - lo4, args.levels, t4, dev, COLUMNS) for _ in range(n_stack)]
         idx_d4 = torch.from_numpy(idx4[lo4:hi4].astype(np.int32)).to(dev)
-        w_d4 = torch.from_numpy(w4[lo4:hi4].astype(np_dtype)).to(dev)
+        w_d4 = torch.from_numpy(w4[lo4:hi4].astype(np4)).to(dev)
 
         def go():
             native.regrid_ell_batch([s.data for s in srcs], [d.data for d in dsts], idx_d4, w_d4, n_src=n4_src, n_tgt=hi4 - lo4, k=4,
@@ -506,7 +507,8 @@ def multi_gpu_lines(args, result, dist, rank, world, dev, plan, stacks, outs, la
         t = max_over_ranks(time.perf_counter() - t0)
         return {"value": n4_tgt * args.levels * n_stack * reps / t, "unit": "grid-points/s", "ms_per_step": t / reps * 1e3, "fields": n_stack * args.levels,
                 "targets_of_this_rank": hi4 - lo4,
-                "workload": f"O1280 -> N320-sized ({n4_tgt} pts), k=4, 24 stacks x {args.levels} levels resident on every rank, target points over {world} ranks"}
+                "dtype": "f32",
+                "workload": f"O1280 -> N320-sized ({n4_tgt} pts), k=4, float32, 24 stacks x {args.levels} levels resident on every rank, target points over {world} ranks"}
 
     def config5():
         plain, fused, _, all_units, _, keep = config5_case(args, dev, tdtype, np_dtype, rank, world)
@@ -787,7 +789,7 @@ def single_gpu_lines(args, result, dev, stacks, outs, launch, idx_d, w_d, idx64,
 
     # ---- BASELINE configs[3]: O1280 -> N320-sized, 6 variables x 137 levels x 4 timesteps = 24 stacks, 8 target shards
     try:
-        extras["config4"] = config4_lines(args, dev, tdtype, np_dtype, itemsize)
+        extras["config4"] = config4_lines(args, dev, torch.float32, np.float32, 4)  # float32 as SURVEY.md §8d sizes it (86.8 GB resident)
     except Exception as e:
         extras["config4"] = {"error": f"{type(e).__name__}: {e}"}
     torch.cuda.empty_cache()
@@ -886,7 +888,8 @@ def config4_lines(args, dev, tdtype, np_dtype, itemsize):
         u = int(np.unique(idx[lo:hi]).size)
         return dict(line((hi - lo) * n_lev * n_stack, ms, n_stack * algorithmic_bytes(n_lev, itemsize, u, hi - lo, k)), targets=hi - lo)
 
-    out = {"workload": f"O1280 -> N320-sized reduced Gaussian ({n_tgt} pts, grids.sized_row_lengths), k=4, {n_stack} stacks x {n_lev} levels "
+    out = {"dtype": "f32" if itemsize == 4 else "f64",
+           "workload": f"O1280 -> N320-sized reduced Gaussian ({n_tgt} pts, grids.sized_row_lengths), k=4, {n_stack} stacks x {n_lev} levels "
                        f"= {n_stack * n_lev} fields resident ({sum(s.data.numel() for s in stacks) * itemsize / 1e9:.1f} GB)",
            "all_targets_one_gpu": run(0, n_tgt)}
     bounds = plan.bounds(8)
