@@ -412,10 +412,18 @@ def multi_gpu_lines(args, result, dist, rank, world, dev, plan, stacks, outs, la
     watchdog.daemon = True
     watchdog.start()
 
+    t_secondary = time.monotonic()
+
     def section(name, fn):
-        """Run one secondary measurement on all ranks; an exception on any rank is recorded and the ranks stay in step."""
+        """Run one secondary measurement on all ranks; an exception on any rank is recorded and the ranks stay in step.
+        Past half of the secondary budget the remaining sections are skipped (all ranks decide together): the hard limit — which
+        ends the run with a non-zero status — is for a collective that never returns, not for a slow box."""
         state["section"] = name
         barrier()
+        spent = torch.tensor([time.monotonic() - t_secondary], dtype=torch.float64)
+        dist.all_reduce(spent, op=dist.ReduceOp.MAX)
+        if spent.item() > 0.5 * args.secondary_seconds:
+            return {"skipped": f"{spent.item():.0f} s of the {args.secondary_seconds:.0f} s secondary budget already spent"}
         try:
             out = fn()
             ok = 1.0
@@ -635,7 +643,7 @@ def multi_gpu_lines(args, result, dist, rank, world, dev, plan, stacks, outs, la
                     "verified_bit_equal": all(torch.equal(g.data, o.data) for g, o in zip(got, outs))}
 
         c_abi["init"] = section("c_abi init", c_abi_init)
-        if "error" not in c_abi["init"]:
+        if "error" not in c_abi["init"] and "skipped" not in c_abi["init"]:  # (the same on every rank: `section` agrees on both)
             c_abi["broadcast"] = section("c_abi broadcast", c_abi_broadcast)
             c_abi["bands"] = section("c_abi bands", c_abi_bands)
             c_abi["end_to_end"] = section("c_abi end_to_end", c_abi_end_to_end)
@@ -733,6 +741,7 @@ def single_gpu_lines(args, result, dev, stacks, outs, launch, idx_d, w_d, idx64,
     # the one-off index build on the device instead of cKDTree: raw kernel order, and with equidistant candidates settled by
     # cKDTree (the table the reference builds, bit for bit)
     args4 = (src_grid["latitudes"], src_grid["longitudes"], tgt_grid["latitudes"], tgt_grid["longitudes"])
+    interp.knn_cache_clear()  # the tables of this grid pair are remembered since the precompute above: time a first construction
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     raw_i = interp.nearest_grid_points_device(*args4, num_neighbours_to_return=args.k, ties="index")
@@ -740,6 +749,11 @@ def single_gpu_lines(args, result, dev, stacks, outs, launch, idx_d, w_d, idx64,
     t0 = time.perf_counter()
     di = interp.nearest_grid_points_device(*args4, num_neighbours_to_return=args.k)
     extras["knn_device_ties_settled_s"] = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    again = interp.nearest_grid_points_device(*args4, num_neighbours_to_return=args.k)
+    extras["knn_remembered_s"] = time.perf_counter() - t0  # the same request again: process memo (interp._remembered_table)
+    assert np.array_equal(again, di)
+    del again
     extras["knn_rows_identical_to_ckdtree"] = float((di.reshape(n_tgt, -1) == idx64).all(axis=1).mean())
     extras["knn_rows_identical_to_ckdtree_kernel_order"] = float((raw_i.reshape(n_tgt, -1) == idx64).all(axis=1).mean())
     del raw_i, di
