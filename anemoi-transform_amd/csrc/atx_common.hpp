@@ -299,6 +299,27 @@ static inline bool uniform_level_program(const atx_level_op* host_prog, int n_st
     return true;
 }
 
+// Does some 16-byte vector of levels hold two different operators at some stage (once the parameters are rounded to T)?  Such
+// "mixed" vectors are evaluated level by level from the per-level program — fine for the odd boundary vector of a two-variable
+// stack, slow when every vector is one (a different scale per level, float32: 2.20 ms on the per-vector-table kernel, 1.82 ms on
+// the chunked one; staging the per-level operators in LDS as well made it 2.08 ms — bank conflicts — and was dropped).
+template <typename T>
+static inline bool program_has_mixed_vectors(const atx_level_op* host_prog, int n_stage, int n_lev, int vec) {
+    if (!host_prog) return false;  // unknown
+    for (int s = 0; s < n_stage; ++s) {
+        const atx_level_op* row = host_prog + (int64_t)s * n_lev;
+        for (int l0 = 0; l0 < n_lev; l0 += vec) {
+            for (int l = l0 + 1; l < n_lev && l < l0 + vec; ++l) {
+                const T a0 = static_cast<T>(row[l0].p0), a1 = static_cast<T>(row[l0].p1), b0 = static_cast<T>(row[l].p0), b1 = static_cast<T>(row[l].p1);
+                if (row[l].op != row[l0].op || (row[l].use_mask != 0) != (row[l0].use_mask != 0) || std::memcmp(&a0, &b0, sizeof(T)) != 0 ||
+                    std::memcmp(&a1, &b1, sizeof(T)) != 0)
+                    return true;
+            }
+        }
+    }
+    return false;
+}
+
 // Does a host copy of a program (n_stage * n_lev entries) hold an operator that needs the TRANS = true instantiation?  Without a
 // host copy the answer is "maybe".
 static inline bool program_has_transcendental(const atx_level_op* host_prog, int n_stage, int n_lev) {

@@ -895,7 +895,8 @@ static int pointwise_typed(const void* x_, void* y_, int64_t n_pts, int n_lev, i
 #endif
             const bool table_narrow = !mask && sizeof(T) == 4 && n_stage == 1 && !in_place;
             const bool table_wide = ATX_PW_TABLE_RULE == 1 && !mask && sizeof(T) == 4 && n_stage == 1;
-            if (vec_prog && (table_narrow || table_wide) && (n_vec + kBlock - 1) / kBlock <= 0x7fffffffll) {
+            if (vec_prog && (table_narrow || table_wide) && (n_vec + kBlock - 1) / kBlock <= 0x7fffffffll &&
+                !program_has_mixed_vectors<T>(host_prog, n_stage, n_lev, VEC)) {  // (mixed vectors: the chunked kernel serves them better)
                 hipLaunchKernelGGL((pointwise_cols_table_kernel<T, VEC>), dim3((unsigned)((n_vec + kBlock - 1) / kBlock)), dim3(kBlock), 0, st,
                                    x, y, n_vec, n_lev, C, prog, vec_prog, n_stage, mask, in_place);
                 ATX_LAUNCH_CHECK("pointwise_stack");

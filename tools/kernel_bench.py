@@ -129,6 +129,15 @@ def main():
         stack_bytes = n_src * L * B
         record(f"pointwise affine {tag} out-of-place", timeit(lambda: native.pointwise_stack(x.data, y.data, prog=p1, n_stage=1, **kw)), 2 * stack_bytes)
         record(f"pointwise affine {tag} in-place", timeit(lambda: native.pointwise_stack(y.data, y.data, prog=p1, n_stage=1, **kw)), 2 * stack_bytes)
+        p2 = native.level_program([[(native.OP_MUL, 0, 9.80665, 0.0)] * L, [(native.OP_AFFINE, 0, 1.0, -273.15)] * L], dev)
+        record(f"pointwise 2 stages, uniform over the levels {tag} out-of-place", timeit(lambda: native.pointwise_stack(x.data, y.data, prog=p2, n_stage=2, **kw)), 2 * stack_bytes,
+               "operators by value")
+        pl = native.level_program([[(native.OP_AFFINE, 0, 1.0 + 0.001 * l, -273.15) for l in range(L)]], dev)
+        record(f"pointwise affine, a different operator per level {tag} out-of-place", timeit(lambda: native.pointwise_stack(x.data, y.data, prog=pl, n_stage=1, **kw)), 2 * stack_bytes,
+               "per-vector table (f32) / chunked kernel (f64)")
+        pe = native.level_program([[(native.OP_LOG, 0, 0.0, 0.0)] * L, [(native.OP_EXP, 0, 0.0, 0.0)] * L], dev)
+        record(f"pointwise log then exp (sp_to_lnsp | lnsp_to_sp) {tag} out-of-place", timeit(lambda: native.pointwise_stack(x.data, y.data, prog=pe, n_stage=2, **kw)), 2 * stack_bytes,
+               "device-library log and exp on every element")
         pm = (torch.rand(n_src + 8, device=dev) < 0.3).to(torch.uint8)
         pmask = native.level_program([[(native.OP_COPY, 1, 0.0, 0.0)] * L], dev)
         record(f"apply_mask {tag}", timeit(lambda: native.pointwise_stack(x.data, y.data, prog=pmask, n_stage=1, point_mask=pm, **kw)), 2 * stack_bytes + n_src)
