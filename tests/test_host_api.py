@@ -612,3 +612,13 @@ def test_shard_bounds_invariants_on_random_plans(monkeypatch):
         full = plan.apply(x).numpy()
         parts = [plan.shard(r, world).apply(x).numpy() for r in range(world)]
         assert np.array_equal(np.concatenate(parts, axis=1), full, equal_nan=True), (case, kind, world)
+
+
+def test_design_tables_are_generated():
+    """DESIGN.md's measured tables come from the tracked JSON records (tools/design_tables.py): hand-copied cells drifted in round 2."""
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    run = subprocess.run([sys.executable, os.path.join(root, "tools", "design_tables.py"), "--check"], capture_output=True, text=True)
+    assert run.returncode == 0, run.stderr

@@ -30,7 +30,7 @@ def kernel_table(path: str) -> str:
             continue
         m = re.search(r"\bf(32|64)\b", name)
         tag = f"f{m.group(1)}" if m else "-"
-        key = re.sub(r"\s+", " ", re.sub(r"\bf(32|64)\b", "", name)).strip()
+        key = re.sub(r"\s+", " ", re.sub(r"\bf(32|64)\b", "", name)).strip().replace("|", "\\|")
         if key not in rows:
             rows[key] = {}
             order.append(key)
