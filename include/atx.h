@@ -232,7 +232,9 @@ typedef enum {
 #define ATX_COMB_DEGREES 1
 #define ATX_COMB_MAX_INPUTS 8
 /* inputs / outputs: HOST arrays of n_in / n_out DEVICE pointers (n_in <= ATX_COMB_MAX_INPUTS, n_out <= 2).
- * level_param: device double[n_lev] or NULL (required by the W/WZ operators). */
+ * level_param: device double[n_lev] or NULL (required by the W/WZ operators).
+ * All stacks share n_pts, n_lev, pitch and layout; the padding of the outputs (elements between a row's length and the pitch) is
+ * written with zeros. */
 int atx_combine_stack(int op, const void* const* inputs, int32_t n_in, void* const* outputs, int32_t n_out,
                       int64_t n_pts, int64_t n_lev, int64_t pitch, int dtype, int layout,
                       const double* level_param, int32_t flags, void* stream);

@@ -238,3 +238,59 @@ def test_random_pointwise_and_level_gather_cases(dev, seed):
         assert np.array_equal(same.values().view(itype), x.view(itype)) and same.padding_untouched(), what + " pitched copy"
         # pitched reduction ignores the poisoned padding
         assert native.reduce_stack(src2.data, native.RED_NANCOUNT, n_pts=n_pts, n_lev=n_lev, pitch=src2.pitch, layout=layout) == float(np.isnan(x).sum())
+
+
+COMBINE_SEEDS = range(_FIRST, _FIRST + _COUNT) if _COUNT else range(12)
+
+
+@pytest.mark.parametrize("seed", COMBINE_SEEDS)
+def test_random_combine_cases(dev, seed):
+    """The multi-input per-point kernels (one per operator since round 3) on random shapes, layouts and pitches — 16-byte vector
+    and scalar forms, tails, poisoned padding — against the oracle's statements."""
+    rng = np.random.default_rng(7000 + seed)
+    np_dtype = np.float64 if rng.random() < 0.5 else np.float32
+    layout = COLUMNS if rng.random() < 0.6 else FIELDS
+    n_lev = int(rng.integers(1, 40))
+    n_pts = int(rng.choice([1, 2, 3, 5, 63, 64, 257, 1000, 4099, 20011]))
+    pad, align16 = int(rng.integers(0, 6)), bool(rng.random() < 0.6)
+    rtol = 1e-13 if np_dtype == np.float64 else 2e-6
+    shape = (n_lev, n_pts)
+    sd = rng.uniform(0.0, 0.3, shape).astype(np_dtype)
+    sd[rng.random(shape) < 0.3] = 0.0  # bare ground: the exact-zero shortcut
+    rsn = rng.uniform(50.0, 600.0, shape).astype(np_dtype)
+    ang = rng.uniform(-6.3, 6.3, shape).astype(np_dtype)
+    t = (250.0 + 40.0 * rng.random(shape)).astype(np_dtype)
+    w = rng.normal(0, 0.5, shape).astype(np_dtype)
+    q = rng.uniform(0.0, 0.02, shape).astype(np_dtype)
+    levels = np.sort(rng.uniform(1.0, 1000.0, n_lev))
+
+    def run(op, ins, n_out, flags=0, with_levels=False):
+        stacks = [Loose(x, layout, pad, dev, align16) for x in ins]
+        outs = [Loose(np.full(shape, 7.0, dtype=np_dtype), layout, pad, dev, align16) for _ in range(n_out)]
+        lp = torch.from_numpy(levels).to(dev) if with_levels else None
+        native.combine_stack(op, [s.data for s in stacks], [o.data for o in outs], n_pts=n_pts, n_lev=n_lev, pitch=stacks[0].pitch, layout=layout,
+                             level_param=lp, flags=flags)
+        for o in outs:  # atx.h: the padding of the outputs is written with zeros (or left alone where no vector reaches it)
+            padding = o.data[:, o.row_len:]
+            assert bool(((padding == 0) | torch.isnan(padding)).all().item()), (op, layout, pad, align16)
+        return [o.values() for o in outs]
+
+    assert np.array_equal(run(native.COMB_SNOW_DEPTH_M, [sd, rsn], 1)[0], oracle.snow_depth_m(sd, rsn))
+    assert np.array_equal(run(native.COMB_SUB, [t, w], 1)[0], t - w)
+    np.testing.assert_allclose(run(native.COMB_SNOW_COVER, [sd, rsn], 1)[0], oracle.snow_cover(sd, rsn), rtol=rtol, atol=1e-7)
+    deg = bool(rng.random() < 0.5)
+    x = np.rad2deg(ang).astype(np_dtype) if deg else ang
+    co, si = run(native.COMB_COS_SIN, [x], 2, flags=native.COMB_DEGREES if deg else 0)
+    wc, ws = oracle.cos_sin(x, deg)
+    atol = 1e-6 if np_dtype == np.float32 else 1e-15
+    np.testing.assert_allclose(co, wc, rtol=rtol, atol=atol)
+    np.testing.assert_allclose(si, ws, rtol=rtol, atol=atol)
+    back = run(native.COMB_ATAN2, [wc.astype(np_dtype), ws.astype(np_dtype)], 1, flags=native.COMB_DEGREES if deg else 0)[0]
+    np.testing.assert_allclose(back, oracle.direction_from_cos_sin(wc.astype(np_dtype), ws.astype(np_dtype), deg), rtol=rtol, atol=1e-4)
+    want = np.stack([oracle.w_to_wz(w[l], t[l], q[l], np_dtype(levels[l])) for l in range(n_lev)])
+    np.testing.assert_allclose(run(native.COMB_W_TO_WZ, [w, t, q], 1, with_levels=True)[0], want, rtol=rtol)
+    want = np.stack([oracle.wz_to_w(w[l], t[l], q[l], np_dtype(levels[l])) for l in range(n_lev)])
+    np.testing.assert_allclose(run(native.COMB_WZ_TO_W, [w, t, q], 1, with_levels=True)[0], want, rtol=rtol)
+    n_terms = int(rng.integers(1, 9))
+    terms = [sd, rsn, ang, t, w, q, sd * 2, t * 3][:n_terms]
+    assert np.array_equal(run(native.COMB_SUM, terms, 1)[0], np.stack([oracle.sum_fields([x[l] for x in terms]) for l in range(n_lev)]))
