@@ -634,7 +634,10 @@ static int launch_cols_ell(const EllBatch& batch, const int32_t* idx, const T* w
     // 0.8343 ms; 1-60 levels equal or up to 15 % faster; 2 / 4 items per lane -4 % / -9 %.  Same bits, no tile heuristic to tune.
     // With an epilogue it still does when the operators can reach it without a per-workgroup set-up: by value (uniform
     // program seen through host_prog) or, for multiply-add programs, through the host-built per-vector table (vec_prog);
-    // profiles/r02_ab_epilogue_routes.log.
+    // profiles/r02_ab_epilogue_routes.log.  Round 3 tried TWO vectors per lane (columns c and c + ceil(C/2) of one target: half the
+    // lanes read the index / weight words, 2 k source loads in flight per lane) — slower everywhere: k=4 f64 0.841 -> 0.912 ms,
+    // k=1 f64 0.368 -> 0.420, k=4 f32 0.439 -> 0.523, k=1 f32 0.197 -> 0.236 (profiles/r03_direct_v2_experiment.log); one item per
+    // lane in many short waves it stays.
 #ifndef ATX_ELL_DIRECT
 #define ATX_ELL_DIRECT 1
 #endif

@@ -76,11 +76,13 @@ def main():
                                     dev) if "e" in case[2:] else None
         f64 = "f64" in case
 
+        vec_p, host_p = native._program_companions(prog, tdt)
+
         def run(h, tile):
             h.atx_set_tuning(tile)
             rc = h.atx_regrid_ell(src.data.data_ptr(), out.data.data_ptr(), idx.data_ptr(), None if w is None else w.data_ptr(),
                                   n_src, n_tgt, k, args.levels, src.pitch, out.pitch, 1 if f64 else 0, 0, 0,
-                                  None if prog is None else prog.data_ptr(), 0 if prog is None else 2, None, stream)
+                                  None if prog is None else prog.data_ptr(), vec_p, host_p, 0 if prog is None else 2, None, stream)
             assert rc == 0, h.atx_last_error()
 
         combos = [(name, tile) for name in libs for tile in args.tiles]
