@@ -110,8 +110,9 @@ def _worker(rank: int, world: int, port: int, kind: str, tmpdir: str) -> None:
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("kind", ["ell", "csr"])
-def test_target_sharded_regrid_world2(tmp_path, kind):
-    world = 2
+@pytest.mark.parametrize("kind,world", [("ell", 2), ("csr", 2), ("ell", 3)])
+def test_target_sharded_regrid(tmp_path, kind, world):
+    """World 2 for both plan kinds; world 3 as well: the double-buffered step then re-uses a receive buffer (stack r + 1 may get
+    the block of stack r - 1) and every rank has two peers in the band exchange."""
     mp.spawn(_worker, args=(world, _free_port(), kind, str(tmp_path)), nprocs=world, join=True)
     assert all((tmp_path / f"ok{r}").exists() for r in range(world))
