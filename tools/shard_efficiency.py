@@ -18,20 +18,21 @@ n_src, n_tgt, L = len(src['latitudes']), len(tgt['latitudes']), 137
 idx, w = interp.knn_inverse_distance(src, tgt, k=4, device=True, ties="index")
 plan = GatherPlan(n_src, n_tgt, index=idx, weights=w)
 world = int(sys.argv[1]) if len(sys.argv) > 1 else 8
+TDT, NPDT = (torch.float64, np.float64) if os.environ.get("ATX_SHARD_DTYPE", "f64") == "f64" else (getattr(torch, "float32"), getattr(np, "float32"))  # f64: the headline since round 3
 if len(sys.argv) > 2:  # try another weight of the shard cost model
     from anemoi_transform_amd import gather as _gather
 
     _gather.TARGET_COST = float(sys.argv[2])
     print('TARGET_COST =', _gather.TARGET_COST)
-stacks = [bench.synth_stack(src, L, torch.float32, dev, s, COLUMNS) for s in range(world)]
+stacks = [bench.synth_stack(src, L, TDT, dev, s, COLUMNS) for s in range(world)]
 for name, bounds, batched in (("equal-count", [(n_tgt * r) // world for r in range(world + 1)], False),
                               ("traffic-balanced", plan.bounds(world), False),
                               ("balanced+batched", plan.bounds(world), True)):
     times = []
     for r in range(world):
         lo, hi = bounds[r], bounds[r + 1]
-        idx_d = torch.from_numpy(idx[lo:hi].astype(np.int32)).to(dev); w_d = torch.from_numpy(w[lo:hi].astype(np.float32)).to(dev)
-        outs = [Stack.empty(hi - lo, L, torch.float32, dev, COLUMNS) for _ in range(world)]
+        idx_d = torch.from_numpy(idx[lo:hi].astype(np.int32)).to(dev); w_d = torch.from_numpy(w[lo:hi].astype(NPDT)).to(dev)
+        outs = [Stack.empty(hi - lo, L, TDT, dev, COLUMNS) for _ in range(world)]
         def step():
             if batched:  # one launch over the `world` stacks of the step (atx_regrid_ell_batch)
                 native.regrid_ell_batch([s.data for s in stacks], [o.data for o in outs], idx_d, w_d, n_src=n_src, n_tgt=hi - lo, k=4,
