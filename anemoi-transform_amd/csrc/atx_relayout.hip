@@ -12,6 +12,42 @@
 
 namespace atx {
 
+// global accesses of the transposes: every element is read once and written once.  Non-temporal accesses measured in round 3
+// (profiles/r03_relayout_nt_experiment.log): towards columns +6 % f32 / +3 % f64 (1.32 -> 1.25 ms, 2.64 -> 2.55 ms), towards fields
+// -10 % / -2 % (that direction runs on 4-byte accesses) — so they are used towards columns only.
+#ifndef ATX_TP_NT
+#define ATX_TP_NT 1
+#endif
+template <bool NT, typename X>
+__device__ __forceinline__ X tp_load(const X* p) {
+    if constexpr (NT) return __builtin_nontemporal_load(p);
+    else return *p;
+}
+template <bool NT, typename X>
+__device__ __forceinline__ void tp_store(X* p, X v) {
+    if constexpr (NT) __builtin_nontemporal_store(v, p);
+    else *p = v;
+}
+template <bool NT, typename T, int N>
+__device__ __forceinline__ Pack<T, N> tp_load_vec(const T* p) {
+    if constexpr (NT && N > 1) {
+        typedef T NV __attribute__((ext_vector_type(N)));
+        NV v = __builtin_nontemporal_load(reinterpret_cast<const NV*>(p));
+        return *reinterpret_cast<Pack<T, N>*>(&v);
+    } else {
+        return *reinterpret_cast<const Pack<T, N>*>(p);
+    }
+}
+template <bool NT, typename T, int N>
+__device__ __forceinline__ void tp_store_vec(T* p, const Pack<T, N>& v) {
+    if constexpr (NT && N > 1) {
+        typedef T NV __attribute__((ext_vector_type(N)));
+        __builtin_nontemporal_store(*reinterpret_cast<const NV*>(&v), reinterpret_cast<NV*>(p));
+    } else {
+        *reinterpret_cast<Pack<T, N>*>(p) = v;
+    }
+}
+
 template <typename T, bool TO_COLUMNS>
 __global__ void __launch_bounds__(kBlock)
 transpose_kernel(const T* __restrict__ src, T* __restrict__ dst, int64_t n_pts, int n_lev,
@@ -29,23 +65,23 @@ transpose_kernel(const T* __restrict__ src, T* __restrict__ dst, int64_t n_pts, 
 #pragma unroll 4
         for (int i = tid; i < nl * TP; i += kBlock) {
             const int l = i / TP, p = i - l * TP;
-            if (p < np) tile[p * LCpad + l] = src[(int64_t)(l0 + l) * src_pitch + p0 + p];
+            if (p < np) tile[p * LCpad + l] = tp_load<TO_COLUMNS && ATX_TP_NT>(src + (int64_t)(l0 + l) * src_pitch + p0 + p);
         }
         __syncthreads();
         for (int i = tid; i < np * nl; i += kBlock) {
             const int p = i / nl, l = i - p * nl;
-            dst[(p0 + p) * dst_pitch + l0 + l] = tile[p * LCpad + l];
+            tp_store<TO_COLUMNS && ATX_TP_NT>(dst + (p0 + p) * dst_pitch + l0 + l, tile[p * LCpad + l]);
         }
     } else {
 #pragma unroll 4
         for (int i = tid; i < np * nl; i += kBlock) {
             const int p = i / nl, l = i - p * nl;
-            tile[p * LCpad + l] = src[(p0 + p) * src_pitch + l0 + l];
+            tile[p * LCpad + l] = tp_load<TO_COLUMNS && ATX_TP_NT>(src + (p0 + p) * src_pitch + l0 + l);
         }
         __syncthreads();
         for (int i = tid; i < nl * TP; i += kBlock) {
             const int l = i / TP, p = i - l * TP;
-            if (p < np) dst[(int64_t)(l0 + l) * dst_pitch + p0 + p] = tile[p * LCpad + l];
+            if (p < np) tp_store<TO_COLUMNS && ATX_TP_NT>(dst + (int64_t)(l0 + l) * dst_pitch + p0 + p, tile[p * LCpad + l]);
         }
     }
 }
@@ -78,7 +114,7 @@ transpose_vec_kernel(const T* __restrict__ src, T* __restrict__ dst, int64_t n_p
             const int l = i / PV, pv = i - l * PV;
             const int p = pv * VEC;
             if (p + VEC <= np) {
-                const V v = *reinterpret_cast<const V*>(src + (int64_t)(l0 + l) * fields_pitch + p0 + p);
+                const V v = tp_load_vec<TO_COLUMNS && ATX_TP_NT, T, VEC>(src + (int64_t)(l0 + l) * fields_pitch + p0 + p);
 #pragma unroll
                 for (int e = 0; e < VEC; ++e) tile[(p + e) * LCpad + l] = v.v[e];
             } else {
@@ -92,12 +128,12 @@ transpose_vec_kernel(const T* __restrict__ src, T* __restrict__ dst, int64_t n_p
             V v;
 #pragma unroll
             for (int e = 0; e < VEC; ++e) v.v[e] = (c * VEC + e < nl) ? tile[p * LCpad + c * VEC + e] : T(0);
-            *reinterpret_cast<V*>(dst + (p0 + p) * cols_pitch + l0 + c * VEC) = v;
+            tp_store_vec<TO_COLUMNS && ATX_TP_NT, T, VEC>(dst + (p0 + p) * cols_pitch + l0 + c * VEC, v);
         }
     } else {
         for (int i = tid; i < np * CV; i += kBlock) {
             const int p = i / CV, c = i - p * CV;
-            const V v = *reinterpret_cast<const V*>(src + (p0 + p) * cols_pitch + l0 + c * VEC);
+            const V v = tp_load_vec<TO_COLUMNS && ATX_TP_NT, T, VEC>(src + (p0 + p) * cols_pitch + l0 + c * VEC);
 #pragma unroll
             for (int e = 0; e < VEC; ++e)
                 if (c * VEC + e < nl) tile[p * LCpad + c * VEC + e] = v.v[e];
@@ -110,7 +146,7 @@ transpose_vec_kernel(const T* __restrict__ src, T* __restrict__ dst, int64_t n_p
                 V v;
 #pragma unroll
                 for (int e = 0; e < VEC; ++e) v.v[e] = tile[(p + e) * LCpad + l];
-                *reinterpret_cast<V*>(dst + (int64_t)(l0 + l) * fields_pitch + p0 + p) = v;
+                tp_store_vec<TO_COLUMNS && ATX_TP_NT, T, VEC>(dst + (int64_t)(l0 + l) * fields_pitch + p0 + p, v);
             } else {
                 for (int e = 0; e < VEC; ++e)
                     if (p + e < np) dst[(int64_t)(l0 + l) * fields_pitch + p0 + p + e] = tile[(p + e) * LCpad + l];
