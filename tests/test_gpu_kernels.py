@@ -274,6 +274,28 @@ def test_argument_errors_map_to_reference_exceptions(dev):
         native.regrid_ell(t.cpu(), t.cpu(), i.cpu(), None, n_src=4, n_tgt=4, k=1, n_lev=4, src_pitch=4, out_pitch=4, layout=COLUMNS)
 
 
+def test_reduce_single_launch_finish_with_a_workspace(dev, monkeypatch):
+    """`atx_reduce[_stack]` given a workspace: one launch, partials + ticket, the last workgroup writes the result — here straight
+    into a pinned host cell.  (Off by default: measured slower than per-workgroup atomics on MI355X; the route must stay correct.)"""
+    monkeypatch.setattr(native, "_REDUCE_TICKET", True)
+    rng = np.random.default_rng(18)
+    for np_dtype in (np.float64, np.float32):
+        for n in (4, 4096, 1_000_000, 5_000_001):  # the last one has a tail: falls back to the atomics route inside the library
+            x = make_fields(rng, 1, n, np_dtype)[0]
+            xd = to_dev(x, dev)
+            for _ in range(3):  # the ticket must be back at zero after every call
+                assert native.reduce(xd, native.RED_MINMAX) == (float(x.min()), float(x.max()))
+            assert native.reduce(xd, native.RED_MIN) == float(x.min()) and native.reduce(xd, native.RED_NANCOUNT) == 0.0
+            x[n // 2] = np.nan
+            xd = to_dev(x, dev)
+            assert all(np.isnan(v) for v in native.reduce(xd, native.RED_MINMAX)) and native.reduce(xd, native.RED_NANCOUNT) == 1.0
+        z = make_fields(rng, 37, 20011, np_dtype)
+        st = Stack.from_fields(z, dev=dev)
+        kw = dict(n_pts=st.n_pts, n_lev=st.n_lev, pitch=st.pitch, layout=COLUMNS)
+        assert native.reduce_stack(st.data, native.RED_MINMAX, **kw) == (float(z.min()), float(z.max()))
+        assert native.reduce_stack(st.data, native.RED_MAX, **kw) == float(z.max())
+
+
 # ---------------------------------------------------------------------------------
 # per-point programs
 # ---------------------------------------------------------------------------------
