@@ -599,32 +599,25 @@ __device__ __forceinline__ double red_combine(double a, double b, int red) {
 }
 
 // Two-level finish WITHOUT one atomic per workgroup on the result (a CAS loop on one address: 1 600 workgroups over one 26 MB
-// field spent 10 us of a 43 us call in it, min AND max 57 us; the 8 192 workgroups of a 137-level stack more).  With a caller-provided
-// workspace every workgroup stores its partial(s), takes a ticket, and the LAST one to arrive combines all partials, writes
-// `result` with a plain store — `result` may then be a pinned HOST cell: no init launch, no copy back — and leaves the ticket at 0
-// for the next call on the stream.  Layout: [0] ticket (zeroed once by the caller), [8 ..] partial_a[kRedGrid], partial_b[kRedGrid].
+// field spent 10 us of a 43 us call in it, min AND max 30 us) and without an initialisation launch: with a caller-provided workspace
+// every workgroup stores its partial(s) with plain stores, and a second, one-workgroup launch (reduce_final_kernel) combines them and
+// writes `result` — which may then be a pinned HOST cell: no copy back either.  The kernel boundary is the only synchronisation.
+// (Round 3 first tried a single launch with a ticket — the last workgroup to arrive combines — and measured it SLOWER than the
+// atomics: the device-scope release every workgroup needs before taking its ticket writes the XCD's L2 back; 43 -> 60 us for one
+// field, 0.66 -> 1.0 ms for a 137-level stack.  profiles/r03_small_calls.log.)
 struct RedWorkspace {
-    unsigned long long ticket;
     double a[kRedGrid];
     double b[kRedGrid];
 };
 
-__device__ __forceinline__ void reduce_finish(RedWorkspace* ws, double ta, double tb, int ra, int red, double* result) {
-    __shared__ bool last;
+__global__ void __launch_bounds__(kBlock)
+reduce_final_kernel(const RedWorkspace* __restrict__ ws, int n, int ra, int red, double* result) {
     __shared__ double fa[kBlock / kWave], fb[kBlock / kWave];
-    if (threadIdx.x == 0) {
-        __hip_atomic_store(&ws->a[blockIdx.x], ta, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(&ws->b[blockIdx.x], tb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const unsigned long long t = __hip_atomic_fetch_add(&ws->ticket, 1ull, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-        last = t == (unsigned long long)gridDim.x - 1;
-    }
-    __syncthreads();
-    if (!last) return;
     const double id_a = ra == ATX_RED_MIN ? INFINITY : (ra == ATX_RED_MAX ? -INFINITY : 0.0);
     double a = id_a, b = -INFINITY;
-    for (unsigned i = threadIdx.x; i < gridDim.x; i += kBlock) {
-        a = red_combine(a, __hip_atomic_load(&ws->a[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), ra);
-        if (red == ATX_RED_MINMAX) b = red_combine(b, __hip_atomic_load(&ws->b[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), ATX_RED_MAX);
+    for (int i = threadIdx.x; i < n; i += kBlock) {
+        a = red_combine(a, ws->a[i], ra);
+        if (red == ATX_RED_MINMAX) b = red_combine(b, ws->b[i], ATX_RED_MAX);
     }
 #pragma unroll
     for (int off = kWave / 2; off > 0; off >>= 1) {
@@ -644,7 +637,6 @@ __device__ __forceinline__ void reduce_finish(RedWorkspace* ws, double ta, doubl
         }
         result[0] = xa;
         if (red == ATX_RED_MINMAX) result[1] = xb;
-        __hip_atomic_store(&ws->ticket, 0ull, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
         __threadfence_system();  // `result` may live in pinned host memory
     }
 }
@@ -689,16 +681,12 @@ reduce_kernel(const T* __restrict__ x, int64_t n_rows, int64_t row_len, int64_t 
         double total = partial[0];
         for (int w = 1; w < kBlock / kWave; ++w) total = red_combine(total, partial[w], red);
         if (ws) {
-            partial[0] = total;
+            ws->a[blockIdx.x] = total;
         } else if (red == ATX_RED_NANCOUNT) {
             if (total != 0.0) atomicAdd(result, total);
         } else {
             atomic_minmax(result, total, red == ATX_RED_MAX);
         }
-    }
-    if (ws) {  // uniform
-        __syncthreads();
-        reduce_finish(ws, partial[0], -INFINITY, red, red, result);
     }
 }
 
@@ -771,18 +759,14 @@ reduce_vec_kernel(const T* __restrict__ x, int64_t n_rows, int64_t row_len, int 
             tb = red_combine(tb, pb[w], ATX_RED_MAX);
         }
         if (ws) {
-            pa[0] = ta;
-            pb[0] = tb;
+            ws->a[blockIdx.x] = ta;
+            ws->b[blockIdx.x] = tb;
         } else if (red == ATX_RED_NANCOUNT) {
             if (ta != 0.0) atomicAdd(result, ta);
         } else {
             atomic_minmax(result, ta, !want_min);
             if (red == ATX_RED_MINMAX) atomic_minmax(result + 1, tb, true);
         }
-    }
-    if (ws) {  // uniform
-        __syncthreads();
-        reduce_finish(ws, pa[0], pb[0], ra, red, result);
     }
     (void)want_max;
 }
@@ -1044,8 +1028,8 @@ static int reduce_rows(const void* x, int64_t n_rows, int64_t row_len, int64_t p
     const int64_t vec_len = row_len - tail;
     const int64_t C = (vec_len + vec - 1) / vec;
     const bool vec_ok = aligned16(x) && (n_rows == 1 || (pitch % vec == 0 && C * vec <= pitch)) && C <= 0x7fffffff;
-    // the ticketed finish (no init launch, plain store of the result) serves the single-launch case; everything else — empty
-    // input, a tail after the last whole vector, the scalar fallback's two MINMAX passes — combines through atomics on `result`
+    // the two-level finish (no init launch, no atomics, plain store of the result) serves the single-pass case; everything else —
+    // empty input, a tail after the last whole vector, the scalar fallback's two MINMAX passes — combines through atomics on `result`
     RedWorkspace* ws = static_cast<RedWorkspace*>(workspace);
     const bool single = n_rows > 0 && row_len > 0 && ((vec_ok && tail == 0 && C > 0) || (!vec_ok && red != ATX_RED_MINMAX));
     if (!(ws && single)) {
@@ -1063,6 +1047,11 @@ static int reduce_rows(const void* x, int64_t n_rows, int64_t row_len, int64_t p
             else
                 hipLaunchKernelGGL((reduce_vec_kernel<double, 2>), dim3(grid), dim3(kBlock), 0, s, static_cast<const double*>(x), n_rows, vec_len, (int)C, pitch, red, result, ws);
             ATX_LAUNCH_CHECK("reduce_vec");
+            if (ws) {
+                const int ra = red == ATX_RED_NANCOUNT ? ATX_RED_NANCOUNT : ((red == ATX_RED_MIN || red == ATX_RED_MINMAX) ? ATX_RED_MIN : ATX_RED_MAX);
+                hipLaunchKernelGGL(reduce_final_kernel, dim3(1), dim3(kBlock), 0, s, ws, (int)grid, ra, red, result);
+                ATX_LAUNCH_CHECK("reduce_final");
+            }
         }
         if (tail > 0) {  // combines into the same result cells (atomics): MINMAX as min -> result[0], max -> result[1]
             const size_t esz = dtype == ATX_F32 ? 4 : 8;
@@ -1088,6 +1077,10 @@ static int reduce_rows(const void* x, int64_t n_rows, int64_t row_len, int64_t p
             hipLaunchKernelGGL(reduce_kernel<double>, dim3(grid), dim3(kBlock), 0, s, static_cast<const double*>(x), n_rows, row_len, pitch, r, result + pass, ws);
     }
     ATX_LAUNCH_CHECK("reduce");
+    if (ws) {  // (single pass: MINMAX never comes here with a workspace)
+        hipLaunchKernelGGL(reduce_final_kernel, dim3(1), dim3(kBlock), 0, s, ws, (int)grid, red, red, result);
+        ATX_LAUNCH_CHECK("reduce_final");
+    }
     return ATX_OK;
 }
 

@@ -397,7 +397,7 @@ class _Scratch:
         self.result = torch.zeros(2, dtype=torch.float64, device=device)
         self.host = torch.zeros(2, dtype=torch.float64).pin_memory()
         self.host_count = torch.zeros(1, dtype=torch.int64).pin_memory()
-        self.reduce_ws = torch.zeros(load().atx_reduce_workspace() // 8 + 1, dtype=torch.int64, device=device)  # zeroed ONCE
+        self.reduce_ws = torch.empty(load().atx_reduce_workspace() // 8 + 1, dtype=torch.int64, device=device)
         self.event = torch.cuda.Event()
         self.workspace = torch.empty(4096, dtype=torch.uint8, device=device)
 
@@ -421,10 +421,8 @@ class _Scratch:
         return self.workspace
 
 
-# ATX_REDUCE_TICKET=1: the single-launch ticketed finish of atx_reduce (workspace given).  Measured SLOWER on MI355X than the
-# per-workgroup atomics it avoids — its device-scope release per workgroup writes the XCD's L2 back (one 26 MB field 43 -> 60 us,
-# a 137-level stack 0.66 -> 1.0 ms; profiles/r03_small_calls.log) — so the default passes no workspace.
-_REDUCE_TICKET = os.environ.get("ATX_REDUCE_TICKET", "0") == "1"
+# ATX_REDUCE_WORKSPACE=0 takes the library's route without a workspace (per-workgroup atomics on a device cell + a copy back).
+_REDUCE_TICKET = os.environ.get("ATX_REDUCE_WORKSPACE", "1") == "1"
 
 
 def _reduce_ws(slot: "_Scratch"):

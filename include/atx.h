@@ -266,10 +266,10 @@ typedef enum { ATX_RED_MIN = 0, ATX_RED_MAX = 1, ATX_RED_NANCOUNT = 2, ATX_RED_M
  * min/max ignore nothing (NaN propagates like np.min); NANCOUNT returns the count as a double.
  *   R: filters/fields/cos_sin_from_rad.py:73-76 `data.min()/max()`;
  *      tests/field_filters/test_apply_mask.py:106 `np.sum(np.isnan(result))`
- * workspace (optional, NULL = none): device scratch of atx_reduce_workspace() bytes, 8-byte aligned, ZEROED ONCE by the caller and
- * then reusable for any number of calls on one stream at a time.  With it the reduction is ONE launch that finishes with a plain
- * store — no per-workgroup atomics on `result`, no initialisation launch — and `result` may be a pinned HOST cell the caller reads
- * after synchronising the stream (no copy back).  Without it the workgroups combine through atomics on `result` (device memory). */
+ * workspace (optional, NULL = none): device scratch of atx_reduce_workspace() bytes, 8-byte aligned, usable by one call at a time
+ * per stream (no initialisation needed).  With it the workgroups store partials and a second one-workgroup launch combines them: no
+ * per-workgroup atomics on `result`, no initialisation launch, and `result` may be a pinned HOST cell the caller reads after
+ * synchronising the stream (no copy back).  Without it the workgroups combine through atomics on `result` (device memory). */
 size_t atx_reduce_workspace(void);
 int atx_reduce(const void* x, int64_t n, int red, double* result, int dtype, void* workspace, size_t workspace_bytes, void* stream);
 /* the same over the n_pts x n_lev elements of a (pitched) stack, padding excluded */

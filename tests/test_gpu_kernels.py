@@ -274,16 +274,17 @@ def test_argument_errors_map_to_reference_exceptions(dev):
         native.regrid_ell(t.cpu(), t.cpu(), i.cpu(), None, n_src=4, n_tgt=4, k=1, n_lev=4, src_pitch=4, out_pitch=4, layout=COLUMNS)
 
 
-def test_reduce_single_launch_finish_with_a_workspace(dev, monkeypatch):
-    """`atx_reduce[_stack]` given a workspace: one launch, partials + ticket, the last workgroup writes the result — here straight
-    into a pinned host cell.  (Off by default: measured slower than per-workgroup atomics on MI355X; the route must stay correct.)"""
-    monkeypatch.setattr(native, "_REDUCE_TICKET", True)
+@pytest.mark.parametrize("workspace", [True, False])
+def test_reduce_routes_with_and_without_a_workspace(dev, monkeypatch, workspace):
+    """`atx_reduce[_stack]` given a workspace (the default of native.py): partials, a one-workgroup finish, the result written
+    straight into a pinned host cell; without one: per-workgroup atomics on a device cell."""
+    monkeypatch.setattr(native, "_REDUCE_TICKET", workspace)
     rng = np.random.default_rng(18)
     for np_dtype in (np.float64, np.float32):
         for n in (4, 4096, 1_000_000, 5_000_001):  # the last one has a tail: falls back to the atomics route inside the library
             x = make_fields(rng, 1, n, np_dtype)[0]
             xd = to_dev(x, dev)
-            for _ in range(3):  # the ticket must be back at zero after every call
+            for _ in range(3):  # the workspace is reused call after call
                 assert native.reduce(xd, native.RED_MINMAX) == (float(x.min()), float(x.max()))
             assert native.reduce(xd, native.RED_MIN) == float(x.min()) and native.reduce(xd, native.RED_NANCOUNT) == 0.0
             x[n // 2] = np.nan
