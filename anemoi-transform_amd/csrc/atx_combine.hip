@@ -99,7 +99,21 @@ __device__ __forceinline__ void combine_one(int flags, const T* x, int n_in, T l
             } else if (arg == T(0)) {
                 y0 = arg;
             } else {
-                T sc = tanh(arg);
+                // tanh through expm1: e = expm1(2|x|), tanh|x| = e / (e + 2) — no cancellation anywhere on (0, 2.65], 2-3 ulp — instead
+                // of the device library's tanh (float64: 907 VALU instructions per wave of 4 elements per lane against ~350 this way;
+                // profiles/r03_pmc_sq_combine.txt).  ATX_SNOW_TANH=1 restores the library call.
+#ifndef ATX_SNOW_TANH
+#define ATX_SNOW_TANH 0
+#endif
+                T sc;
+                if constexpr (ATX_SNOW_TANH || sizeof(T) == 4) {
+                    sc = tanh(arg);
+                } else {
+                    const T mag = fabs(arg);  // (only negative arguments get here beyond 2.65: they end up clipped to 0)
+                    const T e = expm1(T(2) * (mag < T(20) ? mag : T(20)));
+                    sc = copysign(mag < T(20) ? e / (e + T(2)) : T(1), arg);  // tanh(20) rounds to 1.0 in float64
+                    if (arg != arg) sc = arg;  // NaN stays NaN
+                }
                 sc = (sc < T(0)) ? T(0) : sc;
                 sc = (sc > T(1)) ? T(1) : sc;
                 y0 = (sc > T(0.99)) ? T(1.0) : sc;

@@ -297,6 +297,28 @@ def test_combine_kernel_vs_oracle(dev, tdtype, np_dtype, rtol, layout):
 
 
 @pytest.mark.gpu
+def test_snow_cover_float64_tanh_within_ulps_of_numpy(dev):
+    """float64 snow_cover evaluates tanh as expm1(2x) / (expm1(2x) + 2) (atx_combine.hip) instead of the device library's tanh: on
+    the arguments where tanh decides the value — (0, 2.65] — the result stays within 4 ulp of numpy's."""
+    from anemoi_transform_amd.stack import Stack
+
+    rng = np.random.default_rng(9)
+    n = 1 << 18
+    arg = np.concatenate([rng.uniform(0.0, 2.65, n // 2), 10.0 ** rng.uniform(-12, 0.4, n // 2)])
+    rsn = rng.uniform(100.0, 400.0, n)
+    sd = arg * rsn * rsn / 4.0e6  # 4000 * (1000 * sd / rsn) / clip(rsn, 100, 400) == arg up to rounding
+    want = oracle.snow_cover(sd[None, :].copy(), rsn[None, :].copy())[0]
+    a, b = Stack.from_fields(sd[None, :], dev=dev), Stack.from_fields(rsn[None, :], dev=dev)
+    out = a.new_like(zero=False)
+    native.combine_stack(native.COMB_SNOW_COVER, [a.data, b.data], [out.data], n_pts=n, n_lev=1, pitch=a.pitch, layout=native.COLUMNS)
+    got = out.numpy()[0]
+    live = (want > 0) & (want < 1)
+    assert live.sum() > n // 2
+    assert float(np.max(np.abs(got[live] - want[live]) / np.spacing(want[live]))) <= 4.0
+    assert np.array_equal(got[~live], want[~live])
+
+
+@pytest.mark.gpu
 def test_fast_sincos_float64_within_ulps_of_numpy(dev):
     """The float64 cos+sin operator reduces moderate arguments itself (atx_combine.hip: sincos_moderate) instead of calling the
     device library's general routine: at most 2 ulp from numpy (each side is within 1 ulp of the true value) on the ranges the
