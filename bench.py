@@ -741,18 +741,24 @@ def single_gpu_lines(args, result, dev, stacks, outs, launch, idx_d, w_d, idx64,
     # the one-off index build on the device instead of cKDTree: raw kernel order, and with equidistant candidates settled by
     # cKDTree (the table the reference builds, bit for bit)
     args4 = (src_grid["latitudes"], src_grid["longitudes"], tgt_grid["latitudes"], tgt_grid["longitudes"])
-    interp.knn_cache_clear()  # the tables of this grid pair are remembered since the precompute above: time a first construction
+    # first constructions, timed on the uncached workers (the tables of this grid pair are remembered — process and files — since
+    # the precompute above; the host tree is forgotten first so that settling the ties pays its build)
+    interp.knn_cache_clear()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    raw_i = interp.nearest_grid_points_device(*args4, num_neighbours_to_return=args.k, ties="index")
+    src_xyz, tgt_xyz = interp.unit_sphere_xyz(*args4[:2]), interp.unit_sphere_xyz(*args4[2:])
+    raw_i = interp.device_knn(src_xyz, tgt_xyz, args.k, ties="index")[0]
     extras["knn_device_s"] = time.perf_counter() - t0
     t0 = time.perf_counter()
-    di = interp.nearest_grid_points_device(*args4, num_neighbours_to_return=args.k)
+    src_xyz, tgt_xyz = interp.unit_sphere_xyz(*args4[:2]), interp.unit_sphere_xyz(*args4[2:])
+    di = interp.device_knn(src_xyz, tgt_xyz, args.k)[0]
     extras["knn_device_ties_settled_s"] = time.perf_counter() - t0
+    del src_xyz, tgt_xyz
+    interp.nearest_grid_points_device(*args4, num_neighbours_to_return=args.k)
     t0 = time.perf_counter()
     again = interp.nearest_grid_points_device(*args4, num_neighbours_to_return=args.k)
     extras["knn_remembered_s"] = time.perf_counter() - t0  # the same request again: process memo (interp._remembered_table)
-    assert np.array_equal(again, di)
+    assert np.array_equal(again.reshape(n_tgt, -1), di)
     del again
     extras["knn_rows_identical_to_ckdtree"] = float((di.reshape(n_tgt, -1) == idx64).all(axis=1).mean())
     extras["knn_rows_identical_to_ckdtree_kernel_order"] = float((raw_i.reshape(n_tgt, -1) == idx64).all(axis=1).mean())

@@ -61,6 +61,16 @@ def bench_line(path: str) -> str:
         f"{r['peak']:.0f} = **{r['frac']:.3f}** on {r['algorithmic_bytes_per_launch'] / 1e9:.3f} GB algorithmic bytes per launch "
         f"(HIP events: avg {r['avg_launch_ms']:.4f} ms, min {r['min_launch_ms']:.4f} ms); traffic {('%.3f GB' % (r['traffic'] / 1e9)) if r.get('traffic') else 'null'}",
     ]
+    shape_csv = os.path.join(ROOT, "profiles", "r03_bench_kernel_by_launch_shape.csv")
+    if os.path.exists(shape_csv):
+        import csv
+
+        rows = list(csv.DictReader(open(shape_csv)))
+        if rows:
+            h = rows[0]  # the shape with the most dispatches: the headline launch
+            lines.append(f"* rocprofv3 `--kernel-trace` of the same command, headline launch shape (`{h['kernel'].replace('atx::', '')}`, {h['grid_x_lanes']} lanes): "
+                         f"{h['calls']} dispatches, average **{float(h['average_ns']) / 1e3:.1f} µs**, min {float(h['min_ns']) / 1e3:.1f} µs "
+                         f"(`profiles/r03_bench_kernel_by_launch_shape.csv`; HIP events of the run under rocprof: `profiles/r03_bench_under_rocprof.json`)")
     for name in ("f32_columns", "f64_columns", "nearest_k1", "nearest_k1_f32", "nearest_k1_f64", "fused_regrid_orog_to_z_convert", "f64_fields", "f32_fields"):
         if name in e:
             lines.append(f"* `extras.{name}`: {e[name]['value']:.4g} grid-points/s, {e[name]['avg_launch_ms']:.4f} ms, {e[name]['frac']:.3f}")
