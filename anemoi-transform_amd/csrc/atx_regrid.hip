@@ -118,7 +118,7 @@ regrid_cols_ell_kernel(EllBatch batch,
                        int64_t n_tgt, int k_rt, int n_lev, int C,
                        int64_t src_pitch, int64_t out_pitch, int tile, unsigned n_tiles,
                        const atx_level_op* __restrict__ prog, int n_stage,
-                       const uint8_t* __restrict__ tgt_mask) {
+                       const uint8_t* __restrict__ tgt_mask, const int32_t* __restrict__ tgt_rows) {
     using V = Pack<T, VEC>;
     // items in flight per lane: the epilogue variant trades half of them for registers (its operator
     // dispatch would otherwise push the kernel from 5 to 2-4 waves per SIMD; 2 vs 4 in flight costs ~1 %)
@@ -246,11 +246,12 @@ regrid_cols_ell_kernel(EllBatch batch,
 #pragma unroll
             for (int u = 0; u < kU; ++u) {
                 if (!ok[u]) continue;
+                const int64_t row = tgt_rows ? (int64_t)tgt_rows[t0 + tt[u]] : t0 + tt[u];  // (uniform branch)
                 if (EPI) {
-                    const bool masked = tgt_mask ? (tgt_mask[t0 + tt[u]] != 0) : false;
+                    const bool masked = tgt_mask ? (tgt_mask[row] != 0) : false;
                     apply_program_vec<T, VEC>(vops_s, prog, n_stage, n_lev, C, cc[u], acc[u], masked);
                 }
-                store_out(reinterpret_cast<V*>(out + (t0 + tt[u]) * out_pitch + (int64_t)cc[u] * VEC), acc[u]);
+                store_out(reinterpret_cast<V*>(out + row * out_pitch + (int64_t)cc[u] * VEC), acc[u]);
             }
         }
     }  // stacks of the batch
@@ -294,7 +295,8 @@ __global__ void __launch_bounds__(kEllBlock)
 regrid_cols_ell_direct_kernel(EllBatch batch, const int32_t* __restrict__ idx, const T* __restrict__ w, int64_t n_items,
                               int C, int64_t src_pitch, int64_t out_pitch, unsigned n_blocks, int items_per_lane,
                               UniformOps<T> uniform, const atx_level_op* __restrict__ vec_prog,
-                              const atx_level_op* __restrict__ prog, int n_stage, int n_lev, const uint8_t* __restrict__ tgt_mask) {
+                              const atx_level_op* __restrict__ prog, int n_stage, int n_lev, const uint8_t* __restrict__ tgt_mask,
+                              const int32_t* __restrict__ tgt_rows) {
     using V = Pack<T, VEC>;
     const T* __restrict__ src = static_cast<const T*>(batch.src[blockIdx.y]);
     T* __restrict__ out = static_cast<T*>(batch.out[blockIdx.y]);
@@ -304,6 +306,9 @@ regrid_cols_ell_direct_kernel(EllBatch batch, const int32_t* __restrict__ idx, c
         if (q >= n_items) return;
         const unsigned t = (unsigned)((uint64_t)q / (unsigned)C);
         const int c = (int)(q - (int64_t)t * C);
+        // ordered traversal: the index / weight table is stored in the order the targets are to be visited (column blocks of the
+        // target grid: vertically adjacent targets meet in L2) and row t of it belongs to output row tgt_rows[t]
+        const unsigned row = tgt_rows ? (unsigned)tgt_rows[t] : t;
         int32_t p[K];
         T wv[K];
 #pragma unroll
@@ -315,7 +320,7 @@ regrid_cols_ell_direct_kernel(EllBatch batch, const int32_t* __restrict__ idx, c
         // latency passes under the gather instead of after it (loaded after the accumulation they cost 9 %: 478 vs 439 us)
         LevelOp<T> pre[kMaxTable];
         bool masked = false;
-        if (EPI == kEpiUniform) masked = tgt_mask ? (tgt_mask[t] != 0) : false;
+        if (EPI == kEpiUniform) masked = tgt_mask ? (tgt_mask[row] != 0) : false;
         if (EPI == kEpiTable) {
 #pragma unroll
             for (int s = 0; s < kMaxTable; ++s) {
@@ -324,7 +329,7 @@ regrid_cols_ell_direct_kernel(EllBatch batch, const int32_t* __restrict__ idx, c
                 pre[s].p0 = pre[s].p1 = T(0);
                 if (s < n_stage) pre[s] = load_level_op<T>(vec_prog, (int64_t)s * C + c);
             }
-            masked = tgt_mask ? (tgt_mask[t] != 0) : false;
+            masked = tgt_mask ? (tgt_mask[row] != 0) : false;
         }
         V v[K];
 #pragma unroll
@@ -372,7 +377,7 @@ regrid_cols_ell_direct_kernel(EllBatch batch, const int32_t* __restrict__ idx, c
                 }
             }
         }
-        store_out(reinterpret_cast<V*>(out + (int64_t)t * out_pitch + (int64_t)c * VEC), acc);
+        store_out(reinterpret_cast<V*>(out + (int64_t)row * out_pitch + (int64_t)c * VEC), acc);
     }
 }
 
@@ -602,6 +607,7 @@ struct Epilogue {
     const atx_level_op* host_prog = nullptr;
     int n_stage = 0;
     const uint8_t* mask = nullptr;
+    const int32_t* tgt_rows = nullptr;  // ordered traversal (atx_regrid_ell_ordered): table row t is output row tgt_rows[t]
 };
 
 // Every operator of the program is COPY, AFFINE or MUL (masked or not) and there are <= kMaxTable stages: the direct
@@ -651,21 +657,21 @@ static int launch_cols_ell(const EllBatch& batch, const int32_t* idx, const T* w
             UniformOps<T> uniform{};
             if (!prog) {
                 hipLaunchKernelGGL((regrid_cols_ell_direct_kernel<T, VEC, K, WEIGHTED, PAD, kEpiNone>), dim3(n_blocks, batch.n), dim3(kEllBlock), 0,
-                                   stream, batch, idx, w, n_items, C, src_pitch, out_pitch, n_blocks, 1, uniform, nullptr, nullptr, 0, n_lev, nullptr);
+                                   stream, batch, idx, w, n_items, C, src_pitch, out_pitch, n_blocks, 1, uniform, nullptr, nullptr, 0, n_lev, nullptr, epi.tgt_rows);
                 ATX_LAUNCH_CHECK("regrid_cols_ell_direct");
                 return ATX_OK;
             }
             if (ATX_EPI_DIRECT && uniform_program<T>(epi, n_lev, VEC, uniform)) {
                 hipLaunchKernelGGL((regrid_cols_ell_direct_kernel<T, VEC, K, WEIGHTED, PAD, kEpiUniform>), dim3(n_blocks, batch.n), dim3(kEllBlock),
                                    0, stream, batch, idx, w, n_items, C, src_pitch, out_pitch, n_blocks, 1, uniform, nullptr, nullptr, n_stage, n_lev,
-                                   tgt_mask);
+                                   tgt_mask, epi.tgt_rows);
                 ATX_LAUNCH_CHECK("regrid_cols_ell_direct_uniform");
                 return ATX_OK;
             }
             if (ATX_EPI_DIRECT && VEC == Vec16<T>::N && madd_family_program(epi, n_lev)) {  // the table is built for 16-byte vectors
                 hipLaunchKernelGGL((regrid_cols_ell_direct_kernel<T, VEC, K, WEIGHTED, PAD, kEpiTable>), dim3(n_blocks, batch.n), dim3(kEllBlock), 0,
                                    stream, batch, idx, w, n_items, C, src_pitch, out_pitch, n_blocks, 1, uniform, epi.vec_prog, prog, n_stage, n_lev,
-                                   tgt_mask);
+                                   tgt_mask, epi.tgt_rows);
                 ATX_LAUNCH_CHECK("regrid_cols_ell_direct_table");
                 return ATX_OK;
             }
@@ -680,10 +686,10 @@ static int launch_cols_ell(const EllBatch& batch, const int32_t* idx, const T* w
     ATX_REQUIRE(lds <= 64 * 1024, ATX_ENOTIMPL, "regrid_ell: tile needs %zu B of LDS (k=%d, n_lev=%d, stages=%d)", lds, k, n_lev, n_stage);
     if (prog) {
         hipLaunchKernelGGL((regrid_cols_ell_kernel<T, VEC, K, WEIGHTED, true, PAD>), dim3(n_tiles, ATX_BATCH_LOOP ? 1 : batch.n), dim3(kEllBlock), lds, stream,
-                           batch, idx, w, n_tgt, k, n_lev, C, src_pitch, out_pitch, tile, n_tiles, prog, n_stage, tgt_mask);
+                           batch, idx, w, n_tgt, k, n_lev, C, src_pitch, out_pitch, tile, n_tiles, prog, n_stage, tgt_mask, epi.tgt_rows);
     } else {
         hipLaunchKernelGGL((regrid_cols_ell_kernel<T, VEC, K, WEIGHTED, false, PAD>), dim3(n_tiles, ATX_BATCH_LOOP ? 1 : batch.n), dim3(kEllBlock), lds, stream,
-                           batch, idx, w, n_tgt, k, n_lev, C, src_pitch, out_pitch, tile, n_tiles, prog, n_stage, tgt_mask);
+                           batch, idx, w, n_tgt, k, n_lev, C, src_pitch, out_pitch, tile, n_tiles, prog, n_stage, tgt_mask, epi.tgt_rows);
     }
     ATX_LAUNCH_CHECK("regrid_cols_ell");
     return ATX_OK;
@@ -882,8 +888,9 @@ static int regrid_ell_common(const char* fn, const void* const* srcs, void* cons
                              const void* w, int64_t n_src, int64_t n_tgt, int32_t k, int64_t n_lev, int64_t src_pitch,
                              int64_t out_pitch, int dtype, int layout, int32_t flags, const atx_level_op* prog,
                              const atx_level_op* vec_prog, const atx_level_op* host_prog, int32_t n_stage, const uint8_t* tgt_mask,
-                             void* stream) {
+                             const int32_t* tgt_rows, void* stream) {
     ATX_REQUIRE(srcs && outs && n_stack >= 1, ATX_EINVAL, "%s: needs at least one stack", fn);
+    ATX_REQUIRE(!tgt_rows || layout == ATX_COLUMNS, ATX_ENOTIMPL, "%s: an ordered traversal (tgt_rows) is available for ATX_COLUMNS stacks only", fn);
     for (int32_t i = 0; i < n_stack; ++i) {
         int st = check_stack_args(fn, srcs[i], outs[i], n_src, n_tgt, n_lev, src_pitch, out_pitch, dtype, layout);
         if (st != ATX_OK) return st;
@@ -905,6 +912,7 @@ static int regrid_ell_common(const char* fn, const void* const* srcs, void* cons
     epi.host_prog = host_prog;
     epi.n_stage = n_stage;
     epi.mask = tgt_mask;
+    epi.tgt_rows = tgt_rows;
     for (int32_t first = 0; first < n_stack; first += kMaxBatch) {
         EllBatch batch;
         batch.n = n_stack - first < kMaxBatch ? n_stack - first : kMaxBatch;
@@ -925,7 +933,7 @@ extern "C" int atx_regrid_ell(const void* src, void* out, const int32_t* idx, co
                               int dtype, int layout, int32_t flags, const atx_level_op* prog, const atx_level_op* vec_prog,
                               const atx_level_op* host_prog, int32_t n_stage, const uint8_t* tgt_mask, void* stream) {
     return regrid_ell_common("atx_regrid_ell", &src, &out, 1, idx, w, n_src, n_tgt, k, n_lev, src_pitch, out_pitch, dtype,
-                             layout, flags, prog, vec_prog, host_prog, n_stage, tgt_mask, stream);
+                             layout, flags, prog, vec_prog, host_prog, n_stage, tgt_mask, nullptr, stream);
 }
 
 extern "C" int atx_regrid_ell_batch(const void* const* srcs, void* const* outs, int32_t n_stack, const int32_t* idx,
@@ -934,7 +942,17 @@ extern "C" int atx_regrid_ell_batch(const void* const* srcs, void* const* outs, 
                                     const atx_level_op* prog, const atx_level_op* vec_prog, const atx_level_op* host_prog,
                                     int32_t n_stage, const uint8_t* tgt_mask, void* stream) {
     return regrid_ell_common("atx_regrid_ell_batch", srcs, outs, n_stack, idx, w, n_src, n_tgt, k, n_lev, src_pitch, out_pitch,
-                             dtype, layout, flags, prog, vec_prog, host_prog, n_stage, tgt_mask, stream);
+                             dtype, layout, flags, prog, vec_prog, host_prog, n_stage, tgt_mask, nullptr, stream);
+}
+
+extern "C" int atx_regrid_ell_ordered(const void* const* srcs, void* const* outs, int32_t n_stack, const int32_t* idx,
+                                      const void* w, const int32_t* tgt_rows, int64_t n_src, int64_t n_tgt, int32_t k, int64_t n_lev,
+                                      int64_t src_pitch, int64_t out_pitch, int dtype, int layout, int32_t flags,
+                                      const atx_level_op* prog, const atx_level_op* vec_prog, const atx_level_op* host_prog,
+                                      int32_t n_stage, const uint8_t* tgt_mask, void* stream) {
+    ATX_REQUIRE(tgt_rows, ATX_EINVAL, "atx_regrid_ell_ordered: null tgt_rows (use atx_regrid_ell_batch for the natural order)");
+    return regrid_ell_common("atx_regrid_ell_ordered", srcs, outs, n_stack, idx, w, n_src, n_tgt, k, n_lev, src_pitch, out_pitch,
+                             dtype, layout, flags, prog, vec_prog, host_prog, n_stage, tgt_mask, tgt_rows, stream);
 }
 
 extern "C" int atx_regrid_csr(const void* src, void* out, const int32_t* indptr, const int32_t* indices,

@@ -23,7 +23,7 @@ import numpy as np
 import torch
 
 from . import native
-from .stack import Stack
+from .stack import COLUMNS, Stack
 
 
 # Cost of one target column relative to one first-touched source column in ``GatherPlan.bounds``.  By bytes alone the stored
@@ -48,6 +48,7 @@ class GatherPlan:
         self.n_src = int(n_src)
         self.n_tgt = int(n_tgt)
         self.padded = bool(padded)
+        self.order: np.ndarray | None = None  # visiting order of the targets on the device (order_targets); results never depend on it
         self._device: dict[tuple[str, torch.dtype], tuple[torch.Tensor, ...]] = {}
         if csr is not None:
             data, indices, indptr = csr
@@ -186,20 +187,44 @@ class GatherPlan:
         """The ``rank``-th of ``world`` contiguous, traffic-balanced slices of the target points."""
         lo, hi = self.shard_range(rank, world)
         if self.kind == "ell":
-            return GatherPlan(self.n_src, hi - lo, index=self.index[lo:hi],
+            part = GatherPlan(self.n_src, hi - lo, index=self.index[lo:hi],
                               weights=None if self.weights is None else self.weights[lo:hi], padded=self.padded)
+            if self.order is not None:  # the slice keeps the visiting order of its own targets
+                inside = self.order[(self.order >= lo) & (self.order < hi)]
+                part.order = (inside - lo).astype(np.int32)
+            return part
         p0, p1 = int(self.indptr[lo]), int(self.indptr[hi])
         return GatherPlan(self.n_src, hi - lo, csr=(self.data[p0:p1], self.indices[p0:p1], self.indptr[lo:hi + 1] - p0))
 
     # ---- device side -------------------------------------------------------------------
-    def _tensors(self, device: torch.device, dtype: torch.dtype) -> tuple[torch.Tensor, ...]:
-        key = (str(device), dtype)
+    def order_targets(self, order: np.ndarray | None) -> "GatherPlan":
+        """Visit the targets in ``order`` (a permutation of ``range(n_tgt)``; ``None``: natural order) on the device —
+        ``atx_regrid_ell_ordered``.  Results are identical; what changes is which targets run together: a lat-lon grid visited in
+        column blocks (``column_block_order``) lets vertically adjacent targets, whose neighbour patches overlap, meet in an XCD's
+        L2 (O1280 -> 0.25 degree: k = 16 +9-12 %, k = 8 +5-9 %; k <= 4 loses 2-7 % to the scattered output rows, so the library's own
+        policy, ``target_order_for``, orders long rows only).  Fixed-k plans on column stacks only; elsewhere the order is ignored."""
+        if order is not None:
+            order = np.ascontiguousarray(order, dtype=np.int64)
+            if order.shape != (self.n_tgt,) or not np.array_equal(np.sort(order), np.arange(self.n_tgt)):
+                raise ValueError("order must be a permutation of range(n_tgt)")
+            order = order.astype(np.int32)
+        self.order = order
+        self._device.clear()
+        return self
+
+    def _tensors(self, device: torch.device, dtype: torch.dtype, ordered: bool = False) -> tuple[torch.Tensor, ...]:
+        ordered = bool(ordered and self.kind == "ell" and self.order is not None)
+        key = (str(device), dtype, ordered)
         if key not in self._device:
             np_dtype = np.float32 if dtype == torch.float32 else np.float64
             if self.kind == "ell":
-                idx = torch.from_numpy(self.index.reshape(-1)).to(device)
-                w = None if self.weights is None else torch.from_numpy(self.weights.astype(np_dtype).reshape(-1)).to(device)
-                self._device[key] = (idx, w)
+                index, weights = self.index, self.weights
+                if ordered:
+                    index, weights = index[self.order], None if weights is None else weights[self.order]
+                idx = torch.from_numpy(np.ascontiguousarray(index).reshape(-1)).to(device)
+                w = None if weights is None else torch.from_numpy(np.ascontiguousarray(weights).astype(np_dtype).reshape(-1)).to(device)
+                rows = torch.from_numpy(self.order).to(device) if ordered else None
+                self._device[key] = (idx, w, rows)
             else:
                 self._device[key] = (
                     torch.from_numpy(self.indptr.astype(np.int32)).to(device),
@@ -217,11 +242,11 @@ class GatherPlan:
         if self.n_tgt == 0:
             return out
         if self.kind == "ell":
-            idx, w = self._tensors(src.device, src.dtype)
+            idx, w, rows = self._tensors(src.device, src.dtype, ordered=src.layout == COLUMNS)
             native.regrid_ell(
                 src.data, out.data, idx, w, n_src=self.n_src, n_tgt=self.n_tgt, k=self.k, n_lev=src.n_lev,
                 src_pitch=src.pitch, out_pitch=out.pitch, layout=src.layout, prog=prog, n_stage=n_stage, tgt_mask=tgt_mask,
-                padded=self.padded,
+                padded=self.padded, **({} if rows is None else {"tgt_rows": rows}),
             )
         else:
             indptr, indices, data = self._tensors(src.device, src.dtype)
@@ -244,10 +269,11 @@ class GatherPlan:
             return [self.apply(s) for s in stacks]
         assert first.n_pts == self.n_src, (first.n_pts, self.n_src)
         outs = [first.new_like(n_pts=self.n_tgt, zero=False) for _ in stacks]
-        idx, w = self._tensors(first.device, first.dtype)
+        idx, w, rows = self._tensors(first.device, first.dtype, ordered=first.layout == COLUMNS)
         native.regrid_ell_batch(
             [s.data for s in stacks], [o.data for o in outs], idx, w, n_src=self.n_src, n_tgt=self.n_tgt, k=self.k,
             n_lev=first.n_lev, src_pitch=first.pitch, out_pitch=outs[0].pitch, layout=first.layout, padded=self.padded,
+            **({} if rows is None else {"tgt_rows": rows}),
         )
         return outs
 
@@ -256,3 +282,43 @@ def equal_count_bounds(n: int, rank: int, world: int) -> tuple[int, int]:
     """Contiguous partition of ``range(n)`` into ``world`` slices of (almost) equal length — for per-point work,
     whose cost is uniform; gathers use ``GatherPlan.bounds`` (balanced by traffic) instead."""
     return (n * rank) // world, (n * (rank + 1)) // world
+
+
+ORDER_MIN_TARGETS = 200_000  # smaller target grids: their whole neighbourhood fits the caches whatever the order
+ORDER_BLOCK_POINTS = 360     # targets across a column block (measured on O1280 -> 0.25 degree, k = 16 and 8: 360 best, 160-256 within 3 %)
+ORDER_MIN_K = 5              # rows of 1-4 neighbours LOSE 2-7 % to the scattered output rows; from 5 on the L2 hits win (k = 8: +5-9 %, k = 16: +9-12 %)
+
+
+def target_order_for(latitudes, longitudes, k: int | None) -> np.ndarray | None:
+    """The library's policy: ``column_block_order`` for fixed-k plans with at least ``ORDER_MIN_K`` neighbours per target, natural
+    order otherwise (profiles/r03_column_blocks_experiment.log: the measured net effect on O1280 -> 0.25 degree, 137 levels)."""
+    if k is None or k < ORDER_MIN_K or latitudes is None or longitudes is None:
+        return None
+    return column_block_order(latitudes, longitudes)
+
+
+def column_block_order(latitudes: np.ndarray, longitudes: np.ndarray, block_points: int | None = None) -> np.ndarray | None:
+    """A visiting order for ``GatherPlan.order_targets``: the target points in bands of longitude about ``block_points`` points
+    wide, each band in the points' own order (row by row for a lat-lon or Gaussian grid).  ``None`` for small or degenerate grids.
+
+    Why: with 4-16 neighbours the source patches of vertically adjacent targets overlap; in row-major order a whole target row of
+    source columns (1440 targets x 3-6 distinct columns x 0.5-1.1 KB = 2-13 MB on O1280 -> 0.25 degree) passes through an XCD's
+    4 MB L2 before the next row asks for them again, in a band of 240 targets a sixth of that
+    (profiles/r03_column_blocks_experiment.log).  The output rows of an ordered launch are written band by band instead of end to
+    end, which costs 2-7 % by itself: see ``target_order_for`` for when the library uses it."""
+    block_points = ORDER_BLOCK_POINTS if block_points is None else block_points
+    lat = np.asarray(latitudes, dtype=np.float64).reshape(-1)
+    lon = np.asarray(longitudes, dtype=np.float64).reshape(-1)
+    n = lat.size
+    if n < ORDER_MIN_TARGETS or lon.size != n:
+        return None
+    lon = np.mod(lon, 360.0)
+    lon_span, lat_span = float(lon.max() - lon.min()), float(lat.max() - lat.min())
+    if lon_span <= 0.0 or lat_span <= 0.0:
+        return None
+    spacing = np.sqrt(lon_span * lat_span / n)  # mean point spacing in degrees
+    n_bands = int(round(lon_span / (block_points * spacing)))
+    if n_bands < 2:
+        return None
+    band = np.minimum(((lon - lon.min()) * (n_bands / lon_span)).astype(np.int64), n_bands - 1)
+    return np.argsort(band, kind="stable").astype(np.int32)

@@ -65,6 +65,11 @@ SIGNATURES: dict[str, tuple[Any, list[Any]]] = {
         [c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_int64, c_int64, c_int32, c_int64, c_int64, c_int64, c_int, c_int,
          c_int32, c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_void_p],
     ),
+    "atx_regrid_ell_ordered": (
+        c_int,
+        [c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int32, c_int64, c_int64, c_int64, c_int, c_int, c_int32,
+         c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_void_p],
+    ),
     "atx_regrid_csr": (
         c_int,
         [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int64, c_int64, c_int64, c_int,
@@ -206,9 +211,14 @@ def _program_companions(prog, dtype) -> tuple[int | None, int | None]:
 
 
 def regrid_ell(src, out, idx, w, *, n_src, n_tgt, k, n_lev, src_pitch, out_pitch, layout, prog=None, n_stage=0,
-               tgt_mask=None, padded: bool = False) -> None:
+               tgt_mask=None, padded: bool = False, tgt_rows=None) -> None:
     """out[t, l] = sum_j w[t, j] * src[idx[t, j], l]; ``w is None`` -> pure k = 1 gather;
-    ``padded``: negative indices are absent entries of padded ragged rows (ATX_ELL_PADDED)."""
+    ``padded``: negative indices are absent entries of padded ragged rows (ATX_ELL_PADDED);
+    ``tgt_rows`` (device int32 permutation): ordered traversal — table row t is output row ``tgt_rows[t]``
+    (``atx_regrid_ell_ordered``; column stacks only)."""
+    if tgt_rows is not None:
+        return regrid_ell_batch([src], [out], idx, w, n_src=n_src, n_tgt=n_tgt, k=k, n_lev=n_lev, src_pitch=src_pitch, out_pitch=out_pitch,
+                                layout=layout, prog=prog, n_stage=n_stage, tgt_mask=tgt_mask, padded=padded, tgt_rows=tgt_rows)
     assert src.dtype == out.dtype, (src.dtype, out.dtype)
     assert idx.dtype == torch.int32
     if w is not None:
@@ -221,9 +231,9 @@ def regrid_ell(src, out, idx, w, *, n_src, n_tgt, k, n_lev, src_pitch, out_pitch
 
 
 def regrid_ell_batch(srcs, outs, idx, w, *, n_src, n_tgt, k, n_lev, src_pitch, out_pitch, layout, prog=None, n_stage=0,
-                     tgt_mask=None, padded: bool = False) -> None:
-    """``regrid_ell`` over several stacks of identical shape in one launch (``atx_regrid_ell_batch``): ``srcs`` / ``outs``
-    are sequences of device tensors."""
+                     tgt_mask=None, padded: bool = False, tgt_rows=None) -> None:
+    """``regrid_ell`` over several stacks of identical shape in one launch (``atx_regrid_ell_batch``; with ``tgt_rows``:
+    ``atx_regrid_ell_ordered``): ``srcs`` / ``outs`` are sequences of device tensors."""
     assert len(srcs) == len(outs) >= 1
     assert idx.dtype == torch.int32
     dtype = srcs[0].dtype
@@ -232,6 +242,14 @@ def regrid_ell_batch(srcs, outs, idx, w, *, n_src, n_tgt, k, n_lev, src_pitch, o
     src_ptrs = (c_void_p * n)(*[_ptr(t) for t in srcs])
     out_ptrs = (c_void_p * n)(*[_ptr(t) for t in outs])
     vec, host = _program_companions(prog, dtype)
+    if tgt_rows is not None:
+        assert tgt_rows.dtype == torch.int32 and tgt_rows.numel() >= n_tgt
+        _call(
+            "atx_regrid_ell_ordered", ctypes.cast(src_ptrs, c_void_p), ctypes.cast(out_ptrs, c_void_p), n, _ptr(idx), _ptr(w), _ptr(tgt_rows),
+            n_src, n_tgt, k, n_lev, src_pitch, out_pitch, dtype_code(dtype), layout, ELL_PADDED if padded else 0, _ptr(prog), vec, host,
+            n_stage, _ptr(tgt_mask), _stream(),
+        )
+        return
     _call(
         "atx_regrid_ell_batch", ctypes.cast(src_ptrs, c_void_p), ctypes.cast(out_ptrs, c_void_p), n, _ptr(idx), _ptr(w), n_src,
         n_tgt, k, n_lev, src_pitch, out_pitch, dtype_code(dtype), layout, ELL_PADDED if padded else 0, _ptr(prog), vec, host, n_stage,

@@ -66,6 +66,7 @@ def parse_args():
                          "the other width is reported in extras")
     ap.add_argument("--layout", default="columns", choices=["columns", "fields"])
     ap.add_argument("--tile", type=int, default=0, help="targets per workgroup (0 = library default)")
+    ap.add_argument("--natural-order", action="store_true", help="visit the targets in row-major order instead of column blocks (A/B)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the secondary lines (N = 1: extras; N > 1: exchange / end-to-end / strong)")
     ap.add_argument("--headline-shape-only", action="store_true",
@@ -116,6 +117,19 @@ def algorithmic_bytes(n_lev, itemsize, n_unique, n_tgt, k):
     if k > 1:
         b += n_tgt * k * itemsize
     return b
+
+
+def ordered_tables(idx, w, grid, lo, hi, np_dtype, dev, natural=False):
+    """Device tables of the targets [lo, hi) in the order the library's policy visits them (gather.target_order_for: column blocks
+    of the target grid for rows of 5 or more neighbours, natural order for the headline's k = 4) + the output row of every table
+    row; (idx, w, None) in natural order."""
+    from anemoi_transform_amd.gather import target_order_for
+
+    order = None if natural else target_order_for(grid["latitudes"][lo:hi], grid["longitudes"][lo:hi], idx.shape[1] if idx.ndim == 2 else 1)
+    pick = slice(None) if order is None else order
+    idx_d = torch.from_numpy(np.ascontiguousarray(idx[lo:hi][pick]).astype(np.int32)).to(dev)
+    w_d = torch.from_numpy(np.ascontiguousarray(w[lo:hi][pick]).astype(np_dtype)).to(dev)
+    return idx_d, w_d, (None if order is None else torch.from_numpy(order).to(dev))
 
 
 def time_launches(fn, steps, warmup):
@@ -264,26 +278,32 @@ def main():
     # target-point shard of this rank: contiguous, balanced by HBM traffic (GatherPlan.bounds) — equal-count
     # shards of a lat-lon target are 1.8x apart in cost (polar targets share their source columns)
     plan = GatherPlan(n_src, n_tgt, index=idx64, weights=w64)
+    if layout == COLUMNS and not args.natural_order:  # shards of the plan (the N > 1 sections) keep the visiting order of their targets
+        from anemoi_transform_amd.gather import target_order_for
+
+        plan.order_targets(target_order_for(tgt_grid["latitudes"], tgt_grid["longitudes"], args.k))
     bounds = plan.bounds(world)
     lo, hi = bounds[rank], bounds[rank + 1]
 
     # ---- sources resident in HBM before the timed region: the N stacks of the step, each a pure function of its id
     stacks = [synth_stack(src_grid, args.levels, tdtype, dev, r, layout) for r in range(world)]
-    idx_d = torch.from_numpy(idx64[lo:hi].astype(np.int32)).to(dev)
-    w_d = torch.from_numpy(w64[lo:hi].astype(np_dtype)).to(dev)
+    # the tables in the order the library's policy visits the targets (natural for the headline's k = 4; column blocks of the target
+    # grid from k = 5 on: GatherPlan.order_targets / atx_regrid_ell_ordered, same results bit for bit)
+    idx_d, w_d, rows_d = ordered_tables(idx64, w64, tgt_grid, lo, hi, np_dtype, dev, natural=layout != COLUMNS or args.natural_order)
     assert native.check_indices(idx_d, n_src) == 0
     outs = [Stack.empty(hi - lo, args.levels, tdtype, dev, layout) for _ in stacks]
 
-    def launch(src, out, idx=idx_d, w=w_d, k=args.k, n_t=hi - lo):
-        native.regrid_ell(src.data, out.data, idx, w if k > 1 else None, n_src=n_src, n_tgt=n_t, k=k,
-                          n_lev=src.n_lev, src_pitch=src.pitch, out_pitch=out.pitch, layout=src.layout)
+    def launch(src, out, idx=None, w=w_d, k=args.k, n_t=hi - lo):
+        rows = rows_d if idx is None else None  # callers that bring their own tables bring them in natural order
+        native.regrid_ell(src.data, out.data, idx_d if idx is None else idx, w if k > 1 else None, n_src=n_src, n_tgt=n_t, k=k,
+                          n_lev=src.n_lev, src_pitch=src.pitch, out_pitch=out.pitch, layout=src.layout, tgt_rows=rows)
 
-    def step():  # one launch over all stacks of the step (atx_regrid_ell_batch: grid.y = stack)
+    def step():  # one launch over all stacks of the step (atx_regrid_ell_batch / _ordered: grid.y = stack)
         if len(stacks) == 1:
             launch(stacks[0], outs[0])
         else:
             native.regrid_ell_batch([s.data for s in stacks], [o.data for o in outs], idx_d, w_d, n_src=n_src, n_tgt=hi - lo,
-                                    k=args.k, n_lev=args.levels, src_pitch=stacks[0].pitch, out_pitch=outs[0].pitch, layout=layout)
+                                    k=args.k, n_lev=args.levels, src_pitch=stacks[0].pitch, out_pitch=outs[0].pitch, layout=layout, tgt_rows=rows_d)
 
     # ---- timed region: W warm-up steps, then exactly K steps between barriers
     for _ in range(args.warmup):
@@ -339,6 +359,7 @@ def main():
             "workload": f"{args.src_grid.upper()} ({n_src} pts) -> {args.tgt_grid} deg lat-lon ({n_tgt} pts), "
                         f"k={args.k} inverse-distance regrid x {args.levels} levels per stack",
             "layout": args.layout,
+            "target_order": "natural (row-major)" if rows_d is None else "column blocks of the target grid (results identical; atx_regrid_ell_ordered: the library's policy for k >= 5)",
             "stacks_per_step": world,
             "sharding": ("target points over ranks (contiguous, traffic-balanced), every rank holds the N source stacks before the timed "
                          "region; `value` EXCLUDES the source exchange, which is measured beside it (source_exchange_ms, end_to_end)")
@@ -378,7 +399,7 @@ def main():
             quiet.__exit__()
 
     if rank == 0 and world == 1 and not args.rehearse_multi:
-        single_gpu_lines(args, result, dev, stacks, outs, launch, idx_d, w_d, idx64, w64, n_src, n_tgt, n_unique, alg, src_grid, tgt_grid,
+        single_gpu_lines(args, result, dev, stacks, outs, launch, idx_d, w_d, rows_d, idx64, w64, n_src, n_tgt, n_unique, alg, src_grid, tgt_grid,
                          tdtype, np_dtype, itemsize)
 
     if rank == 0:
@@ -496,12 +517,11 @@ def multi_gpu_lines(args, result, dist, rank, world, dev, plan, stacks, outs, la
             st.data[:, : args.levels].normal_(250.0 + 5.0 * (i // 4), 20.0, generator=gen)
             srcs.append(st)
         dsts = [Stack.empty(hi4 - lo4, args.levels, t4, dev, COLUMNS) for _ in range(n_stack)]
-        idx_d4 = torch.from_numpy(idx4[lo4:hi4].astype(np.int32)).to(dev)
-        w_d4 = torch.from_numpy(w4[lo4:hi4].astype(np4)).to(dev)
+        idx_d4, w_d4, rows_d4 = ordered_tables(idx4, w4, g_tgt, lo4, hi4, np4, dev, natural=args.natural_order)
 
         def go():
             native.regrid_ell_batch([s.data for s in srcs], [d.data for d in dsts], idx_d4, w_d4, n_src=n4_src, n_tgt=hi4 - lo4, k=4,
-                                    n_lev=args.levels, src_pitch=srcs[0].pitch, out_pitch=dsts[0].pitch, layout=COLUMNS)
+                                    n_lev=args.levels, src_pitch=srcs[0].pitch, out_pitch=dsts[0].pitch, layout=COLUMNS, tgt_rows=rows_d4)
 
         reps = max(3, min(args.steps, 20))
         for _ in range(3):
@@ -657,7 +677,7 @@ def multi_gpu_lines(args, result, dist, rank, world, dev, plan, stacks, outs, la
 # ------------------------------------------------------------------------------------------------------------------------
 # N = 1: parity spot check, CPU baseline, secondary kernel lines, BASELINE configs 2 and 4
 # ------------------------------------------------------------------------------------------------------------------------
-def single_gpu_lines(args, result, dev, stacks, outs, launch, idx_d, w_d, idx64, w64, n_src, n_tgt, n_unique, alg, src_grid, tgt_grid,
+def single_gpu_lines(args, result, dev, stacks, outs, launch, idx_d, w_d, rows_d, idx64, w64, n_src, n_tgt, n_unique, alg, src_grid, tgt_grid,
                      tdtype, np_dtype, itemsize):
     from anemoi_transform_amd import interp, native
     from anemoi_transform_amd.gather import GatherPlan
@@ -728,14 +748,14 @@ def single_gpu_lines(args, result, dev, stacks, outs, launch, idx_d, w_d, idx64,
     extras = {}
     n_lev = args.levels
     # k = 1 nearest-neighbour gather (R: regrid.py:380), same stack
-    idx1 = torch.from_numpy(idx64[:, 0].astype(np.int32).copy()).to(dev)
+    idx1 = torch.from_numpy(idx64[:, 0].astype(np.int32).copy()).to(dev)  # (natural order: the k = 1 lines are the plain gather)
     ms1, _ = time_launches(lambda: launch(stacks[0], outs[0], idx=idx1, w=None, k=1, n_t=n_tgt), 10, 2)
     extras["nearest_k1"] = line(n_tgt * n_lev, ms1, algorithmic_bytes(n_lev, itemsize, int(np.unique(idx64[:, 0]).size), n_tgt, 1))
     # config-5 shape on the same stack: regrid -> orog_to_z -> convert fused in ONE launch
     prog = native.level_program([[(native.OP_MUL, 0, 9.80665, 0.0)] * n_lev, [(native.OP_AFFINE, 0, 1.0, -273.15)] * n_lev], dev)
     msf, _ = time_launches(lambda: native.regrid_ell(
         stacks[0].data, outs[0].data, idx_d, w_d, n_src=n_src, n_tgt=n_tgt, k=args.k, n_lev=n_lev,
-        src_pitch=stacks[0].pitch, out_pitch=outs[0].pitch, layout=stacks[0].layout, prog=prog, n_stage=2), 10, 2)
+        src_pitch=stacks[0].pitch, out_pitch=outs[0].pitch, layout=stacks[0].layout, prog=prog, n_stage=2, tgt_rows=rows_d), 10, 2)
     extras["fused_regrid_orog_to_z_convert"] = line(n_tgt * n_lev, msf, alg)
 
     # the one-off index build on the device instead of cKDTree: raw kernel order, and with equidistant candidates settled by
@@ -772,9 +792,12 @@ def single_gpu_lines(args, result, dev, stacks, outs, launch, idx_d, w_d, idx64,
                                      (f"{args.dtype}_fields", tdtype, np_dtype, itemsize, FIELDS)):
         s = synth_stack(src_grid, n_lev, dt, dev, 0, lay)
         o = Stack.empty(n_tgt, n_lev, dt, dev, lay)
-        wd = torch.from_numpy(w64.astype(npdt)).to(dev)
-        ms, _ = time_launches(lambda: launch(s, o, w=wd), 10, 2)
+        # the other width in the headline's (ordered) traversal; the field-major kernel has no ordered form: natural tables
+        i2, wd, r2 = ordered_tables(idx64, w64, tgt_grid, 0, n_tgt, npdt, dev, natural=lay != COLUMNS or args.natural_order)
+        ms, _ = time_launches(lambda: native.regrid_ell(s.data, o.data, i2, wd, n_src=n_src, n_tgt=n_tgt, k=args.k, n_lev=n_lev, src_pitch=s.pitch,
+                                                        out_pitch=o.pitch, layout=lay, tgt_rows=r2), 10, 2)
         extras[name] = line(n_tgt * n_lev, ms, algorithmic_bytes(n_lev, isz, n_unique, n_tgt, args.k))
+        del i2, r2
         if name.endswith("_columns"):  # the k = 1 gather in the other width too
             ms, _ = time_launches(lambda: launch(s, o, idx=idx1, w=None, k=1, n_t=n_tgt), 10, 2)
             extras[f"nearest_k1_{other[0]}"] = line(n_tgt * n_lev, ms, algorithmic_bytes(n_lev, isz, int(np.unique(idx64[:, 0]).size), n_tgt, 1))
@@ -861,16 +884,15 @@ def config5_case(args, dev, tdtype, np_dtype, rank=0, world=1):
     lo, hi = b5[rank], b5[rank + 1]
     x = synth_stack(g_src, L, tdtype, dev, 0, COLUMNS)
     out = Stack.empty(hi - lo, L, tdtype, dev, COLUMNS)
-    idx_d = torch.from_numpy(idx5[lo:hi].astype(np.int32)).to(dev)
-    w_d = torch.from_numpy(w5[lo:hi].astype(np_dtype)).to(dev)
+    idx_d, w_d, rows_d = ordered_tables(idx5, w5, g_tgt, lo, hi, np_dtype, dev, natural=args.natural_order)
     cp = (native.OP_COPY, 0, 0.0, 0.0)
     prog = native.level_program([[cp] * (L - 1) + [(native.OP_MUL, 0, 9.80665, 0.0)], [(native.OP_AFFINE, 0, 1.0, -273.15)] * (L - 1) + [cp]], dev)
-    kw = dict(n_src=n5_src, n_tgt=hi - lo, k=4, n_lev=L, src_pitch=x.pitch, out_pitch=out.pitch, layout=COLUMNS)
+    kw = dict(n_src=n5_src, n_tgt=hi - lo, k=4, n_lev=L, src_pitch=x.pitch, out_pitch=out.pitch, layout=COLUMNS, tgt_rows=rows_d)
     plain = lambda: native.regrid_ell(x.data, out.data, idx_d, w_d, **kw)  # noqa: E731
     fused = lambda: native.regrid_ell(x.data, out.data, idx_d, w_d, prog=prog, n_stage=2, **kw)  # noqa: E731
     itemsize = 4 if tdtype == torch.float32 else 8
     alg = algorithmic_bytes(L, itemsize, int(np.unique(idx5[lo:hi]).size), hi - lo, 4)
-    return plain, fused, (hi - lo) * L, n5_tgt * L, alg, (x, out, idx_d, w_d, prog)
+    return plain, fused, (hi - lo) * L, n5_tgt * L, alg, (x, out, idx_d, w_d, rows_d, prog)
 
 
 def config4_lines(args, dev, tdtype, np_dtype, itemsize):
@@ -896,13 +918,12 @@ def config4_lines(args, dev, tdtype, np_dtype, itemsize):
     outs = [Stack.empty(n_tgt, n_lev, tdtype, dev, COLUMNS) for _ in range(n_stack)]
 
     def run(lo, hi):
-        idx_d = torch.from_numpy(idx[lo:hi].astype(np.int32)).to(dev)
-        w_d = torch.from_numpy(w[lo:hi].astype(np_dtype)).to(dev)
+        idx_d, w_d, rows_d = ordered_tables(idx, w, tgt, lo, hi, np_dtype, dev, natural=args.natural_order)
         views = [o.data[lo:hi] for o in outs]
 
-        def go():  # atx_regrid_ell_batch: one launch per 16 stacks -> 2 launches for the 24
+        def go():  # atx_regrid_ell_batch / _ordered: one launch per 16 stacks -> 2 launches for the 24
             native.regrid_ell_batch([s.data for s in stacks], views, idx_d, w_d, n_src=n_src, n_tgt=hi - lo, k=k, n_lev=n_lev,
-                                    src_pitch=stacks[0].pitch, out_pitch=outs[0].pitch, layout=COLUMNS)
+                                    src_pitch=stacks[0].pitch, out_pitch=outs[0].pitch, layout=COLUMNS, tgt_rows=rows_d)
 
         ms, _ = time_launches(go, 10, 2)
         u = int(np.unique(idx[lo:hi]).size)

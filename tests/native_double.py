@@ -71,16 +71,23 @@ def _epilogue(levels: np.ndarray, prog, n_stage, mask, n_lev):
 
 
 def regrid_ell(src, out, idx, w, *, n_src, n_tgt, k, n_lev, src_pitch, out_pitch, layout, prog=None, n_stage=0, tgt_mask=None,
-               padded=False):
+               padded=False, tgt_rows=None):
     x = _levels(src, n_src, n_lev, layout)
     y = _levels(out, n_tgt, n_lev, layout)
     index = idx.numpy().reshape(n_tgt, k)
-    if w is None:
+    weights = None if w is None else w.numpy().reshape(n_tgt, k)
+    if tgt_rows is not None:  # ordered traversal: table row t belongs to output row tgt_rows[t] — undo the permutation of the tables
+        rows = tgt_rows.numpy()[:n_tgt]
+        assert sorted(rows.tolist()) == list(range(n_tgt)), "tgt_rows must be a permutation"
+        back = np.empty(n_tgt, dtype=np.int64)
+        back[rows] = np.arange(n_tgt)
+        index = index[back]
+        weights = None if weights is None else weights[back]
+    if weights is None:
         assert k == 1
         for l in range(n_lev):
             y[l] = oracle.gather_nn(x[l], index[:, 0])
     else:
-        weights = w.numpy().reshape(n_tgt, k)
         assert padded or (index >= 0).all()
         present = index >= 0  # ATX_ELL_PADDED: negative index = absent entry of a padded row (atx.h)
         indptr = np.concatenate([[0], np.cumsum(present.sum(axis=1))])

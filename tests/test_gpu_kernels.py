@@ -257,6 +257,61 @@ def test_fused_epilogue_kernel_variants_agree(dev, tdtype, np_dtype, k, padded, 
     assert np.array_equal(full, tiled, equal_nan=True) and np.array_equal(table_only, tiled, equal_nan=True)  # same arithmetic, same bits
 
 
+@pytest.mark.parametrize("tdtype,np_dtype", DTYPES)
+@pytest.mark.parametrize("k,padded,program", [(1, False, None), (4, False, None), (3, True, None), (4, False, "masked_uniform"), (4, False, "per_level"),
+                                              (7, False, None), (7, False, "masked_uniform")])
+def test_ordered_traversal_gives_the_natural_orders_bits(dev, tdtype, np_dtype, k, padded, program):
+    """`atx_regrid_ell_ordered`: the tables permuted into a visiting order + `tgt_rows` give, bit for bit, what the un-permuted
+    tables give — direct kernel (k <= 4, every epilogue route), tiled kernel (k = 7 and a forced tile), one stack and a batch of
+    three, the target mask indexed by OUTPUT row."""
+    rng = np.random.default_rng(31)
+    n_src, n_tgt, n_lev = 5000, 3001, 21
+    x = [make_fields(rng, n_lev, n_src, np_dtype) for _ in range(3)]
+    idx, w = random_ell(rng, n_src, n_tgt, k, np_dtype)
+    if padded:
+        drop = rng.random((n_tgt, k)) < 0.25
+        drop[:, 0] = False
+        idx = np.where(drop, -1, idx).astype(np.int32)
+        w = np.where(drop, 0.0, w).astype(np_dtype)
+    aff, msk = (native.OP_AFFINE, 0, 1.0, -273.15), (native.OP_COPY, 1, 0.0, 0.0)
+    stages = None
+    if program == "masked_uniform":
+        stages = [[aff] * n_lev, [msk] * n_lev]
+    elif program == "per_level":
+        stages = [[(native.OP_AFFINE, 0, 1.0 + 0.01 * l, float(l)) for l in range(n_lev)]]
+    tmask = to_dev((rng.random(n_tgt) < 0.3).astype(np.uint8), dev) if program == "masked_uniform" else None
+    order = rng.permutation(n_tgt).astype(np.int32)
+    srcs = [Stack.from_fields(f, dev=dev) for f in x]
+    weighted = k > 1 or padded
+    tables = {"natural": (to_dev(idx, dev), to_dev(w, dev) if weighted else None, None),
+              "ordered": (to_dev(idx[order], dev), to_dev(w[order], dev) if weighted else None, to_dev(order, dev))}
+
+    def run(which, n_stack, tile=0):
+        i_d, w_d, rows = tables[which]
+        prog = native.level_program(stages, dev) if stages else None
+        outs = [srcs[0].new_like(n_pts=n_tgt) for _ in range(n_stack)]
+        native.set_tuning(tile)
+        try:
+            native.regrid_ell_batch([s.data for s in srcs[:n_stack]], [o.data for o in outs], i_d, w_d, n_src=n_src, n_tgt=n_tgt, k=k, n_lev=n_lev,
+                                    src_pitch=srcs[0].pitch, out_pitch=outs[0].pitch, layout=COLUMNS, prog=prog, n_stage=len(stages) if stages else 0,
+                                    tgt_mask=tmask, padded=padded, tgt_rows=rows)
+        finally:
+            native.set_tuning(0)
+        return [o.numpy() for o in outs]
+
+    for n_stack in (1, 3):
+        for tile in (0, 16):
+            want = run("natural", n_stack, tile)
+            got = run("ordered", n_stack, tile)
+            assert all(np.array_equal(g, v, equal_nan=True) for g, v in zip(got, want)), (n_stack, tile)
+    # field-major stacks have no ordered form: refused, not ignored
+    f = srcs[0].to_layout(FIELDS)
+    with pytest.raises(NotImplementedError):
+        i_d, w_d, rows = tables["ordered"]
+        native.regrid_ell(f.data, f.new_like(n_pts=n_tgt).data, i_d, w_d, n_src=n_src, n_tgt=n_tgt, k=k, n_lev=n_lev, src_pitch=f.pitch,
+                          out_pitch=f.new_like(n_pts=n_tgt).pitch, layout=FIELDS, padded=padded, tgt_rows=rows)
+
+
 def test_check_indices(dev):
     idx = np.array([0, 5, 9, 10, -1, 3], dtype=np.int32)
     assert native.check_indices(to_dev(idx, dev), 10) == 2

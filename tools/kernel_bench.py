@@ -87,7 +87,12 @@ def main():
         U16 = int(np.unique(idx16).size)
         plan16 = GatherPlan(n_src, n_tgt, index=idx16, weights=w16)
         bytes16 = bench.algorithmic_bytes(L, B, U16, n_tgt, 16)
-        record(f"regrid_ell k=16 {tag} columns", timeit(lambda: plan16.apply(x)), bytes16, "fixed k beyond 4: tiled kernel, runtime k")
+        record(f"regrid_ell k=16 {tag} columns", timeit(lambda: plan16.apply(x)), bytes16, "fixed k beyond 4: tiled kernel, runtime k; targets in natural order")
+        from anemoi_transform_amd.gather import target_order_for
+
+        plan16.order_targets(target_order_for(tgt_grid["latitudes"], tgt_grid["longitudes"], 16))
+        record(f"regrid_ell k=16 {tag} columns, targets in column blocks", timeit(lambda: plan16.apply(x)), bytes16,
+               "what regrid(matrix=...) does for k >= 5 on large output grids (atx_regrid_ell_ordered; same bits)")
         rng16 = np.random.default_rng(16)
         keep16 = rng16.random(idx16.shape) < 0.75
         keep16[:, :9] = True
