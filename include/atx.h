@@ -168,7 +168,8 @@ int atx_regrid_ell_batch(const void* const* srcs, void* const* outs, int32_t n_s
  * of 0 .. n_tgt-1, device int32; tgt_mask stays indexed by output row).  The result is identical to atx_regrid_ell_batch on the
  * un-permuted tables, bit for bit — only the order in which the device visits the targets changes.  Visiting a lat-lon target grid
  * in column blocks (each block top to bottom) lets vertically adjacent targets, whose neighbour patches overlap, meet in an XCD's
- * L2: O1280 -> 0.25 degree, 137 levels: k = 16 +8 %, k = 4 +2-3 % (profiles/r03_column_blocks_experiment.log).  ATX_COLUMNS only. */
+ * L2.  Measured on O1280 -> 0.25 degree, 137 levels (profiles/r03_column_blocks_experiment.log): k = 16 +9-12 %, k = 8 +5-9 %;
+ * k <= 4 is 2-7 % SLOWER (the output rows are then written band by band) — order long rows only.  ATX_COLUMNS only. */
 int atx_regrid_ell_ordered(const void* const* srcs, void* const* outs, int32_t n_stack, const int32_t* idx, const void* w,
                            const int32_t* tgt_rows, int64_t n_src, int64_t n_tgt, int32_t k, int64_t n_lev, int64_t src_pitch,
                            int64_t out_pitch, int dtype, int layout, int32_t flags, const atx_level_op* prog,
