@@ -393,7 +393,7 @@ regrid_cols_csr_kernel(const T* __restrict__ src, T* __restrict__ out,
                        const T* __restrict__ data, int64_t n_tgt, int n_lev, int C,
                        int64_t src_pitch, int64_t out_pitch, int tile, unsigned n_tiles, int cap,
                        const atx_level_op* __restrict__ prog, int n_stage,
-                       const uint8_t* __restrict__ tgt_mask) {
+                       const uint8_t* __restrict__ tgt_mask, const int32_t* __restrict__ tgt_rows) {
     using V = Pack<T, VEC>;
     extern __shared__ __align__(16) unsigned char smem[];
     T* w_s = reinterpret_cast<T*>(smem);
@@ -455,11 +455,12 @@ regrid_cols_csr_kernel(const T* __restrict__ src, T* __restrict__ out,
 #pragma unroll
             for (int e = 0; e < VEC; ++e) acc.v[e] = acc.v[e] + wv * v.v[e];
         }
+        const int64_t row = tgt_rows ? (int64_t)tgt_rows[t0 + t] : t0 + t;  // ordered traversal: CSR row t is output row tgt_rows[t]
         if (EPI) {
-            const bool masked = tgt_mask ? (tgt_mask[t0 + t] != 0) : false;
+            const bool masked = tgt_mask ? (tgt_mask[row] != 0) : false;
             apply_program_vec<T, VEC>(vops_s, prog, n_stage, n_lev, C, c, acc, masked);
         }
-        store_out(reinterpret_cast<V*>(out + (t0 + t) * out_pitch + (int64_t)c * VEC), acc);
+        store_out(reinterpret_cast<V*>(out + row * out_pitch + (int64_t)c * VEC), acc);
     }
 }
 
@@ -795,7 +796,7 @@ static int regrid_ell_typed(const EllBatch& batch, const int32_t* idx, const voi
 template <typename T, int VEC>
 static int launch_cols_csr(const T* src, T* out, const int32_t* indptr, const int32_t* indices, const T* data,
                            int64_t n_tgt, int64_t nnz, int n_lev, int64_t sp, int64_t op,
-                           const atx_level_op* prog, int n_stage, const uint8_t* m, hipStream_t st) {
+                           const atx_level_op* prog, int n_stage, const uint8_t* m, const int32_t* rows, hipStream_t st) {
     const int C = (n_lev + VEC - 1) / VEC;
     // (A "direct" form of this kernel — one item per lane, row walked from the CSR arrays in L1 — was measured and dropped: rows of
     // 3-4 entries 0.478 ms against 0.450 ms tiled, rows of 9-16 entries 1.06 against 1.01 ms f32, 2.03 against 2.10 ms f64; with 8
@@ -817,10 +818,10 @@ static int launch_cols_csr(const T* src, T* out, const int32_t* indptr, const in
     ATX_REQUIRE(lds <= 64 * 1024, ATX_ENOTIMPL, "regrid_csr: tile needs %zu B of LDS", lds);
     if (prog) {
         hipLaunchKernelGGL((regrid_cols_csr_kernel<T, VEC, true>), dim3(n_tiles), dim3(kBlock), lds, st, src, out, indptr,
-                           indices, data, n_tgt, n_lev, C, sp, op, tile, n_tiles, cap, prog, n_stage, m);
+                           indices, data, n_tgt, n_lev, C, sp, op, tile, n_tiles, cap, prog, n_stage, m, rows);
     } else {
         hipLaunchKernelGGL((regrid_cols_csr_kernel<T, VEC, false>), dim3(n_tiles), dim3(kBlock), lds, st, src, out, indptr,
-                           indices, data, n_tgt, n_lev, C, sp, op, tile, n_tiles, cap, prog, n_stage, m);
+                           indices, data, n_tgt, n_lev, C, sp, op, tile, n_tiles, cap, prog, n_stage, m, rows);
     }
     ATX_LAUNCH_CHECK("regrid_cols_csr");
     return ATX_OK;
@@ -829,7 +830,7 @@ static int launch_cols_csr(const T* src, T* out, const int32_t* indptr, const in
 template <typename T>
 static int regrid_csr_typed(const void* src_, void* out_, const int32_t* indptr, const int32_t* indices,
                             const void* data_, int64_t n_tgt, int64_t nnz, int n_lev, int64_t sp, int64_t op,
-                            int layout, const atx_level_op* prog, int n_stage, const uint8_t* m, hipStream_t st) {
+                            int layout, const atx_level_op* prog, int n_stage, const uint8_t* m, const int32_t* rows, hipStream_t st) {
     const T* src = static_cast<const T*>(src_);
     T* out = static_cast<T*>(out_);
     const T* data = static_cast<const T*>(data_);
@@ -837,9 +838,10 @@ static int regrid_csr_typed(const void* src_, void* out_, const int32_t* indptr,
         constexpr int VEC = Vec16<T>::N;
         const int64_t covered = ((int64_t)(n_lev + VEC - 1) / VEC) * VEC;
         if (cols_vector_ok<T>(src_, out_, sp, op) && covered <= sp && covered <= op)
-            return launch_cols_csr<T, VEC>(src, out, indptr, indices, data, n_tgt, nnz, n_lev, sp, op, prog, n_stage, m, st);
-        return launch_cols_csr<T, 1>(src, out, indptr, indices, data, n_tgt, nnz, n_lev, sp, op, prog, n_stage, m, st);
+            return launch_cols_csr<T, VEC>(src, out, indptr, indices, data, n_tgt, nnz, n_lev, sp, op, prog, n_stage, m, rows, st);
+        return launch_cols_csr<T, 1>(src, out, indptr, indices, data, n_tgt, nnz, n_lev, sp, op, prog, n_stage, m, rows, st);
     }
+    ATX_REQUIRE(!rows, ATX_ENOTIMPL, "regrid_csr: an ordered traversal (tgt_rows) is available for ATX_COLUMNS stacks only");
     const unsigned n_tiles = (unsigned)((n_tgt + kBlock - 1) / kBlock);
     const int lev_chunk = pick_lev_chunk(n_lev);
     const unsigned n_chunks = (unsigned)((n_lev + lev_chunk - 1) / lev_chunk);
@@ -955,22 +957,39 @@ extern "C" int atx_regrid_ell_ordered(const void* const* srcs, void* const* outs
                              dtype, layout, flags, prog, vec_prog, host_prog, n_stage, tgt_mask, tgt_rows, stream);
 }
 
+static int regrid_csr_common(const char* fn, const void* src, void* out, const int32_t* indptr, const int32_t* indices,
+                             const void* data, int64_t n_src, int64_t n_tgt, int64_t nnz, int64_t n_lev,
+                             int64_t src_pitch, int64_t out_pitch, int dtype, int layout, const atx_level_op* prog,
+                             int32_t n_stage, const uint8_t* tgt_mask, const int32_t* tgt_rows, void* stream) {
+    int st = check_stack_args(fn, src, out, n_src, n_tgt, n_lev, src_pitch, out_pitch, dtype, layout);
+    if (st != ATX_OK) return st;
+    ATX_REQUIRE(indptr, ATX_EINVAL, "%s: null indptr", fn);
+    ATX_REQUIRE(nnz >= 0 && nnz <= INT32_MAX, ATX_ENOTIMPL, "%s: nnz=%lld outside int32", fn, (long long)nnz);
+    ATX_REQUIRE(nnz == 0 || (indices && data), ATX_EINVAL, "%s: null indices/data", fn);
+    ATX_REQUIRE((prog == nullptr) == (n_stage == 0) && n_stage >= 0 && n_stage <= 8, ATX_EINVAL,
+                "%s: prog/n_stage mismatch (n_stage=%d)", fn, n_stage);
+    if (n_tgt == 0) return ATX_OK;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (dtype == ATX_F32)
+        return regrid_csr_typed<float>(src, out, indptr, indices, data, n_tgt, nnz, (int)n_lev, src_pitch, out_pitch, layout, prog, n_stage, tgt_mask, tgt_rows, s);
+    return regrid_csr_typed<double>(src, out, indptr, indices, data, n_tgt, nnz, (int)n_lev, src_pitch, out_pitch, layout, prog, n_stage, tgt_mask, tgt_rows, s);
+}
+
 extern "C" int atx_regrid_csr(const void* src, void* out, const int32_t* indptr, const int32_t* indices,
                               const void* data, int64_t n_src, int64_t n_tgt, int64_t nnz, int64_t n_lev,
                               int64_t src_pitch, int64_t out_pitch, int dtype, int layout, const atx_level_op* prog,
                               int32_t n_stage, const uint8_t* tgt_mask, void* stream) {
-    int st = check_stack_args("atx_regrid_csr", src, out, n_src, n_tgt, n_lev, src_pitch, out_pitch, dtype, layout);
-    if (st != ATX_OK) return st;
-    ATX_REQUIRE(indptr, ATX_EINVAL, "atx_regrid_csr: null indptr");
-    ATX_REQUIRE(nnz >= 0 && nnz <= INT32_MAX, ATX_ENOTIMPL, "atx_regrid_csr: nnz=%lld outside int32", (long long)nnz);
-    ATX_REQUIRE(nnz == 0 || (indices && data), ATX_EINVAL, "atx_regrid_csr: null indices/data");
-    ATX_REQUIRE((prog == nullptr) == (n_stage == 0) && n_stage >= 0 && n_stage <= 8, ATX_EINVAL,
-                "atx_regrid_csr: prog/n_stage mismatch (n_stage=%d)", n_stage);
-    if (n_tgt == 0) return ATX_OK;
-    hipStream_t s = static_cast<hipStream_t>(stream);
-    if (dtype == ATX_F32)
-        return regrid_csr_typed<float>(src, out, indptr, indices, data, n_tgt, nnz, (int)n_lev, src_pitch, out_pitch, layout, prog, n_stage, tgt_mask, s);
-    return regrid_csr_typed<double>(src, out, indptr, indices, data, n_tgt, nnz, (int)n_lev, src_pitch, out_pitch, layout, prog, n_stage, tgt_mask, s);
+    return regrid_csr_common("atx_regrid_csr", src, out, indptr, indices, data, n_src, n_tgt, nnz, n_lev, src_pitch, out_pitch, dtype, layout,
+                             prog, n_stage, tgt_mask, nullptr, stream);
+}
+
+extern "C" int atx_regrid_csr_ordered(const void* src, void* out, const int32_t* indptr, const int32_t* indices,
+                                      const void* data, const int32_t* tgt_rows, int64_t n_src, int64_t n_tgt, int64_t nnz, int64_t n_lev,
+                                      int64_t src_pitch, int64_t out_pitch, int dtype, int layout, const atx_level_op* prog,
+                                      int32_t n_stage, const uint8_t* tgt_mask, void* stream) {
+    ATX_REQUIRE(tgt_rows, ATX_EINVAL, "atx_regrid_csr_ordered: null tgt_rows (use atx_regrid_csr for the natural order)");
+    return regrid_csr_common("atx_regrid_csr_ordered", src, out, indptr, indices, data, n_src, n_tgt, nnz, n_lev, src_pitch, out_pitch, dtype,
+                             layout, prog, n_stage, tgt_mask, tgt_rows, stream);
 }
 
 extern "C" int atx_check_indices(const int32_t* idx, int64_t n, int64_t n_src, int64_t* n_bad, void* stream) {

@@ -50,8 +50,9 @@ def as_griddata(grid: Any) -> dict[str, Any] | None:
 def _ordered(plan: GatherPlan, out_grid: dict) -> GatherPlan:
     """The plan with its targets visited in column blocks of the output grid where that pays — long rows on large grids
     (device-side order only, results identical: ``gather.target_order_for``)."""
-    if plan.kind == "ell" and out_grid.get("latitudes") is not None and len(out_grid["latitudes"]) == plan.n_tgt:
-        order = target_order_for(out_grid["latitudes"], out_grid["longitudes"], plan.k)
+    if out_grid.get("latitudes") is not None and len(out_grid["latitudes"]) == plan.n_tgt and plan.n_tgt > 0:
+        k = plan.k if plan.kind == "ell" else int(round(len(plan.indices) / plan.n_tgt))  # general CSR: the mean row length
+        order = target_order_for(out_grid["latitudes"], out_grid["longitudes"], k)
         if order is not None:
             plan.order_targets(order)
     return plan

@@ -194,7 +194,11 @@ class GatherPlan:
                 part.order = (inside - lo).astype(np.int32)
             return part
         p0, p1 = int(self.indptr[lo]), int(self.indptr[hi])
-        return GatherPlan(self.n_src, hi - lo, csr=(self.data[p0:p1], self.indices[p0:p1], self.indptr[lo:hi + 1] - p0))
+        part = GatherPlan(self.n_src, hi - lo, csr=(self.data[p0:p1], self.indices[p0:p1], self.indptr[lo:hi + 1] - p0))
+        if self.order is not None:
+            inside = self.order[(self.order >= lo) & (self.order < hi)]
+            part.order = (inside - lo).astype(np.int32)
+        return part
 
     # ---- device side -------------------------------------------------------------------
     def order_targets(self, order: np.ndarray | None) -> "GatherPlan":
@@ -202,7 +206,7 @@ class GatherPlan:
         ``atx_regrid_ell_ordered``.  Results are identical; what changes is which targets run together: a lat-lon grid visited in
         column blocks (``column_block_order``) lets vertically adjacent targets, whose neighbour patches overlap, meet in an XCD's
         L2 (O1280 -> 0.25 degree: k = 16 +9-12 %, k = 8 +5-9 %; k <= 4 loses 2-7 % to the scattered output rows, so the library's own
-        policy, ``target_order_for``, orders long rows only).  Fixed-k plans on column stacks only; elsewhere the order is ignored."""
+        policy, ``target_order_for``, orders long rows only).  Column stacks only; field-major stacks ignore the order."""
         if order is not None:
             order = np.ascontiguousarray(order, dtype=np.int64)
             if order.shape != (self.n_tgt,) or not np.array_equal(np.sort(order), np.arange(self.n_tgt)):
@@ -213,7 +217,7 @@ class GatherPlan:
         return self
 
     def _tensors(self, device: torch.device, dtype: torch.dtype, ordered: bool = False) -> tuple[torch.Tensor, ...]:
-        ordered = bool(ordered and self.kind == "ell" and self.order is not None)
+        ordered = bool(ordered and self.order is not None)
         key = (str(device), dtype, ordered)
         if key not in self._device:
             np_dtype = np.float32 if dtype == torch.float32 else np.float64
@@ -226,10 +230,17 @@ class GatherPlan:
                 rows = torch.from_numpy(self.order).to(device) if ordered else None
                 self._device[key] = (idx, w, rows)
             else:
+                indptr, indices, data = self.indptr, self.indices, self.data
+                if ordered:  # the CSR rows in visiting order: row i of the permuted matrix is row order[i] of the original
+                    lengths = np.diff(indptr)[self.order]
+                    new_ptr = np.concatenate([[0], np.cumsum(lengths)])
+                    take = np.repeat(indptr[:-1][self.order] - new_ptr[:-1], lengths) + np.arange(int(new_ptr[-1]))
+                    indptr, indices, data = new_ptr, indices[take], data[take]
                 self._device[key] = (
-                    torch.from_numpy(self.indptr.astype(np.int32)).to(device),
-                    torch.from_numpy(self.indices).to(device),
-                    torch.from_numpy(self.data.astype(np_dtype)).to(device),
+                    torch.from_numpy(np.ascontiguousarray(indptr).astype(np.int32)).to(device),
+                    torch.from_numpy(np.ascontiguousarray(indices)).to(device),
+                    torch.from_numpy(np.ascontiguousarray(data).astype(np_dtype)).to(device),
+                    torch.from_numpy(self.order).to(device) if ordered else None,
                 )
         return self._device[key]
 
@@ -249,11 +260,11 @@ class GatherPlan:
                 padded=self.padded, **({} if rows is None else {"tgt_rows": rows}),
             )
         else:
-            indptr, indices, data = self._tensors(src.device, src.dtype)
+            indptr, indices, data, rows = self._tensors(src.device, src.dtype, ordered=src.layout == COLUMNS)
             native.regrid_csr(
                 src.data, out.data, indptr, indices, data, n_src=self.n_src, n_tgt=self.n_tgt, nnz=len(self.indices),
                 n_lev=src.n_lev, src_pitch=src.pitch, out_pitch=out.pitch, layout=src.layout, prog=prog, n_stage=n_stage,
-                tgt_mask=tgt_mask,
+                tgt_mask=tgt_mask, **({} if rows is None else {"tgt_rows": rows}),
             )
         return out
 

@@ -75,6 +75,11 @@ SIGNATURES: dict[str, tuple[Any, list[Any]]] = {
         [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int64, c_int64, c_int64, c_int,
          c_int, c_void_p, c_int32, c_void_p, c_void_p],
     ),
+    "atx_regrid_csr_ordered": (
+        c_int,
+        [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int64, c_int64, c_int64, c_int,
+         c_int, c_void_p, c_int32, c_void_p, c_void_p],
+    ),
     "atx_check_indices": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_void_p]),
     "atx_pointwise_stack": (
         c_int,
@@ -258,10 +263,18 @@ def regrid_ell_batch(srcs, outs, idx, w, *, n_src, n_tgt, k, n_lev, src_pitch, o
 
 
 def regrid_csr(src, out, indptr, indices, data, *, n_src, n_tgt, nnz, n_lev, src_pitch, out_pitch, layout, prog=None,
-               n_stage=0, tgt_mask=None) -> None:
-    """out[t, l] = sum over the CSR row t of data * src[indices, l] (scipy csr_matvec order)."""
+               n_stage=0, tgt_mask=None, tgt_rows=None) -> None:
+    """out[t, l] = sum over the CSR row t of data * src[indices, l] (scipy csr_matvec order); with ``tgt_rows`` (device int32
+    permutation) CSR row t is output row ``tgt_rows[t]`` (``atx_regrid_csr_ordered``; column stacks only)."""
     assert src.dtype == out.dtype == data.dtype, (src.dtype, out.dtype, data.dtype)
     assert indptr.dtype == torch.int32 and indices.dtype == torch.int32
+    if tgt_rows is not None:
+        assert tgt_rows.dtype == torch.int32 and tgt_rows.numel() >= n_tgt
+        _call(
+            "atx_regrid_csr_ordered", _ptr(src), _ptr(out), _ptr(indptr), _ptr(indices), _ptr(data), _ptr(tgt_rows), n_src, n_tgt, nnz, n_lev,
+            src_pitch, out_pitch, dtype_code(src.dtype), layout, _ptr(prog), n_stage, _ptr(tgt_mask), _stream(),
+        )
+        return
     _call(
         "atx_regrid_csr", _ptr(src), _ptr(out), _ptr(indptr), _ptr(indices), _ptr(data), n_src, n_tgt, nnz, n_lev,
         src_pitch, out_pitch, dtype_code(src.dtype), layout, _ptr(prog), n_stage, _ptr(tgt_mask), _stream(),

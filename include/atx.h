@@ -188,6 +188,12 @@ int atx_regrid_csr(const void* src, void* out, const int32_t* indptr, const int3
                    int64_t src_pitch, int64_t out_pitch, int dtype, int layout,
                    const atx_level_op* prog, int32_t n_stage, const uint8_t* tgt_mask,
                    void* stream);
+/* atx_regrid_csr with an ORDERED traversal: CSR row t (indptr[t] .. indptr[t+1]) is the row of OUTPUT point tgt_rows[t] — see
+ * atx_regrid_ell_ordered; rows of 9-16 entries gain like k = 16 there.  ATX_COLUMNS only. */
+int atx_regrid_csr_ordered(const void* src, void* out, const int32_t* indptr, const int32_t* indices, const void* data,
+                           const int32_t* tgt_rows, int64_t n_src, int64_t n_tgt, int64_t nnz, int64_t n_lev, int64_t src_pitch,
+                           int64_t out_pitch, int dtype, int layout, const atx_level_op* prog, int32_t n_stage,
+                           const uint8_t* tgt_mask, void* stream);
 
 /* Counts entries of idx[0..n) outside [0, n_src) into *n_bad (device int64,
  * zeroed by the call).  cKDTree returns n_src for "no neighbour within

@@ -102,11 +102,16 @@ def regrid_ell_batch(srcs, outs, idx, w, **kw):
 
 
 def regrid_csr(src, out, indptr, indices, data, *, n_src, n_tgt, nnz, n_lev, src_pitch, out_pitch, layout, prog=None,
-               n_stage=0, tgt_mask=None):
+               n_stage=0, tgt_mask=None, tgt_rows=None):
     x = _levels(src, n_src, n_lev, layout)
     y = _levels(out, n_tgt, n_lev, layout)
+    rows = None if tgt_rows is None else tgt_rows.numpy()[:n_tgt]
     for l in range(n_lev):
-        y[l] = oracle.csr_apply(data.numpy(), indices.numpy(), indptr.numpy(), (n_tgt, n_src), np.ascontiguousarray(x[l]))
+        r = oracle.csr_apply(data.numpy(), indices.numpy(), indptr.numpy(), (n_tgt, n_src), np.ascontiguousarray(x[l]))
+        if rows is None:
+            y[l] = r
+        else:  # ordered traversal: CSR row t is output row tgt_rows[t]
+            y[l][rows] = r
     _epilogue(y, prog, n_stage, tgt_mask, n_lev)
 
 

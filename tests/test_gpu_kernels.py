@@ -312,6 +312,35 @@ def test_ordered_traversal_gives_the_natural_orders_bits(dev, tdtype, np_dtype, 
                           out_pitch=f.new_like(n_pts=n_tgt).pitch, layout=FIELDS, padded=padded, tgt_rows=rows)
 
 
+@pytest.mark.parametrize("tdtype,np_dtype", DTYPES)
+@pytest.mark.parametrize("with_prog", [False, True])
+def test_ordered_csr_traversal_gives_the_natural_orders_bits(dev, tdtype, np_dtype, with_prog):
+    """`atx_regrid_csr_ordered` through `GatherPlan.order_targets`: the CSR matrix with its rows permuted into a visiting order +
+    `tgt_rows` equals the un-permuted matrix bit for bit (ragged rows, empty rows, a masked epilogue indexed by output row)."""
+    from anemoi_transform_amd.gather import GatherPlan
+
+    rng = np.random.default_rng(37)
+    n_src, n_tgt, n_lev = 4000, 2500, 19
+    indptr, indices, data = random_csr(rng, n_src, n_tgt, 12, np_dtype)
+    x = Stack.from_fields(make_fields(rng, n_lev, n_src, np_dtype), dev=dev)
+    natural = GatherPlan(n_src, n_tgt, csr=(data, indices, indptr))
+    ordered = GatherPlan(n_src, n_tgt, csr=(data, indices, indptr)).order_targets(rng.permutation(n_tgt))
+    kw = {}
+    if with_prog:
+        stages = [[(native.OP_AFFINE, 0, 1.0, -273.15)] * n_lev, [(native.OP_COPY, 1, 0.0, 0.0)] * n_lev]
+        kw = dict(prog=native.level_program(stages, dev), n_stage=2, tgt_mask=to_dev((rng.random(n_tgt) < 0.3).astype(np.uint8), dev))
+    want = natural.apply(x, **kw).numpy()
+    assert np.array_equal(ordered.apply(x, **kw).numpy(), want, equal_nan=True)
+    native.set_tuning(8)
+    try:
+        assert np.array_equal(ordered.apply(x, **kw).numpy(), want, equal_nan=True)
+    finally:
+        native.set_tuning(0)
+    lo, hi = ordered.shard_range(2, 3)
+    assert np.array_equal(ordered.shard(2, 3).apply(x).numpy(), natural.apply(x).numpy()[:, lo:hi])
+    assert np.array_equal(ordered.apply(x.to_layout(FIELDS)).numpy(), natural.apply(x).numpy())  # field-major: order ignored
+
+
 def test_check_indices(dev):
     idx = np.array([0, 5, 9, 10, -1, 3], dtype=np.int32)
     assert native.check_indices(to_dev(idx, dev), 10) == 2

@@ -52,6 +52,15 @@ def test_ordered_plan_equals_natural_order_on_the_double(monkeypatch, k):
             lo, hi = ordered.shard_range(rank, world)
             assert part.order is not None and np.array_equal(np.sort(part.order), np.arange(hi - lo))
             assert np.array_equal(part.apply(x).numpy(), want[:, lo:hi])
+    if k > 1:  # the same through a general CSR plan (ragged rows): the permuted CSR matrix + tgt_rows
+        keep = (np.arange(idx.size) % 5 != 0).reshape(idx.shape)
+        indptr = np.concatenate([[0], np.cumsum(keep.sum(axis=1))])
+        csr_n = GatherPlan(n_src, n_tgt, csr=(w[keep], idx[keep], indptr))
+        csr_o = GatherPlan(n_src, n_tgt, csr=(w[keep], idx[keep], indptr)).order_targets(order)
+        ref = csr_n.apply(x).numpy()
+        assert np.array_equal(csr_o.apply(x).numpy(), ref)
+        lo, hi = csr_o.shard_range(1, 2)
+        assert np.array_equal(csr_o.shard(1, 2).apply(x).numpy(), ref[:, lo:hi]) and csr_o.shard(1, 2).order is not None
     with pytest.raises(ValueError):
         ordered.order_targets(np.zeros(n_tgt, dtype=np.int64))
     ordered.order_targets(None)

@@ -104,6 +104,9 @@ def main():
         native.set_tuning(tile)
         record(f"regrid_csr rows of 9-16 {tag} columns, TILED kernel", timeit(lambda: csr16.apply(x)), csr16_bytes, "round 1's kernel")
         native.set_tuning(0)
+        csr16.order_targets(target_order_for(tgt_grid["latitudes"], tgt_grid["longitudes"], 12))
+        record(f"regrid_csr rows of 9-16 {tag} columns, targets in column blocks", timeit(lambda: csr16.apply(x)), csr16_bytes,
+               "what regrid(matrix=...) does for long ragged rows on large output grids (atx_regrid_csr_ordered; same bits)")
         del plan16, csr16, idx16, w16
         # coarsening by box averages (a conservative-style matrix): every 1-degree cell averages the ~200 O1280 points inside it
         one = lookup([1.0, 1.0])
