@@ -38,6 +38,7 @@ def main():
     ap.add_argument("--layout", default="columns", choices=["columns", "fields"])
     ap.add_argument("--case", default="ell", choices=["ell", "csr34", "csr916", "box"],
                     help="ell: fixed k (--k); csr34 / csr916: general CSR with ragged rows of 3-4 / 9-16 entries; box: O1280 -> 1 degree box averages (~100 per row)")
+    ap.add_argument("--ordered", action="store_true", help="ell only: visit the targets in column blocks (atx_regrid_ell_ordered)")
     ap.add_argument("--chunk", type=int, default=0, help="ell only: one launch per chunk of this many levels (the level-chunk-major traversal, emulated)")
     ap.add_argument("--meta", default=os.path.join(ROOT, "gpurun_out", "pmc_meta.json"))
     args = ap.parse_args()
@@ -96,11 +97,20 @@ def main():
         cuts = list(range(0, args.levels, chunk)) + [args.levels]
         if len(cuts) > 2:
             config += f" level-chunks={chunk}"
+        rows = None
+        if args.ordered:
+            from anemoi_transform_amd.gather import column_block_order
+
+            order = column_block_order(tgt_grid["latitudes"], tgt_grid["longitudes"])
+            idx = torch.from_numpy(np.ascontiguousarray(idx64[order]).astype(np.int32)).to(dev)
+            w = torch.from_numpy(np.ascontiguousarray(w64[order]).astype(npdt)).to(dev) if args.k > 1 else None
+            rows = torch.from_numpy(order).to(dev)
+            config += " column-block order"
         for _ in range(args.launches):
             for a, b in zip(cuts[:-1], cuts[1:]):
                 s_, o_ = (regrid_src.data[:, a:], regrid_out.data[:, a:]) if len(cuts) > 2 else (regrid_src.data, regrid_out.data)
                 native.regrid_ell(s_, o_, idx, w, n_src=n_src, n_tgt=n_tgt, k=args.k, n_lev=b - a,
-                                  src_pitch=regrid_src.pitch, out_pitch=regrid_out.pitch, layout=regrid_src.layout)
+                                  src_pitch=regrid_src.pitch, out_pitch=regrid_out.pitch, layout=regrid_src.layout, tgt_rows=rows)
     else:
         kernel = "regrid_cols_csr_kernel"
         if args.case == "box":  # every 1-degree cell averages the O1280 points inside it: each source column is read exactly once
