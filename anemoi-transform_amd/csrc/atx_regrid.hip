@@ -685,11 +685,12 @@ static int launch_cols_ell(const EllBatch& batch, const int32_t* idx, const T* w
     lds = (lds + 15) & ~size_t(15);
     if (prog) lds += (size_t)n_stage * C * sizeof(LevelOp<T>);
     ATX_REQUIRE(lds <= 64 * 1024, ATX_ENOTIMPL, "regrid_ell: tile needs %zu B of LDS (k=%d, n_lev=%d, stages=%d)", lds, k, n_lev, n_stage);
+    constexpr int KT = K > 4 ? 0 : K;  // the tiled kernel keeps k > 4 on its runtime-k loop (compile-time k would hold 4 x k vectors per lane)
     if (prog) {
-        hipLaunchKernelGGL((regrid_cols_ell_kernel<T, VEC, K, WEIGHTED, true, PAD>), dim3(n_tiles, ATX_BATCH_LOOP ? 1 : batch.n), dim3(kEllBlock), lds, stream,
+        hipLaunchKernelGGL((regrid_cols_ell_kernel<T, VEC, KT, WEIGHTED, true, PAD>), dim3(n_tiles, ATX_BATCH_LOOP ? 1 : batch.n), dim3(kEllBlock), lds, stream,
                            batch, idx, w, n_tgt, k, n_lev, C, src_pitch, out_pitch, tile, n_tiles, prog, n_stage, tgt_mask, epi.tgt_rows);
     } else {
-        hipLaunchKernelGGL((regrid_cols_ell_kernel<T, VEC, K, WEIGHTED, false, PAD>), dim3(n_tiles, ATX_BATCH_LOOP ? 1 : batch.n), dim3(kEllBlock), lds, stream,
+        hipLaunchKernelGGL((regrid_cols_ell_kernel<T, VEC, KT, WEIGHTED, false, PAD>), dim3(n_tiles, ATX_BATCH_LOOP ? 1 : batch.n), dim3(kEllBlock), lds, stream,
                            batch, idx, w, n_tgt, k, n_lev, C, src_pitch, out_pitch, tile, n_tiles, prog, n_stage, tgt_mask, epi.tgt_rows);
     }
     ATX_LAUNCH_CHECK("regrid_cols_ell");
@@ -700,10 +701,16 @@ template <typename T, int VEC>
 static int dispatch_cols_ell(const EllBatch& batch, const int32_t* idx, const T* w, int64_t n_tgt, int k,
                              int n_lev, int64_t sp, int64_t op, bool pad, const Epilogue& e, hipStream_t st) {
     if (!w) return launch_cols_ell<T, VEC, 1, false>(batch, idx, w, n_tgt, k, n_lev, sp, op, e, st);
-    if (pad) {  // padded ragged rows: the common widths compile-time, the rest runtime
+    // compile-time k up to 8 (the direct kernel: all k loads of an item in flight at once); k = 5 .. 8 moved off the runtime-k tiled
+    // kernel in round 3: k = 8 0.608 -> 0.635 f32, 0.625 -> 0.657 f64, k = 6 0.636 -> 0.650 / 0.659 -> 0.683 (profiles/r03_mid_k_experiment.log)
+    if (pad) {  // padded ragged rows
         switch (k) {
             case 3: return launch_cols_ell<T, VEC, 3, true, true>(batch, idx, w, n_tgt, k, n_lev, sp, op, e, st);
             case 4: return launch_cols_ell<T, VEC, 4, true, true>(batch, idx, w, n_tgt, k, n_lev, sp, op, e, st);
+            case 5: return launch_cols_ell<T, VEC, 5, true, true>(batch, idx, w, n_tgt, k, n_lev, sp, op, e, st);
+            case 6: return launch_cols_ell<T, VEC, 6, true, true>(batch, idx, w, n_tgt, k, n_lev, sp, op, e, st);
+            case 7: return launch_cols_ell<T, VEC, 7, true, true>(batch, idx, w, n_tgt, k, n_lev, sp, op, e, st);
+            case 8: return launch_cols_ell<T, VEC, 8, true, true>(batch, idx, w, n_tgt, k, n_lev, sp, op, e, st);
             default: return launch_cols_ell<T, VEC, 0, true, true>(batch, idx, w, n_tgt, k, n_lev, sp, op, e, st);
         }
     }
@@ -712,6 +719,10 @@ static int dispatch_cols_ell(const EllBatch& batch, const int32_t* idx, const T*
         case 2: return launch_cols_ell<T, VEC, 2, true>(batch, idx, w, n_tgt, k, n_lev, sp, op, e, st);
         case 3: return launch_cols_ell<T, VEC, 3, true>(batch, idx, w, n_tgt, k, n_lev, sp, op, e, st);
         case 4: return launch_cols_ell<T, VEC, 4, true>(batch, idx, w, n_tgt, k, n_lev, sp, op, e, st);
+        case 5: return launch_cols_ell<T, VEC, 5, true>(batch, idx, w, n_tgt, k, n_lev, sp, op, e, st);
+        case 6: return launch_cols_ell<T, VEC, 6, true>(batch, idx, w, n_tgt, k, n_lev, sp, op, e, st);
+        case 7: return launch_cols_ell<T, VEC, 7, true>(batch, idx, w, n_tgt, k, n_lev, sp, op, e, st);
+        case 8: return launch_cols_ell<T, VEC, 8, true>(batch, idx, w, n_tgt, k, n_lev, sp, op, e, st);
         default: return launch_cols_ell<T, VEC, 0, true>(batch, idx, w, n_tgt, k, n_lev, sp, op, e, st);
     }
 }
