@@ -711,6 +711,8 @@ static int dispatch_cols_ell(const EllBatch& batch, const int32_t* idx, const T*
             case 6: return launch_cols_ell<T, VEC, 6, true, true>(batch, idx, w, n_tgt, k, n_lev, sp, op, e, st);
             case 7: return launch_cols_ell<T, VEC, 7, true, true>(batch, idx, w, n_tgt, k, n_lev, sp, op, e, st);
             case 8: return launch_cols_ell<T, VEC, 8, true, true>(batch, idx, w, n_tgt, k, n_lev, sp, op, e, st);
+            case 12: return launch_cols_ell<T, VEC, 12, true, true>(batch, idx, w, n_tgt, k, n_lev, sp, op, e, st);
+            case 16: return launch_cols_ell<T, VEC, 16, true, true>(batch, idx, w, n_tgt, k, n_lev, sp, op, e, st);
             default: return launch_cols_ell<T, VEC, 0, true, true>(batch, idx, w, n_tgt, k, n_lev, sp, op, e, st);
         }
     }
@@ -723,6 +725,12 @@ static int dispatch_cols_ell(const EllBatch& batch, const int32_t* idx, const T*
         case 6: return launch_cols_ell<T, VEC, 6, true>(batch, idx, w, n_tgt, k, n_lev, sp, op, e, st);
         case 7: return launch_cols_ell<T, VEC, 7, true>(batch, idx, w, n_tgt, k, n_lev, sp, op, e, st);
         case 8: return launch_cols_ell<T, VEC, 8, true>(batch, idx, w, n_tgt, k, n_lev, sp, op, e, st);
+        // the two round numbers beyond 8 a k-NN regrid is configured with: all 12 / 16 source vectors in flight beat the tiled kernel's
+        // runtime-k loop (k = 16: 0.46 -> 0.51 f32 in natural order, 0.58 with the targets in column blocks, f64 0.48 -> 0.52 / 0.54);
+        // a runtime-k loop IN the direct kernel, 8 or 16 entries per step, measured no better than the tiled kernel and was dropped
+        // (profiles/r03_long_k_direct_experiment.log)
+        case 12: return launch_cols_ell<T, VEC, 12, true>(batch, idx, w, n_tgt, k, n_lev, sp, op, e, st);
+        case 16: return launch_cols_ell<T, VEC, 16, true>(batch, idx, w, n_tgt, k, n_lev, sp, op, e, st);
         default: return launch_cols_ell<T, VEC, 0, true>(batch, idx, w, n_tgt, k, n_lev, sp, op, e, st);
     }
 }

@@ -115,13 +115,16 @@ class GatherPlan:
         return cls(n_src, n_tgt, csr=(data, indices, indptr))
 
     @classmethod
-    def _padded_rows(cls, n_src, n_tgt, data, indices, indptr, max_k: int = 8, min_fill: float = 0.6) -> "GatherPlan | None":
-        """Short ragged rows as fixed-k rows padded with the index -1 (skipped by the kernel): the fast
-        fixed-k kernel, the CSR summation order, no arithmetic on the padding."""
+    def _padded_rows(cls, n_src, n_tgt, data, indices, indptr, max_k: int = 16, min_fill: float = 0.6) -> "GatherPlan | None":
+        """Ragged rows as fixed-k rows padded with the index -1 (skipped by the kernel): the fast
+        fixed-k kernel, the CSR summation order, no arithmetic on the padding.  Widths the direct kernel has compile-time forms for:
+        up to 8 as they are, 9-12 padded to 12, 13-16 to 16 (round 3: rows of 9-16 entries 0.50-0.55 on the general CSR kernel)."""
         if len(indptr) != n_tgt + 1 or n_tgt == 0:
             return None
         lengths = np.diff(indptr.astype(np.int64))
         k = int(lengths.max()) if lengths.size else 0
+        if 8 < k <= max_k:
+            k = 12 if k <= 12 else 16
         if k < 1 or k > max_k or lengths.sum() < min_fill * k * n_tgt:
             return None
         cols = np.arange(k)[None, :]

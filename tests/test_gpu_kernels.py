@@ -83,7 +83,7 @@ def test_gather_nn_bit_exact(dev, tdtype, np_dtype, layout, n_lev):
 
 @pytest.mark.parametrize("tdtype,np_dtype", DTYPES)
 @pytest.mark.parametrize("layout", LAYOUTS)
-@pytest.mark.parametrize("k", [1, 2, 3, 4, 7])
+@pytest.mark.parametrize("k", [1, 2, 3, 4, 5, 7, 8, 9, 13, 16, 33, 64])
 def test_regrid_ell_matches_csr_matvec(dev, tdtype, np_dtype, layout, k):
     """R: regrid.py:310 — fixed-k rows against scipy's csr_matvec."""
     rng = np.random.default_rng(2 + k)
@@ -259,7 +259,8 @@ def test_fused_epilogue_kernel_variants_agree(dev, tdtype, np_dtype, k, padded, 
 
 @pytest.mark.parametrize("tdtype,np_dtype", DTYPES)
 @pytest.mark.parametrize("k,padded,program", [(1, False, None), (4, False, None), (3, True, None), (4, False, "masked_uniform"), (4, False, "per_level"),
-                                              (7, False, None), (7, False, "masked_uniform")])
+                                              (7, False, None), (7, False, "masked_uniform"), (13, False, None), (13, False, "per_level"),
+                                              (11, True, "masked_uniform")])
 def test_ordered_traversal_gives_the_natural_orders_bits(dev, tdtype, np_dtype, k, padded, program):
     """`atx_regrid_ell_ordered`: the tables permuted into a visiting order + `tgt_rows` give, bit for bit, what the un-permuted
     tables give — direct kernel (k <= 4, every epilogue route), tiled kernel (k = 7 and a forced tile), one stack and a batch of

@@ -104,6 +104,13 @@ def main():
         native.set_tuning(tile)
         record(f"regrid_csr rows of 9-16 {tag} columns, TILED kernel", timeit(lambda: csr16.apply(x)), csr16_bytes, "round 1's kernel")
         native.set_tuning(0)
+        padded16 = GatherPlan.from_matrix(dict(matrix_data=w16[keep16], matrix_indices=idx16[keep16], matrix_indptr=indptr16, matrix_shape=(n_tgt, n_src)))
+        assert padded16.padded and padded16.k == 16
+        record(f"regrid rows of 9-16 as padded fixed-k {tag}", timeit(lambda: padded16.apply(x)), csr16_bytes, "what regrid(matrix=...) uses for ragged rows up to 16 entries")
+        padded16.order_targets(target_order_for(tgt_grid["latitudes"], tgt_grid["longitudes"], 16))
+        record(f"regrid rows of 9-16 as padded fixed-k {tag}, targets in column blocks", timeit(lambda: padded16.apply(x)), csr16_bytes,
+               "the same in the order the regrid filter's policy picks on large output grids")
+        del padded16
         csr16.order_targets(target_order_for(tgt_grid["latitudes"], tgt_grid["longitudes"], 12))
         record(f"regrid_csr rows of 9-16 {tag} columns, targets in column blocks", timeit(lambda: csr16.apply(x)), csr16_bytes,
                "what regrid(matrix=...) does for long ragged rows on large output grids (atx_regrid_csr_ordered; same bits)")
