@@ -298,9 +298,11 @@ def equal_count_bounds(n: int, rank: int, world: int) -> tuple[int, int]:
     return (n * rank) // world, (n * (rank + 1)) // world
 
 
-ORDER_MIN_TARGETS = 200_000  # smaller target grids: their whole neighbourhood fits the caches whatever the order
-ORDER_BLOCK_POINTS = 360     # targets across a column block (measured on O1280 -> 0.25 degree, k = 16 and 8: 360 best, 160-256 within 3 %)
-ORDER_MIN_K = 5              # rows of 1-4 neighbours LOSE 2-7 % to the scattered output rows; from 5 on the L2 hits win (k = 8: +5-9 %, k = 16: +9-12 %)
+import os as _os
+
+ORDER_MIN_TARGETS = int(_os.environ.get("ATX_ORDER_MIN_TARGETS", 200_000))  # smaller target grids: their whole neighbourhood fits the caches whatever the order
+ORDER_BLOCK_POINTS = int(_os.environ.get("ATX_ORDER_BLOCK_POINTS", 360))  # targets across a column block (measured on O1280 -> 0.25 degree, k = 16 and 8: 360 best, 160-256 within 3 %)
+ORDER_MIN_K = int(_os.environ.get("ATX_ORDER_MIN_K", 5))  # (the ATX_ORDER_* variables exist for soak runs of the test suites with the ordered route forced on) rows of 1-4 neighbours LOSE 2-7 % to the scattered output rows; from 5 on the L2 hits win (k = 8: +5-9 %, k = 16: +9-12 %)
 
 
 def target_order_for(latitudes, longitudes, k: int | None) -> np.ndarray | None:
