@@ -597,7 +597,7 @@ static int pick_tile(int64_t n_tgt, int C, bool epilogue) {
     return tile;
 }
 
-static int g_tile_override = 0;  // tuning hook (atx_set_tuning): process-wide, meant for benchmarks and tests (results never depend on it)
+static thread_local int g_tile_override = 0;  // tuning hook (atx_set_tuning): per calling thread, meant for benchmarks and tests (results never depend on it)
 
 // The fused per-level program as the launchers see it: `prog` (device, per level) is always there when n_stage > 0; the two
 // optional companions let the direct kernel take the epilogue — `vec_prog` (device: atx_vector_program of the stack's dtype)

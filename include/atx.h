@@ -112,8 +112,8 @@ const char* atx_strerror(int code);        /* host string, static */
 int atx_device_count(void);
 /* Tuning hook for benchmarks and tests: tile > 0 runs the ATX_COLUMNS regrid through the TILED kernels with that
  * many targets per workgroup; 0 = built-in choice (the direct kernel where it applies, else the tile heuristic).
- * PROCESS-WIDE and unsynchronised — the one exception to "no state": set it before other threads launch, not while
- * they do (a racing launch may pick either kernel; results never depend on it, only speed). */
+ * Per CALLING THREAD (thread-local since round 3: the launches of other threads are not affected); results never depend on it,
+ * only speed. */
 int atx_set_tuning(int tile);
 
 /* ---- regrid: precomputed index(+weight) gather ---------------------------- */
