@@ -146,8 +146,11 @@ def rebase_plan(plan: GatherPlan, lo: int, hi: int) -> GatherPlan:
     """The same plan expressed against the source slab ``[lo, hi)``."""
     if plan.kind == "ell":
         index = plan.index.astype(np.int64)
-        return GatherPlan(hi - lo, plan.n_tgt, index=np.where(index >= 0, index - lo, -1), weights=plan.weights, padded=plan.padded)
-    return GatherPlan(hi - lo, plan.n_tgt, csr=(plan.data, plan.indices.astype(np.int64) - lo, plan.indptr))
+        based = GatherPlan(hi - lo, plan.n_tgt, index=np.where(index >= 0, index - lo, -1), weights=plan.weights, padded=plan.padded)
+    else:
+        based = GatherPlan(hi - lo, plan.n_tgt, csr=(plan.data, plan.indices.astype(np.int64) - lo, plan.indptr))
+    based.order = plan.order  # the same targets, visited in the same order
+    return based
 
 
 def exchange_source_bands(mine: Stack, plan: GatherPlan, comm=None) -> tuple[list[Stack], GatherPlan]:
