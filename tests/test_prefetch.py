@@ -1,0 +1,76 @@
+"""`prefetch_to_device`: the next FieldList goes up while the current one is worked on; the consumer sees the same fields."""
+
+from __future__ import annotations
+
+import numpy as np
+import pytest
+
+import native_double
+from anemoi_transform_amd.fields import fieldlist_from_dicts
+from anemoi_transform_amd.filters import create_filter_by_name
+from anemoi_transform_amd.grids import lookup
+from anemoi_transform_amd.prefetch import prefetch_to_device, to_device
+
+
+def _lists(n_lists, n_fields, seed=0):
+    g = lookup("o16")
+    rng = np.random.default_rng(seed)
+    out = []
+    for d in range(n_lists):
+        out.append(fieldlist_from_dicts([{"param": "t", "levelist": l, "values": 250.0 + rng.standard_normal(len(g["latitudes"])) + d,
+                                          "latitudes": g["latitudes"], "longitudes": g["longitudes"], "valid_datetime": f"2020-01-0{d + 1}T00:00:00Z"}
+                                         for l in range(n_fields)]))
+    return out
+
+
+def test_to_device_keeps_fields_order_and_metadata(monkeypatch):
+    native_double.install(monkeypatch)
+    (fl,) = _lists(1, 5)
+    dev = to_device(fl)
+    assert len(dev) == 5 and all(f.stack_ref() is not None for f in dev)
+    assert len({id(f.stack_ref()[0]) for f in dev}) == 1  # one grid, one stack
+    for a, b in zip(fl, dev):
+        assert np.array_equal(a.to_numpy(flatten=True), b.to_numpy(flatten=True))
+        assert a.metadata("levelist") == b.metadata("levelist") and a.metadata("param") == b.metadata("param")
+        assert np.array_equal(a.grid_points()[0], b.grid_points()[0])
+    again = to_device(dev)  # already there: the same field objects
+    assert all(x is y for x, y in zip(dev, again))
+
+
+def test_prefetch_yields_every_list_in_order_and_filters_run_on_them(monkeypatch):
+    native_double.install(monkeypatch)
+    lists = _lists(4, 3)
+    regrid = create_filter_by_name("regrid", in_grid="o16", out_grid=[10.0, 10.0], method="nearest")
+    want = [[f.to_numpy(flatten=True) for f in regrid.forward(fl)] for fl in lists]
+    got = []
+    for dev_fl in prefetch_to_device(iter(lists), depth=2):
+        assert all(f.stack_ref() is not None for f in dev_fl)
+        got.append([f.to_numpy(flatten=True) for f in regrid.forward(dev_fl)])
+    assert len(got) == 4 and all(np.array_equal(a, b) for x, y in zip(got, want) for a, b in zip(x, y))
+
+
+def test_prefetch_passes_errors_on_and_stops_when_closed(monkeypatch):
+    native_double.install(monkeypatch)
+    lists = _lists(3, 2)
+
+    def broken():
+        yield lists[0]
+        raise RuntimeError("decoder failed")
+
+    it = prefetch_to_device(broken())
+    assert len(next(it)) == 2
+    with pytest.raises(RuntimeError, match="decoder failed"):
+        next(it)
+    seen = []
+
+    def counting():
+        for fl in lists:
+            seen.append(1)
+            yield fl
+
+    it = prefetch_to_device(counting(), depth=1)
+    next(it)
+    it.close()  # the consumer walks away: the producer stops, nothing hangs
+    assert len(seen) <= 3
+    with pytest.raises(ValueError):
+        next(prefetch_to_device(iter(lists), depth=0))

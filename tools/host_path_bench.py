@@ -62,6 +62,31 @@ def main():
     res["filter_forward_plus_to_numpy_ms"] = (t1 - t0) * 1e3
     res["host_fed_grid_points_per_s"] = L * n_tgt / (t1 - t0)
     assert np.array_equal(arrays[-1], back[-1])
+
+    # a job of several FieldLists (dates): one after the other, and with the next upload running ahead (prefetch_to_device)
+    from anemoi_transform_amd.prefetch import prefetch_to_device
+
+    n_lists = 6
+    jobs = [fields] + [FieldList([ArrayField(a + np.float32(d), {"param": "t", "levelist": l + 1}, src["latitudes"], src["longitudes"])
+                                  for l, a in enumerate(host)]) for d in range(1, n_lists)]
+
+    def consume(result):
+        return [f.to_numpy(flatten=True) for f in result]
+
+    sync(); t0 = time.perf_counter()
+    last = None
+    for fl in jobs:
+        last = consume(regrid.forward(fl))
+    sync(); t_seq = time.perf_counter() - t0
+    sync(); t0 = time.perf_counter()
+    last_p = None
+    for dev_fl in prefetch_to_device(iter(jobs), depth=1):
+        last_p = consume(regrid.forward(dev_fl))
+    sync(); t_pre = time.perf_counter() - t0
+    assert np.array_equal(last[-1], last_p[-1])
+    res["job_of_6_lists_sequential_ms_per_list"] = t_seq / n_lists * 1e3
+    res["job_of_6_lists_prefetch_ms_per_list"] = t_pre / n_lists * 1e3
+    res["job_host_fed_grid_points_per_s_prefetch"] = n_lists * L * n_tgt / t_pre
     print(json.dumps(res, indent=1))
 
 
