@@ -187,6 +187,14 @@ def main():
                dst_pitch=f.pitch, src_layout=COLUMNS, dst_layout=FIELDS)), 2 * stack_bytes)
         record(f"relayout fields->columns {tag}", timeit(lambda: native.relayout(f.data, y.data, n_pts=n_src, n_lev=L, src_pitch=f.pitch,
                dst_pitch=y.pitch, src_layout=FIELDS, dst_layout=COLUMNS)), 2 * stack_bytes)
+        # ---- level gather (re-listing / sub-selecting the fields of a stack, operand stacks of the multi-input filters)
+        half = Stack.empty(n_src, 68, tdt, dev, COLUMNS)
+        record(f"select 68 of {L} levels (every other one) {tag}", timeit(lambda: native.select_levels(x.data, half.data, list(range(0, L - 1, 2)), n_pts=n_src, n_src_lev=L,
+               src_pitch=x.pitch, dst_pitch=half.pitch, layout=COLUMNS)), 2 * n_src * 68 * B, "atx_select_levels; the source lines are read whole: 3x the algorithmic bytes")
+        one_lev = Stack.empty(n_src, 1, tdt, dev, COLUMNS)
+        record(f"select 1 of {L} levels {tag}", timeit(lambda: native.select_levels(x.data, one_lev.data, [77], n_pts=n_src, n_src_lev=L, src_pitch=x.pitch,
+               dst_pitch=one_lev.pitch, layout=COLUMNS)), 2 * n_src * B, "one field out of a column stack: a 64-byte sector per point is the least that can move")
+        del half, one_lev
         # ---- regrid on field-major
         record(f"regrid_ell k=4 {tag} fields", timeit(lambda: plan4.apply(f)), bench.algorithmic_bytes(L, B, U4, n_tgt, 4))
         # ---- masks / reductions on one field
