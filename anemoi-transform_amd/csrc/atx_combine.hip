@@ -73,6 +73,10 @@ __device__ __forceinline__ bool sincos_moderate(double x, double& sn, double& cs
     return true;
 }
 
+#ifndef ATX_FAST_SINCOS
+#define ATX_FAST_SINCOS 1
+#endif
+
 // g = 9.80665 (R: constants.py:13, value pinned by filters/tabular/geopotential_to_height.py:51)
 // OP is a template parameter: every operator gets its own kernel.  With a runtime switch the float64 kernels carried the
 // inlined tanh, sincos and atan2 bodies for EVERY operator — 164-180 VGPRs, 2-3 waves per SIMD, even for `a - b` (round 2 called
@@ -123,9 +127,6 @@ __device__ __forceinline__ void combine_one(int flags, const T* x, int n_in, T l
         case ATX_COMB_COS_SIN: {
             T a = x[0];
             if (flags & ATX_COMB_DEGREES) a = a * T(0.017453292519943295);  // np.deg2rad: x * (pi/180)
-#ifndef ATX_FAST_SINCOS
-#define ATX_FAST_SINCOS 1
-#endif
             if constexpr (ATX_FAST_SINCOS && sizeof(T) == 8) {
                 double sn, cs;
                 if (sincos_moderate((double)a, sn, cs)) {
@@ -165,6 +166,28 @@ __device__ __forceinline__ void combine_one(int flags, const T* x, int n_in, T l
             break;
         }
         case ATX_COMB_SUB: y0 = x[0] - x[1]; break;
+        case ATX_COMB_XY_TO_POLAR: {  // earthkit.meteo.wind.array.xy_to_polar(u, v, convention="meteo"): numpy's statements, one rounding each
+            y0 = hypot(x[0], x[1]);
+            T d = T(270.0) - atan2(x[1], x[0]) * T(57.29577951308232);  // constants.degree = 180 / pi
+            d = fmod(d, T(360.0));                                       // np.mod(d, 360): the result takes the divisor's sign
+            if (d < T(0)) d = d + T(360.0);
+            y1 = d;
+            break;
+        }
+        case ATX_COMB_POLAR_TO_XY: {  // polar_to_xy(speed, direction, convention="meteo")
+            const T a = (T(270.0) - x[1]) * T(0.017453292519943295);    // constants.radian = pi / 180
+            if constexpr (ATX_FAST_SINCOS && sizeof(T) == 8) {
+                double sn, cs;
+                if (sincos_moderate((double)a, sn, cs)) {
+                    y0 = x[0] * (T)cs;
+                    y1 = x[0] * (T)sn;
+                    break;
+                }
+            }
+            y0 = x[0] * cos(a);
+            y1 = x[0] * sin(a);
+            break;
+        }
         default: y0 = x[0]; break;
     }
 }
@@ -330,6 +353,8 @@ static int combine_typed(const CombArgs& a, int op, int flags, int n_in, int n_o
         ATX_COMB_CASE(ATX_COMB_W_TO_WZ, 3);
         ATX_COMB_CASE(ATX_COMB_WZ_TO_W, 3);
         ATX_COMB_CASE(ATX_COMB_SUB, 2);
+        ATX_COMB_CASE(ATX_COMB_XY_TO_POLAR, 2);
+        ATX_COMB_CASE(ATX_COMB_POLAR_TO_XY, 2);
         default:  // ATX_COMB_SUM
             if (vec_ok) {
                 if (n_in <= 1) ATX_COMB_LAUNCH(VEC, 1, ATX_COMB_SUM);
@@ -357,8 +382,8 @@ using namespace atx;
 extern "C" int atx_combine_stack(int op, const void* const* inputs, int32_t n_in, void* const* outputs, int32_t n_out,
                                  int64_t n_pts, int64_t n_lev, int64_t pitch, int dtype, int layout,
                                  const double* level_param, int32_t flags, void* stream) {
-    static const int kIn[ATX_COMB_COUNT_] = {2, 2, 1, 2, 3, 3, -1, 2};
-    static const int kOut[ATX_COMB_COUNT_] = {1, 1, 2, 1, 1, 1, 1, 1};
+    static const int kIn[ATX_COMB_COUNT_] = {2, 2, 1, 2, 3, 3, -1, 2, 2, 2};
+    static const int kOut[ATX_COMB_COUNT_] = {1, 1, 2, 1, 1, 1, 1, 1, 2, 2};
     ATX_REQUIRE(op >= 0 && op < ATX_COMB_COUNT_, ATX_EINVAL, "atx_combine_stack: bad operator %d", op);
     ATX_REQUIRE(inputs && outputs, ATX_EINVAL, "atx_combine_stack: null pointer table");
     ATX_REQUIRE(n_in >= 1 && n_in <= ATX_COMB_MAX_INPUTS, ATX_EINVAL, "atx_combine_stack: n_in=%d outside [1, %d]", n_in, ATX_COMB_MAX_INPUTS);

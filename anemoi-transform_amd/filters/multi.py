@@ -475,6 +475,41 @@ filter_registry.register("w_to_wz", VerticalVelocity)
 filter_registry.register("wz_to_w", VerticalVelocity.reversed)
 
 
+class WindComponents(StackMatchingFilter):
+    """U and V wind components -> wind speed and direction (the direction the wind blows FROM, degrees clockwise from north), and back
+    (R: filters/fields/uv_to_ddff.py:23-128).  The reference delegates the arithmetic to earthkit-meteo's ``xy_to_polar`` /
+    ``polar_to_xy`` (absent here): its published "meteo" convention is restated in ``atx_combine_stack`` and pinned by the
+    reference's own test vectors (tests/field_filters/test_uv_to_ddff.py)."""
+
+    MATCHING = MatchingSpec(select="param", forward=("u_component", "v_component"), backward=("wind_speed", "wind_direction"))
+
+    def __init__(self, *, u_component: str = "u", v_component: str = "v", wind_speed: str = "ws", wind_direction: str = "wdir",
+                 convention: str = "meteo", radians: bool = False) -> None:
+        self.u_component, self.v_component = u_component, v_component
+        self.wind_speed, self.wind_direction = wind_speed, wind_direction
+        self.convention, self.radians = convention, radians
+        assert not self.radians, "Radians not (yet) supported"  # R: uv_to_ddff.py:74
+        if convention != "meteo":
+            raise NotImplementedError(f"wind convention {convention!r}: only 'meteo' is implemented on the device")
+        super().__init__()
+
+    def forward_plan(self, u_component: Any, v_component: Any):
+        return native.COMB_XY_TO_POLAR, 0, [(u_component, dict(param=self.wind_speed)), (v_component, dict(param=self.wind_direction))], None
+
+    def backward_plan(self, wind_speed: Any, wind_direction: Any):
+        return native.COMB_POLAR_TO_XY, 0, [(wind_speed, dict(param=self.u_component)), (wind_direction, dict(param=self.v_component))], None
+
+    def forward_transform(self, u_component: Any = None, v_component: Any = None) -> Iterator[Any]:
+        return super().forward_transform(u_component=u_component, v_component=v_component)
+
+    def backward_transform(self, wind_speed: Any = None, wind_direction: Any = None) -> Iterator[Any]:
+        return super().backward_transform(wind_speed=wind_speed, wind_direction=wind_direction)
+
+
+filter_registry.register("uv_to_ddff", WindComponents)
+filter_registry.register("ddff_to_uv", WindComponents.reversed)
+
+
 @filter_registry.register("sum")
 class Sum(Filter):
     """Replace ``params`` by their sum ``output``, per date / level / member (R: sum.py:25-121).

@@ -38,7 +38,8 @@ CMP_GT, CMP_LT, CMP_EQ, CMP_NE, CMP_GE, CMP_LE, CMP_NOTNAN, CMP_ISNAN = range(8)
     OP_SET_NAN,
 ) = range(10)
 RED_MIN, RED_MAX, RED_NANCOUNT, RED_MINMAX = range(4)
-COMB_SNOW_DEPTH_M, COMB_SNOW_COVER, COMB_COS_SIN, COMB_ATAN2, COMB_W_TO_WZ, COMB_WZ_TO_W, COMB_SUM, COMB_SUB = range(8)
+(COMB_SNOW_DEPTH_M, COMB_SNOW_COVER, COMB_COS_SIN, COMB_ATAN2, COMB_W_TO_WZ, COMB_WZ_TO_W, COMB_SUM, COMB_SUB, COMB_XY_TO_POLAR,
+ COMB_POLAR_TO_XY) = range(10)
 COMB_DEGREES = 1
 COMB_MAX_INPUTS = 8
 

@@ -245,7 +245,10 @@ typedef enum {
     ATX_COMB_WZ_TO_W = 5,      /* (wz, t, q) -> -1.0*rho*g*wz          R: w_to_wz.py:124-126                       */
     ATX_COMB_SUM = 6,          /* (c0, c1, ...) -> ((c0 + c1) + ...) in input order   R: filters/fields/sum.py:109-116 */
     ATX_COMB_SUB = 7,          /* (a, b) -> a - b                      R: filters/fields/accum_to_interval.py:98   */
-    ATX_COMB_COUNT_ = 8
+    ATX_COMB_XY_TO_POLAR = 8,  /* (u, v) -> (hypot(u, v), mod(270 - atan2(v, u)*180/pi, 360)): speed and the direction the wind blows FROM,
+                                  the "meteo" convention of earthkit.meteo.wind.array.xy_to_polar      R: filters/fields/uv_to_ddff.py:93-97   */
+    ATX_COMB_POLAR_TO_XY = 9,  /* (speed, dir) -> (speed*cos(a), speed*sin(a)), a = (270 - dir)*pi/180   R: uv_to_ddff.py:121-125         */
+    ATX_COMB_COUNT_ = 10
 } atx_comb;
 #define ATX_COMB_DEGREES 1
 #define ATX_COMB_MAX_INPUTS 8

@@ -533,6 +533,24 @@ def direction_from_cos_sin(cos_values, sin_values, degrees: bool = False):
     return d
 
 
+def xy_to_polar(u, v):
+    """R: filters/fields/uv_to_ddff.py:93-97 calls ``earthkit.meteo.wind.array.xy_to_polar(u, v, convention="meteo")`` — third-party
+    (earthkit-meteo >= 0.4.1, absent here).  Its published definition, restated: speed = hypot(u, v); direction = the direction the
+    wind blows FROM, clockwise from north, ``mod(270 - atan2(v, u) * 180 / pi, 360)``.  Pinned by the reference's own vectors
+    (tests/field_filters/test_uv_to_ddff.py:24-43, ``np.allclose``), not bit for bit."""
+    speed = np.hypot(u, v)
+    direction = np.mod(270.0 - np.arctan2(v, u) * (180.0 / np.pi), 360.0)
+    return speed, direction.astype(speed.dtype, copy=False)
+
+
+def polar_to_xy(speed, direction):
+    """R: uv_to_ddff.py:121-125 calls ``earthkit.meteo.wind.array.polar_to_xy(speed, direction, convention="meteo")``: with
+    a = (270 - direction) * pi / 180, u = speed * cos(a), v = speed * sin(a).  Pinned like ``xy_to_polar``."""
+    a = (270.0 - direction) * (np.pi / 180.0)
+    a = a.astype(np.asarray(speed).dtype, copy=False)
+    return speed * np.cos(a), speed * np.sin(a)
+
+
 def w_to_wz(w, t, q, level):
     """R: filters/fields/w_to_wz.py:97-99."""
     rho = (100 * level) / (287 * t * (1 + 0.61 * q) + 1e-8)

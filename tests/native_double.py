@@ -150,6 +150,10 @@ def combine_stack(op, inputs, outputs, *, n_pts, n_lev, pitch, layout, level_par
             ys[0][l] = oracle.sum_fields(a)
         elif op == native.COMB_SUB:
             ys[0][l] = oracle.interval_difference(a[0], a[1])
+        elif op == native.COMB_XY_TO_POLAR:
+            ys[0][l], ys[1][l] = oracle.xy_to_polar(a[0], a[1])
+        elif op == native.COMB_POLAR_TO_XY:
+            ys[0][l], ys[1][l] = oracle.polar_to_xy(a[0], a[1])
         else:
             raise ValueError(op)
     for y in ys:

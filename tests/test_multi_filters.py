@@ -4,6 +4,9 @@ test_snow.py, test_sum.py, tests/test_matching.py, tests/test_grouping.py."""
 
 from __future__ import annotations
 
+import json
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -18,6 +21,8 @@ from oracle import oracle
 
 import native_double
 from test_filters import collect_fields_by_param, test_source
+
+GOLDEN = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_vectors.json")))
 
 MD = {"latitudes": [10.0, 0.0, -10.0], "longitudes": [20, 40.0], "valid_datetime": "2018-08-01T09:00:00Z"}
 
@@ -41,6 +46,48 @@ def engine(request, monkeypatch):
 def mars_test_source(dataset):
     """R: tests/conftest.py:70-80 — fields that expose a MARS namespace."""
     return source_registry.create("testing", dataset=fieldlist_from_dicts(dataset, mars=True))
+
+
+# ---- wind components ------------------------------------------------------------------------
+def _wind_specs(names):
+    g = GOLDEN["uv_to_ddff"]
+    specs = []
+    for level in g["levels"]:
+        for param, key in names:
+            specs.append({"param": param, "levelist": level, "values": np.array(g[key][str(level)]), **MD})
+    return g, specs
+
+
+def test_uv_to_ddff(engine):
+    """R: tests/field_filters/test_uv_to_ddff.py:67-80 — the reference's literal expectations."""
+    g, specs = _wind_specs([("u", "u"), ("v", "v")])
+    out = collect_fields_by_param(test_source(specs) | create_filter_by_name("uv_to_ddff"))
+    assert set(out) == {"ws", "wdir"} and len(out["ws"]) == 2 and len(out["wdir"]) == 2
+    for i, level in enumerate(g["levels"]):
+        assert np.allclose(out["ws"][i].to_numpy(), np.array(g["ws"][str(level)]))
+        assert np.allclose(out["wdir"][i].to_numpy(), np.array(g["wdir"][str(level)]))
+        assert out["ws"][i].metadata("levelist") == level and out["wdir"][i].metadata("levelist") == level
+
+
+def test_ddff_to_uv_and_round_trips(engine):
+    """R: test_uv_to_ddff.py:83-130."""
+    g, specs = _wind_specs([("ws", "ws"), ("wdir", "wdir")])
+    src = test_source(specs)
+    out = collect_fields_by_param(src | create_filter_by_name("ddff_to_uv"))
+    assert set(out) == {"u", "v"}
+    for i, level in enumerate(g["levels"]):
+        assert np.allclose(out["u"][i].to_numpy(), np.array(g["u"][str(level)])) and np.allclose(out["v"][i].to_numpy(), np.array(g["v"][str(level)]))
+        assert out["u"][i].metadata("levelist") == level
+    back = collect_fields_by_param((src | create_filter_by_name("ddff_to_uv")) | create_filter_by_name("uv_to_ddff"))
+    assert set(back) == {"ws", "wdir"}
+    for i, level in enumerate(g["levels"]):
+        assert np.allclose(back["ws"][i].to_numpy(), np.array(g["ws"][str(level)])) and np.allclose(back["wdir"][i].to_numpy(), np.array(g["wdir"][str(level)]))
+    _, uv = _wind_specs([("u", "u"), ("v", "v")])
+    rt = collect_fields_by_param((test_source(uv) | create_filter_by_name("uv_to_ddff")) | create_filter_by_name("ddff_to_uv"))
+    for i, level in enumerate(g["levels"]):
+        assert np.allclose(rt["u"][i].to_numpy(), np.array(g["u"][str(level)])) and np.allclose(rt["v"][i].to_numpy(), np.array(g["v"][str(level)]))
+    with pytest.raises(AssertionError):
+        create_filter_by_name("uv_to_ddff", radians=True)  # R: uv_to_ddff.py:74
 
 
 # ---- cos / sin ----------------------------------------------------------------------------
@@ -292,6 +339,19 @@ def test_combine_kernel_vs_oracle(dev, tdtype, np_dtype, rtol, layout):
     np.testing.assert_allclose(run(native.COMB_WZ_TO_W, [w, t, c], 1, with_levels=True)[0], want, rtol=rtol)
     terms = [a, b, c, t, w]
     assert np.array_equal(run(native.COMB_SUM, terms, 1)[0], np.stack([oracle.sum_fields([x[l] for x in terms]) for l in range(n_lev)]))
+    # wind components <-> speed / direction (R: uv_to_ddff.py:93-97, 121-125)
+    u, v = rng.normal(0, 8, (n_lev, n_pts)).astype(np_dtype), rng.normal(0, 8, (n_lev, n_pts)).astype(np_dtype)
+    u[0, :4], v[0, :4] = [0.0, 0.0, -3.0, 3.0], [5.0, -5.0, 0.0, 0.0]  # from the south / north / east / west: 180, 0, 90, 270 degrees
+    ws, wd = run(native.COMB_XY_TO_POLAR, [u, v], 2)
+    want_ws, want_wd = oracle.xy_to_polar(u, v)
+    np.testing.assert_allclose(ws, want_ws, rtol=rtol)
+    np.testing.assert_allclose(wd, want_wd, rtol=rtol, atol=1e-9 if np_dtype == np.float64 else 1e-3)
+    assert list(wd[0, :4]) == [180.0, 0.0, 90.0, 270.0] and wd.min() >= 0.0 and wd.max() < 360.0
+    bu, bv = run(native.COMB_POLAR_TO_XY, [want_ws.astype(np_dtype), want_wd.astype(np_dtype)], 2)
+    wu, wv = oracle.polar_to_xy(want_ws.astype(np_dtype), want_wd.astype(np_dtype))
+    np.testing.assert_allclose(bu, wu, rtol=rtol, atol=1e-12 if np_dtype == np.float64 else 1e-5)
+    np.testing.assert_allclose(bv, wv, rtol=rtol, atol=1e-12 if np_dtype == np.float64 else 1e-5)
+    np.testing.assert_allclose(bu, u, rtol=1e-9 if np_dtype == np.float64 else 2e-4, atol=1e-9 if np_dtype == np.float64 else 2e-4)
     with pytest.raises(ValueError):
         run(native.COMB_SNOW_COVER, [a], 1)
 

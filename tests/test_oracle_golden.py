@@ -244,6 +244,20 @@ def test_cos_sin_vectors():
     np.testing.assert_allclose(oracle.direction_from_cos_sin(arr(d["cos"]), arr(d["sin"]), degrees=True), arr(d["mwd"]))
 
 
+def test_uv_to_ddff_vectors():
+    """The restated earthkit-meteo wind conversions against the reference's own expectations (np.allclose, as its tests use)."""
+    g = GOLDEN["uv_to_ddff"]
+    for level in g["levels"]:
+        u, v, ws, wdir = (arr(g[k][str(level)]) for k in ("u", "v", "ws", "wdir"))
+        speed, direction = oracle.xy_to_polar(u, v)
+        assert np.allclose(speed, ws) and np.allclose(direction, wdir)
+        assert direction.min() >= 0.0 and direction.max() < 360.0
+        back_u, back_v = oracle.polar_to_xy(ws, wdir)
+        assert np.allclose(back_u, u) and np.allclose(back_v, v)
+        rt_u, rt_v = oracle.polar_to_xy(*oracle.xy_to_polar(u, v))
+        assert np.allclose(rt_u, u) and np.allclose(rt_v, v)
+
+
 def test_sum_vectors():
     g = GOLDEN["sum"]
     t, r = arr(g["t"]), arr(g["r"])
