@@ -278,6 +278,9 @@ regrid_cols_ell_kernel(EllBatch batch,
 //                through the per-level program.
 // Everything else (clip / impute / exp / log / divisions, more stages) stays on the tiled kernel: its general operator switch
 // costs registers (f64: 88 VGPRs, 5 waves per SIMD instead of 8) and time the gather cannot hide (profiles/r02_ab_epilogue_routes.log).
+#ifndef ATX_PAD_SELF
+#define ATX_PAD_SELF 1
+#endif
 constexpr int kEpiNone = 0, kEpiUniform = 1, kEpiTable = 2;
 constexpr int kMaxTable = 4;
 
@@ -332,9 +335,12 @@ regrid_cols_ell_direct_kernel(EllBatch batch, const int32_t* __restrict__ idx, c
             masked = tgt_mask ? (tgt_mask[row] != 0) : false;
         }
         V v[K];
+        // an absent entry of a padded row (index -1) is skipped below; its load goes to the row's FIRST column — a line this lane is
+        // fetching anyway — instead of column 0, which every padded lane of the launch would share (ATX_PAD_SELF=0: column 0)
+        const int32_t spare = (ATX_PAD_SELF && p[0] >= 0) ? p[0] : 0;
 #pragma unroll
-        for (int j = 0; j < K; ++j)  // an absent entry of a padded row (index -1) loads column 0 and is skipped below
-            v[j] = load_src<T, VEC>(src + (int64_t)((PAD && p[j] < 0) ? 0 : p[j]) * src_pitch + (int64_t)c * VEC);
+        for (int j = 0; j < K; ++j)
+            v[j] = load_src<T, VEC>(src + (int64_t)((PAD && p[j] < 0) ? spare : p[j]) * src_pitch + (int64_t)c * VEC);
         V acc;
         if (WEIGHTED) {
 #pragma unroll

@@ -25,16 +25,18 @@ PEAK = 8e12
 
 
 def timeit(fn, n=10, warm=2):
+    """Median of n per-call HIP-event durations: one call in a few hundred stalls for tens of ms on a shared host (a lone 4.4 ms
+    reading among 1.9 ms ones, `profiles/r03_padded_order_probe.log`), which a mean over 10 carries into the table."""
     for _ in range(warm):
         fn()
     torch.cuda.synchronize()
-    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    a.record()
-    for _ in range(n):
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n)]
+    for a, b in evs:
+        a.record()
         fn()
-    b.record()
+        b.record()
     torch.cuda.synchronize()
-    return a.elapsed_time(b) / n
+    return float(np.median([a.elapsed_time(b) for a, b in evs]))
 
 
 def main():
