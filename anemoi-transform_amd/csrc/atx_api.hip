@@ -62,7 +62,9 @@ extern "C" int64_t atx_vector_program(const atx_level_op* prog, int32_t n_stage,
     }
     const int64_t V = dtype == ATX_F32 ? 4 : 2;
     const int64_t C = (n_lev + V - 1) / V;
-    if (!out) return (int64_t)n_stage * C;
+    const atx::LevelTables lay = atx::level_tables_layout(n_stage, n_lev, dtype);
+    const int64_t n_entries = (lay.total_bytes + (int64_t)sizeof(atx_level_op) - 1) / (int64_t)sizeof(atx_level_op);
+    if (!out) return n_entries;
     // the same rule as the kernels' own table build (build_vector_ops): equality of op, use_mask and of the parameters AS
     // THE KERNEL WILL SEE THEM, i.e. after rounding to the stack's arithmetic type
     auto same_param = [dtype](double a, double b) {
@@ -90,7 +92,30 @@ extern "C" int64_t atx_vector_program(const atx_level_op* prog, int32_t n_stage,
             out[(int64_t)s * C + c] = o;
         }
     }
-    return (int64_t)n_stage * C;
+    // second part: every level's operator in the stack's type (atx_common.hpp: level_tables_layout)
+    unsigned char* base = reinterpret_cast<unsigned char*>(out);
+    std::memset(base + (int64_t)n_stage * C * (int64_t)sizeof(atx_level_op), 0,
+                (size_t)(n_entries * (int64_t)sizeof(atx_level_op) - (int64_t)n_stage * C * (int64_t)sizeof(atx_level_op)));
+    const int64_t B = dtype == ATX_F32 ? 4 : 8;
+    unsigned char* p0 = base + lay.levels_offset;
+    unsigned char* p1 = p0 + (int64_t)n_stage * lay.Lp * B;
+    unsigned char* code = p1 + (int64_t)n_stage * lay.Lp * B;
+    for (int32_t s = 0; s < n_stage; ++s) {
+        for (int64_t l = 0; l < lay.Lp; ++l) {
+            const atx_level_op& o = prog[(int64_t)s * n_lev + (l < n_lev ? l : n_lev - 1)];
+            const int64_t i = (int64_t)s * lay.Lp + l;
+            if (dtype == ATX_F32) {
+                const float a = (float)o.p0, b = (float)o.p1;
+                std::memcpy(p0 + i * B, &a, sizeof a);
+                std::memcpy(p1 + i * B, &b, sizeof b);
+            } else {
+                std::memcpy(p0 + i * B, &o.p0, sizeof(double));
+                std::memcpy(p1 + i * B, &o.p1, sizeof(double));
+            }
+            code[i] = (unsigned char)((o.op & 0x7f) | (o.use_mask ? 0x80 : 0));
+        }
+    }
+    return n_entries;
 }
 
 namespace atx {

@@ -203,6 +203,66 @@ __device__ __forceinline__ void apply_level_op_vec(const LevelOp<T>& o, Pack<T, 
     }
 }
 
+// ONE operator kind over the levels of a vector, each level with its OWN parameters (a[e], b[e]): a scale / offset per level,
+// the usual shape of a per-level program.  Same statements and roundings as apply_level_op.
+template <typename T, int VEC, bool TRANS = true>
+__device__ __forceinline__ void apply_level_op_params(int op, bool use_mask, const Pack<T, VEC>& a, const Pack<T, VEC>& b, Pack<T, VEC>& v,
+                                                      bool masked) {
+    switch (op) {
+        case ATX_OP_COPY: break;
+        case ATX_OP_AFFINE:
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) v.v[e] = v.v[e] * a.v[e] + b.v[e];
+            break;
+        case ATX_OP_AFFINE_INV:
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) v.v[e] = (v.v[e] - b.v[e]) / a.v[e];
+            break;
+        case ATX_OP_MUL:
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) v.v[e] = v.v[e] * a.v[e];
+            break;
+        case ATX_OP_DIV:
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) v.v[e] = v.v[e] / a.v[e];
+            break;
+        case ATX_OP_CLIP:
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) {
+                T y = v.v[e];
+                if (a.v[e] == a.v[e]) y = (y < a.v[e]) ? a.v[e] : y;
+                if (b.v[e] == b.v[e]) y = (y > b.v[e]) ? b.v[e] : y;
+                v.v[e] = y;
+            }
+            break;
+        case ATX_OP_IMPUTE_NAN:
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) v.v[e] = (v.v[e] != v.v[e]) ? a.v[e] : v.v[e];
+            break;
+        case ATX_OP_EXP:
+            if constexpr (TRANS) {
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) v.v[e] = exp(v.v[e]);
+            }
+            break;
+        case ATX_OP_LOG:
+            if constexpr (TRANS) {
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) v.v[e] = log(v.v[e]);
+            }
+            break;
+        case ATX_OP_SET_NAN:
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) v.v[e] = quiet_nan<T>();
+            break;
+        default: break;
+    }
+    if (use_mask && masked) {
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) v.v[e] = quiet_nan<T>();
+    }
+}
+
 constexpr int kOpMixed = -1;  // marker in a per-vector operator table: the vector's levels differ
 
 __device__ __forceinline__ bool same_bits(float a, float b) { return __float_as_uint(a) == __float_as_uint(b); }
@@ -248,6 +308,26 @@ __device__ __forceinline__ void apply_program_vec(const LevelOp<T>* __restrict__
             }
         }
     }
+}
+
+// Layout of the table atx_vector_program writes (units: bytes from the table's base, which must be 16-byte aligned for the second
+// part to be used): [n_stage * C] per-vector atx_level_op entries, then — from the next 16-byte boundary — the operators of EVERY
+// LEVEL in the stack's arithmetic type, parameters and codes apart: p0[n_stage][Lp], p1[n_stage][Lp] (T), code[n_stage][Lp]
+// (one byte: op | use_mask << 7), Lp = C * V levels (the padding of the last vector repeats the last level).  A lane reads the
+// parameters of its vector's levels with two 16-byte loads and their codes with one 2- / 4-byte load per stage.
+struct LevelTables {
+    int64_t levels_offset;  // bytes from the base to p0
+    int64_t Lp;
+    int64_t total_bytes;
+};
+static inline LevelTables level_tables_layout(int n_stage, int64_t n_lev, int dtype) {
+    const int64_t V = dtype == ATX_F32 ? 4 : 2, B = dtype == ATX_F32 ? 4 : 8;
+    const int64_t C = (n_lev + V - 1) / V;
+    LevelTables t;
+    t.Lp = C * V;
+    t.levels_offset = (((int64_t)n_stage * C * (int64_t)sizeof(atx_level_op)) + 15) & ~int64_t(15);
+    t.total_bytes = t.levels_offset + (int64_t)n_stage * t.Lp * (2 * B + 1);
+    return t;
 }
 
 // A per-level program whose operators can travel BY VALUE in the kernel arguments (scalar registers, scalar branch on the operator):

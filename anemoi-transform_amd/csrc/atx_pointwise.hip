@@ -10,6 +10,7 @@
 // HBM-bound: 16-byte loads/stores, grid-strided over up to kStreamGrid short workgroups; levels whose program is all-COPY are not touched when the
 // operation is in place.
 #include "atx_common.hpp"
+#include <type_traits>
 
 namespace atx {
 
@@ -192,6 +193,100 @@ pointwise_cols_flat_kernel(const T* __restrict__ x, T* __restrict__ y, int64_t n
                 apply_program_vec<T, VEC, TRANS>(vec_ops, prog, n_stage, n_lev, C, col[u], v[u], masked);
             }
             pw_store<T, VEC>(y + (base + u * kBlock + tid) * VEC, v[u]);
+        }
+    }
+}
+
+// The chunked sweep above with the operators of EVERY LEVEL staged in LDS, parameters and operator codes in separate arrays
+// (p0[stage][level], p1[stage][level] in the stack's type, one byte op | mask << 7 per level): a lane fetches the parameters of the
+// VEC levels of its vector with two conflict-free 16-byte LDS reads and their codes with one 2- / 4-byte read per stage.  A program
+// with a different scale per level — what the packed surface stacks and fused pipelines produce — made every vector "mixed" on the
+// kernel above: VEC x 24 bytes of operators per stage and vector out of L1 for 32 bytes of HBM traffic (137 levels of O1280, a scale
+// per level: f32 1.88 ms = 0.48, f64 2.69 ms = 0.67); array-of-struct operators in LDS had been tried and lost to bank conflicts.
+// NT (non-temporal loads and stores of the stack): float32 only, and not for an in-place call that skips untouched vectors —
+// measured per case in profiles/r03_per_level_programs.log (f32 in place 0.68 -> 0.74, out of place 0.75 -> 0.76; f64 0.76 -> 0.73,
+// in place with skipped vectors 0.71 -> 0.48).
+template <typename T, int VEC, bool TRANS, bool NT>
+__global__ void __launch_bounds__(kBlock)
+pointwise_cols_levels_kernel(const T* __restrict__ x, T* __restrict__ y, int64_t n_pts, int n_lev, int C,
+                             const atx_level_op* __restrict__ prog, int n_stage,
+                             const uint8_t* __restrict__ point_mask, int in_place) {
+    using V = Pack<T, VEC>;
+    using OpWord = typename std::conditional<VEC == 4, uint32_t, uint16_t>::type;
+    static_assert(VEC == 4 || VEC == 2, "16-byte vectors of float or double");
+    constexpr unsigned kRep = VEC == 4 ? 0x01010101u : 0x0101u;
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int Lp = C * VEC;  // levels incl. the padding of the last vector (it repeats the last level's operator)
+    T* lp0 = reinterpret_cast<T*>(smem);                             // [n_stage][Lp]
+    T* lp1 = lp0 + (size_t)n_stage * Lp;                             // [n_stage][Lp]
+    uint8_t* opb = reinterpret_cast<uint8_t*>(lp1 + (size_t)n_stage * Lp);  // [n_stage][Lp]
+    uint8_t* active = opb + (size_t)n_stage * Lp;                    // [C]: the vector has a level that is not a plain COPY
+    const int tid = threadIdx.x;
+    for (int i = tid; i < n_stage * Lp; i += kBlock) {
+        const int s = i / Lp, l = i - s * Lp;
+        const atx_level_op o = prog[(int64_t)s * n_lev + (l < n_lev ? l : n_lev - 1)];
+        lp0[i] = static_cast<T>(o.p0);
+        lp1[i] = static_cast<T>(o.p1);
+        opb[i] = (uint8_t)((o.op & 0x7f) | (o.use_mask ? 0x80 : 0));
+    }
+    __syncthreads();
+    for (int c = tid; c < C; c += kBlock) {
+        unsigned any = 0;
+        for (int s = 0; s < n_stage; ++s) any |= *reinterpret_cast<const OpWord*>(opb + (size_t)s * Lp + c * VEC);
+        active[c] = any ? 1 : 0;  // ATX_OP_COPY without the mask is the zero byte
+    }
+    __syncthreads();
+
+    const int64_t n_vec = n_pts * C;
+    constexpr int64_t kChunk = (int64_t)kBlock * kPwUnroll;
+    for (int64_t base = (int64_t)blockIdx.x * kChunk; base < n_vec; base += (int64_t)gridDim.x * kChunk) {
+        const int64_t row_b = base / C;  // uniform: scalar unit
+        const int col_b = (int)(base - row_b * C);
+        V v[kPwUnroll];
+        int64_t row[kPwUnroll];
+        int col[kPwUnroll];
+        bool ok[kPwUnroll], act[kPwUnroll];
+#pragma unroll
+        for (int u = 0; u < kPwUnroll; ++u) {
+            const int off = col_b + u * kBlock + tid;  // < C + kChunk: 32-bit arithmetic
+            const int dr = off / C;
+            col[u] = off - dr * C;
+            row[u] = row_b + dr;
+            const int64_t vi = base + u * kBlock + tid;
+            ok[u] = vi < n_vec;
+            act[u] = active[col[u]] != 0;
+            if (in_place && !act[u]) ok[u] = false;  // untouched levels of an in-place call: nothing to move
+            if (ok[u]) v[u] = NT ? pw_load_nt<T, VEC>(x + vi * VEC) : pw_load<T, VEC>(x + vi * VEC);
+        }
+#pragma unroll
+        for (int u = 0; u < kPwUnroll; ++u) {
+            if (!ok[u]) continue;
+            if (act[u]) {
+                const bool masked = point_mask ? (point_mask[row[u]] != 0) : false;
+                for (int s = 0; s < n_stage; ++s) {
+                    const unsigned wd = *reinterpret_cast<const OpWord*>(opb + (size_t)s * Lp + col[u] * VEC);
+                    if (wd == 0) continue;
+                    const V a = *reinterpret_cast<const V*>(lp0 + (size_t)s * Lp + col[u] * VEC);
+                    const V b = *reinterpret_cast<const V*>(lp1 + (size_t)s * Lp + col[u] * VEC);
+                    const unsigned first = wd & 0xffu;
+                    if (wd == first * kRep) {  // one operator kind over the vector's levels (their parameters may differ)
+                        apply_level_op_params<T, VEC, TRANS>((int)(first & 0x7fu), (first & 0x80u) != 0, a, b, v[u], masked);
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < VEC; ++e) {
+                            const unsigned code = (wd >> (8 * e)) & 0xffu;
+                            LevelOp<T> o;
+                            o.op = (int)(code & 0x7fu);
+                            o.use_mask = (int)(code >> 7);
+                            o.p0 = a.v[e];
+                            o.p1 = b.v[e];
+                            v[u].v[e] = apply_level_op<T, TRANS>(o, v[u].v[e], masked);
+                        }
+                    }
+                }
+            }
+            if (NT) pw_store_nt<T, VEC>(y + (base + u * kBlock + tid) * VEC, v[u]);
+            else pw_store<T, VEC>(y + (base + u * kBlock + tid) * VEC, v[u]);
         }
     }
 }
@@ -890,6 +985,36 @@ static int pointwise_typed(const void* x_, void* y_, int64_t n_pts, int n_lev, i
             int64_t blocks = n_chunks > kMaxGrid ? kMaxGrid : n_chunks;
             const int64_t per = (n_chunks + blocks - 1) / blocks;
             blocks = (n_chunks + per - 1) / per;  // contiguous runs of `per` chunks: no workgroup without work
+#ifndef ATX_PW_LEVELS
+#define ATX_PW_LEVELS 1  // 0: round 2's chunked kernel (per-vector operators in LDS, mixed vectors from the global program)
+#endif
+            const size_t lds_levels = (size_t)n_stage * C * VEC * (2 * sizeof(T) + 1) + (size_t)C;
+            if (ATX_PW_LEVELS && lds_levels <= 64 * 1024) {
+#ifndef ATX_PW_LEVELS_NT
+#define ATX_PW_LEVELS_NT 1
+#endif
+                bool nt = ATX_PW_LEVELS_NT && sizeof(T) == 4 && host_prog != nullptr;
+                if (nt && in_place) {  // every vector must be touched
+                    for (int c = 0; c < C && nt; ++c) {
+                        bool act = false;
+                        for (int s = 0; s < n_stage && !act; ++s)
+                            for (int l = c * VEC; l < n_lev && l < (c + 1) * VEC && !act; ++l)
+                                act = host_prog[(int64_t)s * n_lev + l].op != ATX_OP_COPY || host_prog[(int64_t)s * n_lev + l].use_mask != 0;
+                        nt = act;
+                    }
+                }
+                if (program_has_transcendental(host_prog, n_stage, n_lev))
+                    hipLaunchKernelGGL((pointwise_cols_levels_kernel<T, VEC, true, false>), dim3((unsigned)blocks), dim3(kBlock), lds_levels, st, x, y,
+                                       n_pts, n_lev, C, prog, n_stage, mask, in_place);
+                else if (nt)
+                    hipLaunchKernelGGL((pointwise_cols_levels_kernel<T, VEC, false, true>), dim3((unsigned)blocks), dim3(kBlock), lds_levels, st, x, y,
+                                       n_pts, n_lev, C, prog, n_stage, mask, in_place);
+                else
+                    hipLaunchKernelGGL((pointwise_cols_levels_kernel<T, VEC, false, false>), dim3((unsigned)blocks), dim3(kBlock), lds_levels, st, x, y,
+                                       n_pts, n_lev, C, prog, n_stage, mask, in_place);
+                ATX_LAUNCH_CHECK("pointwise_stack_levels");
+                return ATX_OK;
+            }
             const size_t lds_flat = lds + (size_t)C;
             if (program_has_transcendental(host_prog, n_stage, n_lev))
                 hipLaunchKernelGGL((pointwise_cols_flat_kernel<T, VEC, true>), dim3((unsigned)blocks), dim3(kBlock), lds_flat, st, x, y, n_pts, n_lev,

@@ -17,6 +17,8 @@
 //    an L2; several stacks of one shape share a launch (grid.y = stack).
 //  * ATX_FIELDS stacks: lane = target, neighbour indices / weights live in registers and are reused for every level of
 //    the level chunk.
+#include <type_traits>
+
 #include "atx_common.hpp"
 
 #include <cstring>
@@ -297,8 +299,8 @@ template <typename T, int VEC, int K, bool WEIGHTED, bool PAD, int EPI>
 __global__ void __launch_bounds__(kEllBlock)
 regrid_cols_ell_direct_kernel(EllBatch batch, const int32_t* __restrict__ idx, const T* __restrict__ w, int64_t n_items,
                               int C, int64_t src_pitch, int64_t out_pitch, unsigned n_blocks, int items_per_lane,
-                              UniformOps<T> uniform, const atx_level_op* __restrict__ vec_prog,
-                              const atx_level_op* __restrict__ prog, int n_stage, int n_lev, const uint8_t* __restrict__ tgt_mask,
+                              UniformOps<T> uniform, const unsigned char* __restrict__ level_tables, int n_stage, int n_lev,
+                              const uint8_t* __restrict__ tgt_mask,
                               const int32_t* __restrict__ tgt_rows) {
     using V = Pack<T, VEC>;
     const T* __restrict__ src = static_cast<const T*>(batch.src[blockIdx.y]);
@@ -321,16 +323,24 @@ regrid_cols_ell_direct_kernel(EllBatch batch, const int32_t* __restrict__ idx, c
         }
         // table route: the first operators and the mask byte are requested HERE, together with the index words, so that their
         // latency passes under the gather instead of after it (loaded after the accumulation they cost 9 %: 478 vs 439 us)
-        LevelOp<T> pre[kMaxTable];
+        V ta[kMaxTable], tb[kMaxTable];
+        unsigned tcode[kMaxTable];
         bool masked = false;
         if (EPI == kEpiUniform) masked = tgt_mask ? (tgt_mask[row] != 0) : false;
-        if (EPI == kEpiTable) {
+        if (EPI == kEpiTable) {  // the operators of this vector's levels, in the stack's type (level_tables_layout)
+            using OpWord = typename std::conditional<VEC == 4, uint32_t, uint16_t>::type;
+            const int Lp = C * VEC;
+            const T* tp0 = reinterpret_cast<const T*>(level_tables);
+            const T* tp1 = tp0 + (int64_t)n_stage * Lp;
+            const uint8_t* tcd = reinterpret_cast<const uint8_t*>(tp1 + (int64_t)n_stage * Lp);
 #pragma unroll
             for (int s = 0; s < kMaxTable; ++s) {
-                pre[s].op = ATX_OP_COPY;
-                pre[s].use_mask = 0;
-                pre[s].p0 = pre[s].p1 = T(0);
-                if (s < n_stage) pre[s] = load_level_op<T>(vec_prog, (int64_t)s * C + c);
+                tcode[s] = 0;
+                if (s < n_stage) {
+                    ta[s] = *reinterpret_cast<const V*>(tp0 + (int64_t)s * Lp + c * VEC);
+                    tb[s] = *reinterpret_cast<const V*>(tp1 + (int64_t)s * Lp + c * VEC);
+                    tcode[s] = *reinterpret_cast<const OpWord*>(tcd + (int64_t)s * Lp + c * VEC);
+                }
             }
             masked = tgt_mask ? (tgt_mask[row] != 0) : false;
         }
@@ -370,15 +380,15 @@ regrid_cols_ell_direct_kernel(EllBatch batch, const int32_t* __restrict__ idx, c
 #pragma unroll
             for (int s = 0; s < kMaxTable; ++s) {
                 if (s < n_stage) {
-                    if (pre[s].op != kOpMixed) {
 #pragma unroll
-                        for (int e = 0; e < VEC; ++e) acc.v[e] = apply_madd_family(pre[s], acc.v[e], masked);
-                    } else {
-#pragma unroll
-                        for (int e = 0; e < VEC; ++e) {
-                            const int l = c * VEC + e;
-                            if (l < n_lev) acc.v[e] = apply_madd_family(load_level_op<T>(prog, (int64_t)s * n_lev + l), acc.v[e], masked);
-                        }
+                    for (int e = 0; e < VEC; ++e) {
+                        const unsigned code = (tcode[s] >> (8 * e)) & 0xffu;
+                        LevelOp<T> o;
+                        o.op = (int)(code & 0x7fu);
+                        o.use_mask = (int)(code >> 7);
+                        o.p0 = ta[s].v[e];
+                        o.p1 = tb[s].v[e];
+                        acc.v[e] = apply_madd_family(o, acc.v[e], masked);
                     }
                 }
             }
@@ -620,7 +630,7 @@ struct Epilogue {
 // Every operator of the program is COPY, AFFINE or MUL (masked or not) and there are <= kMaxTable stages: the direct
 // kernel's table route applies.
 static bool madd_family_program(const Epilogue& e, int n_lev) {
-    if (!e.host_prog || !e.vec_prog || e.n_stage < 1 || e.n_stage > kMaxTable) return false;
+    if (!e.host_prog || !e.vec_prog || !aligned16(e.vec_prog) || e.n_stage < 1 || e.n_stage > kMaxTable) return false;
     for (int64_t i = 0; i < (int64_t)e.n_stage * n_lev; ++i) {
         const int op = e.host_prog[i].op;
         if (op != ATX_OP_COPY && op != ATX_OP_AFFINE && op != ATX_OP_MUL) return false;
@@ -664,20 +674,22 @@ static int launch_cols_ell(const EllBatch& batch, const int32_t* idx, const T* w
             UniformOps<T> uniform{};
             if (!prog) {
                 hipLaunchKernelGGL((regrid_cols_ell_direct_kernel<T, VEC, K, WEIGHTED, PAD, kEpiNone>), dim3(n_blocks, batch.n), dim3(kEllBlock), 0,
-                                   stream, batch, idx, w, n_items, C, src_pitch, out_pitch, n_blocks, 1, uniform, nullptr, nullptr, 0, n_lev, nullptr, epi.tgt_rows);
+                                   stream, batch, idx, w, n_items, C, src_pitch, out_pitch, n_blocks, 1, uniform, nullptr, 0, n_lev, nullptr, epi.tgt_rows);
                 ATX_LAUNCH_CHECK("regrid_cols_ell_direct");
                 return ATX_OK;
             }
             if (ATX_EPI_DIRECT && uniform_program<T>(epi, n_lev, VEC, uniform)) {
                 hipLaunchKernelGGL((regrid_cols_ell_direct_kernel<T, VEC, K, WEIGHTED, PAD, kEpiUniform>), dim3(n_blocks, batch.n), dim3(kEllBlock),
-                                   0, stream, batch, idx, w, n_items, C, src_pitch, out_pitch, n_blocks, 1, uniform, nullptr, nullptr, n_stage, n_lev,
+                                   0, stream, batch, idx, w, n_items, C, src_pitch, out_pitch, n_blocks, 1, uniform, nullptr, n_stage, n_lev,
                                    tgt_mask, epi.tgt_rows);
                 ATX_LAUNCH_CHECK("regrid_cols_ell_direct_uniform");
                 return ATX_OK;
             }
             if (ATX_EPI_DIRECT && VEC == Vec16<T>::N && madd_family_program(epi, n_lev)) {  // the table is built for 16-byte vectors
+                const unsigned char* level_tables = reinterpret_cast<const unsigned char*>(epi.vec_prog) +
+                                                    level_tables_layout(n_stage, n_lev, sizeof(T) == 4 ? ATX_F32 : ATX_F64).levels_offset;
                 hipLaunchKernelGGL((regrid_cols_ell_direct_kernel<T, VEC, K, WEIGHTED, PAD, kEpiTable>), dim3(n_blocks, batch.n), dim3(kEllBlock), 0,
-                                   stream, batch, idx, w, n_items, C, src_pitch, out_pitch, n_blocks, 1, uniform, epi.vec_prog, prog, n_stage, n_lev,
+                                   stream, batch, idx, w, n_items, C, src_pitch, out_pitch, n_blocks, 1, uniform, level_tables, n_stage, n_lev,
                                    tgt_mask, epi.tgt_rows);
                 ATX_LAUNCH_CHECK("regrid_cols_ell_direct_table");
                 return ATX_OK;

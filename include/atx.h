@@ -219,12 +219,19 @@ int atx_pointwise_stack(const void* x, void* y, int64_t n_pts, int64_t n_lev,
                         const atx_level_op* prog, const atx_level_op* vec_prog, const atx_level_op* host_prog,
                         int32_t n_stage, const uint8_t* point_mask, void* stream);
 
-/* Per-vector form of a per-level program, computed on the HOST (no device access): out[s*C + c] is the operator shared
- * by the levels c*V .. c*V+V-1 of stage s (V = 16 bytes / sizeof(dtype), C = ceil(n_lev / V); padding levels join any
- * operator), with op = ATX_OP_MIXED (and use_mask = whether any of them uses the mask) where they differ once the parameters are rounded to dtype.  Returns the number of
- * entries n_stage*C (out == NULL: only that), negative on error.  Uploaded and passed as `vec_prog` (of the stack's
- * dtype) it lets atx_pointwise_stack run without any per-workgroup set-up — one 16-byte vector per lane, the launch
- * shape that streams fastest on MI355X; vec_prog == NULL is always valid (the kernels then derive the table themselves). */
+/* Companion table of a per-level program, computed on the HOST (no device access), in two parts.
+ * (1) Per 16-byte vector: out[s*C + c] is the operator shared by the levels c*V .. c*V+V-1 of stage s (V = 16 bytes /
+ *     sizeof(dtype), C = ceil(n_lev / V); padding levels join any operator), with op = ATX_OP_MIXED (and use_mask = whether any
+ *     of them uses the mask) where they differ once the parameters are rounded to dtype.
+ * (2) From the next 16-byte boundary after those n_stage*C entries: the operators of EVERY level in the stack's arithmetic type,
+ *     parameters and codes apart — p0[n_stage][C*V], p1[n_stage][C*V] (float or double), code[n_stage][C*V] (one byte:
+ *     op | use_mask << 7; the padding of the last vector repeats the last level) — so that a lane reads the parameters of its
+ *     vector's levels with two 16-byte loads: programs with a different scale per level (packed surface stacks, normalisation
+ *     per level) then cost the fused regrid epilogue nothing extra (O1280 -> 0.25 deg, 137 levels: 0.44 ms with or without).
+ * Returns the size of the whole table in atx_level_op entries (out == NULL: only that — always size `out` by this query),
+ * negative on error.  Uploaded to a 16-byte aligned device buffer and passed as `vec_prog` (of the stack's dtype) it lets
+ * atx_regrid_ell fuse multiply-add programs on its fastest kernel and atx_pointwise_stack run without any per-workgroup set-up;
+ * vec_prog == NULL is always valid (the kernels then derive what they need themselves). */
 #define ATX_OP_MIXED (-1)
 int64_t atx_vector_program(const atx_level_op* prog, int32_t n_stage, int64_t n_lev, int dtype, atx_level_op* out);
 

@@ -180,7 +180,7 @@ def test_regrid_fused_epilogue(dev):
 @pytest.mark.parametrize("tdtype,np_dtype", DTYPES)
 @pytest.mark.parametrize("k,padded", [(1, False), (4, False), (3, True)])
 @pytest.mark.parametrize("program", ["uniform", "per_vector", "three_pieces", "mixed_madd", "mixed_vectors", "two_pieces_general", "masked",
-                                     "masked_uniform", "masked_3_stages"])
+                                     "masked_uniform", "masked_3_stages", "scale_per_level"])
 def test_fused_epilogue_kernel_variants_agree(dev, tdtype, np_dtype, k, padded, program):
     """The epilogue reaches the gather by three routes — operators by value in the kernel arguments (uniform programs seen
     through host_prog), the host-built per-vector table (vec_prog), the tiled kernel's LDS table (neither companion) — and
@@ -208,6 +208,8 @@ def test_fused_epilogue_kernel_variants_agree(dev, tdtype, np_dtype, k, padded, 
         stages = [[aff] * n_lev, [(native.OP_COPY, 1, 0.0, 0.0)] * n_lev]
     elif program == "mixed_madd":  # operators differ inside a vector, all of the multiply-add family (direct kernel, per-level path)
         stages = [[mul if l % 3 == 0 else cp for l in range(n_lev)], [aff if l % 2 else cp for l in range(n_lev)]]
+    elif program == "scale_per_level":  # normalisation per level: every level its own parameters (the typed per-level part of vec_prog)
+        stages = [[(native.OP_MUL, 0, 1.0 + 0.01 * l, 0.0) for l in range(n_lev)], [(native.OP_AFFINE, 0, 1.0 / (1 + l), -0.37 * l) for l in range(n_lev)]]
     elif program == "masked_3_stages":  # BASELINE config 5 with apply_mask: orog_to_z on one level, convert on the others, mask on some
         stages = [[cp] * (n_lev - 1) + [mul], [aff] * (n_lev - 1) + [cp], [(native.OP_COPY, 1 if l % 5 else 0, 0.0, 0.0) for l in range(n_lev)]]
     elif program == "mixed_vectors":  # operators differ inside a vector, general operators (tiled kernel)

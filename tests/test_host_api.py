@@ -571,11 +571,22 @@ def test_vector_program_host_helper():
     for code, vec, want in ((native.F32, 4, [native.OP_AFFINE, -1, native.OP_AFFINE]),
                             (native.F64, 2, [native.OP_AFFINE, -1, -1, native.OP_MUL, native.OP_AFFINE])):
         n = lib.atx_vector_program(host.ctypes.data, 1, len(ops), code, None)
-        assert n == (len(ops) + vec - 1) // vec == len(want)
+        C = (len(ops) + vec - 1) // vec
+        assert C == len(want)
+        # second part, from the next 16-byte boundary: p0[Lp], p1[Lp] in the stack's type and one code byte per level
+        np_t, Lp, start = (np.float32, np.float64)[code == native.F64], C * vec, (C * 24 + 15) // 16 * 16
+        assert n == -(-(start + Lp * (2 * np.dtype(np_t).itemsize + 1)) // 24)
         out = np.zeros(n, dtype=native.LEVEL_OP_DTYPE)
         assert lib.atx_vector_program(host.ctypes.data, 1, len(ops), code, out.ctypes.data) == n
-        assert out["op"].tolist() == want
-        assert out["use_mask"][-1] == 1  # the last (partial) vector holds only level 8
+        assert out["op"][:C].tolist() == want
+        assert out["use_mask"][C - 1] == 1  # the last (partial) vector holds only level 8
+        raw = out.view(np.uint8)
+        padded = ops + [ops[-1]] * (Lp - len(ops))  # the padding of the last vector repeats the last level
+        p0 = raw[start:start + Lp * np.dtype(np_t).itemsize].view(np_t)
+        p1 = raw[start + Lp * np.dtype(np_t).itemsize:start + 2 * Lp * np.dtype(np_t).itemsize].view(np_t)
+        codes = raw[start + 2 * Lp * np.dtype(np_t).itemsize:][:Lp]
+        assert p0.tolist() == [np_t(o[2]) for o in padded] and p1.tolist() == [np_t(o[3]) for o in padded]
+        assert codes.tolist() == [o[0] | (o[1] << 7) for o in padded]
     assert lib.atx_vector_program(None, 1, 4, native.F32, None) == native.EINVAL
     assert lib.atx_vector_program(host.ctypes.data, 9, 1, native.F32, None) == native.EINVAL
 
