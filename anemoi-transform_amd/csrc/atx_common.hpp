@@ -89,6 +89,54 @@ __device__ __forceinline__ double quiet_nan<double>() {
     return __longlong_as_double(0x7ff8000000000000ll);  // np.nan
 }
 
+// Natural logarithm for the per-level operator ATX_OP_LOG (sp_to_lnsp, R: filters/fields/lnsp_to_sp.py:65).  float32: the device
+// library's.  float64: the classic argument reduction x = 2^k * m, m in [sqrt(2)/2, sqrt(2)), log(m) = f - s*(f - R(s^2)) with
+// s = f / (2 + f), f = m - 1 and a degree-14 minimax R (the published fdlibm coefficients, the one-form evaluation; measured <= 1 ulp
+// from numpy's in tests/test_gpu_kernels.py) — the device library's double log measured 3.18 ms over 137 levels of O1280 (0.57 of
+// the HBM peak, ALU-bound) where exp takes 2.34 ms; ATX_FAST_LOG=0 restores it.  Zero, negatives, infinities, NaN and subnormals
+// follow IEEE / numpy: -inf, NaN, +inf, NaN, exact scaling.
+#ifndef ATX_FAST_LOG
+#define ATX_FAST_LOG 1
+#endif
+__device__ __forceinline__ float atx_log(float x) { return log(x); }
+__device__ __forceinline__ double atx_log(double x) {
+#if ATX_FAST_LOG
+    constexpr double ln2_hi = 6.93147180369123816490e-01, ln2_lo = 1.90821492927058770002e-10;
+    constexpr double Lg1 = 6.666666666666735130e-01, Lg2 = 3.999999999940941908e-01, Lg3 = 2.857142874366239149e-01,
+                     Lg4 = 2.222219843214978396e-01, Lg5 = 1.818357216161805012e-01, Lg6 = 1.531383769920937332e-01,
+                     Lg7 = 1.479819860511658591e-01;
+    const double x0 = x;
+    int k = 0;
+    int hx = __double2hiint(x);
+    if (hx < 0x00100000) {  // subnormal (or zero / negative: settled at the end): scale into the normal range, exactly
+        x *= 18014398509481984.0;  // 2^54
+        k = -54;
+        hx = __double2hiint(x);
+    }
+    k += (hx >> 20) - 1023;
+    hx &= 0x000fffff;
+    const int i = (hx + 0x95f64) & 0x100000;  // m >= sqrt(2): halve it, k + 1
+    x = __hiloint2double(hx | (i ^ 0x3ff00000), __double2loint(x));
+    k += i >> 20;
+    const double f = x - 1.0;
+    const double s = f / (2.0 + f);
+    const double dk = (double)k;
+    const double z = s * s;
+    const double w = z * z;
+    const double t1 = w * fma(w, fma(w, Lg6, Lg4), Lg2);
+    const double t2 = z * fma(w, fma(w, fma(w, Lg7, Lg5), Lg3), Lg1);
+    const double R = t2 + t1;
+    const double hfsq = 0.5 * f * f;
+    double y = s * (hfsq + R) + dk * ln2_lo - hfsq + f + dk * ln2_hi;  // (the one-form evaluation of FreeBSD / musl)
+    if (x0 == 0.0) y = -__longlong_as_double(0x7ff0000000000000ll);
+    if (x0 < 0.0 || x0 != x0) y = __longlong_as_double(0x7ff8000000000000ll);
+    if (x0 == __longlong_as_double(0x7ff0000000000000ll)) y = x0;
+    return y;
+#else
+    return log(x);
+#endif
+}
+
 // One per-level operator in the arithmetic type of the stack.
 template <typename T>
 struct LevelOp {
@@ -133,7 +181,7 @@ __device__ __forceinline__ T apply_level_op(const LevelOp<T>& o, T x, bool maske
             if constexpr (TRANS) y = exp(x);
             break;
         case ATX_OP_LOG:
-            if constexpr (TRANS) y = log(x);
+            if constexpr (TRANS) y = atx_log(x);
             break;
         case ATX_OP_SET_NAN: y = quiet_nan<T>(); break;
         default: break;
@@ -188,7 +236,7 @@ __device__ __forceinline__ void apply_level_op_vec(const LevelOp<T>& o, Pack<T, 
         case ATX_OP_LOG:
             if constexpr (TRANS) {
 #pragma unroll
-                for (int e = 0; e < VEC; ++e) v.v[e] = log(v.v[e]);
+                for (int e = 0; e < VEC; ++e) v.v[e] = atx_log(v.v[e]);
             }
             break;
         case ATX_OP_SET_NAN:
@@ -248,7 +296,7 @@ __device__ __forceinline__ void apply_level_op_params(int op, bool use_mask, con
         case ATX_OP_LOG:
             if constexpr (TRANS) {
 #pragma unroll
-                for (int e = 0; e < VEC; ++e) v.v[e] = log(v.v[e]);
+                for (int e = 0; e < VEC; ++e) v.v[e] = atx_log(v.v[e]);
             }
             break;
         case ATX_OP_SET_NAN:

@@ -947,16 +947,21 @@ static int pointwise_typed(const void* x_, void* y_, int64_t n_pts, int n_lev, i
 #ifndef ATX_PW_UNIFORM_NT
 #define ATX_PW_UNIFORM_NT 1
 #endif
+#ifndef ATX_PW_TRANS_NT
+#define ATX_PW_TRANS_NT 1  // non-temporal accesses for programs with exp / log too
+#endif
 #define ATX_PW_UNIFORM_LAUNCH(TR_, U_, NT_)                                                                                                \
     hipLaunchKernelGGL((pointwise_cols_uniform_kernel<T, VEC, TR_, U_, NT_>), dim3((unsigned)((n_vec + kBlock * U_ - 1) / (kBlock * U_))), \
                        dim3(kBlock), 0, st, x, y, n_vec, C, uni, uses_mask ? mask : nullptr, need_rc, in_place, act_bits)
                 const bool nt = ATX_PW_UNIFORM_NT && !(uses_mask && mask);
                 if (in_place) {
-                    if (trans) ATX_PW_UNIFORM_LAUNCH(true, ATX_PW_UNIFORM_U_IN, false);  // (exp / log: ALU time dominates)
+                    if (trans && nt && ATX_PW_TRANS_NT) ATX_PW_UNIFORM_LAUNCH(true, ATX_PW_UNIFORM_U_IN, true);
+                    else if (trans) ATX_PW_UNIFORM_LAUNCH(true, ATX_PW_UNIFORM_U_IN, false);
                     else if (nt) ATX_PW_UNIFORM_LAUNCH(false, ATX_PW_UNIFORM_U_IN, true);
                     else ATX_PW_UNIFORM_LAUNCH(false, ATX_PW_UNIFORM_U_IN, false);
                 } else {
-                    if (trans) ATX_PW_UNIFORM_LAUNCH(true, ATX_PW_UNIFORM_U_OUT, false);
+                    if (trans && nt && ATX_PW_TRANS_NT) ATX_PW_UNIFORM_LAUNCH(true, ATX_PW_UNIFORM_U_OUT, true);
+                    else if (trans) ATX_PW_UNIFORM_LAUNCH(true, ATX_PW_UNIFORM_U_OUT, false);
                     else if (nt) ATX_PW_UNIFORM_LAUNCH(false, ATX_PW_UNIFORM_U_OUT, true);
                     else ATX_PW_UNIFORM_LAUNCH(false, ATX_PW_UNIFORM_U_OUT, false);
                 }

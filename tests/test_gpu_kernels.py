@@ -445,6 +445,46 @@ def test_pointwise_ops_bit_exact(dev, tdtype, np_dtype, layout, in_place):
         np.testing.assert_allclose(got[l], want[l], rtol=1e-6 if np_dtype == np.float32 else 1e-14, equal_nan=True)
 
 
+def test_float64_log_within_one_ulp_of_numpy(dev):
+    """ATX_OP_LOG in float64 is evaluated by the library's own argument reduction + polynomial (atx_common.hpp: atx_log) instead of
+    the device library's log: at most 1 ulp from numpy over the whole positive range, exact at 1, IEEE results at 0, negatives, inf, NaN
+    and subnormals — through every kernel that can run the operator (by value, per-level tables, fused regrid epilogue)."""
+    rng = np.random.default_rng(77)
+    n = 1 << 18
+    cases = {
+        "surface pressure (Pa)": rng.uniform(3.0e4, 1.1e5, n),
+        "around 1": 1.0 + rng.uniform(-0.5, 1.0, n),
+        "next to 1": 1.0 + rng.uniform(-1e-9, 1e-9, n),
+        "every magnitude": 10.0 ** rng.uniform(-307, 308, n),
+        "subnormal": rng.uniform(5e-324, 2.2e-308, n),
+    }
+    special = np.array([1.0, 0.0, -0.0, -1.0, np.inf, -np.inf, np.nan, 5e-324, 2.2250738585072014e-308, 1.7976931348623157e308, 2.0, 0.5, np.e])
+
+    def run(x, per_level=False):
+        st = Stack.from_fields(np.stack([x, x[::-1].copy()]), dev=dev)
+        out = st.new_like()
+        second = (native.OP_LOG, 0, 1.0, 0.0) if per_level else (native.OP_LOG, 0, 0.0, 0.0)  # different parameters: not uniform over the levels
+        prog = native.level_program([[(native.OP_LOG, 0, 0.0, 0.0), second]], dev)
+        native.pointwise_stack(st.data, out.data, n_pts=len(x), n_lev=2, x_pitch=st.pitch, y_pitch=out.pitch, layout=COLUMNS, prog=prog, n_stage=1)
+        got = out.numpy()
+        assert np.array_equal(got[0], got[1][::-1], equal_nan=True)
+        return got[0]
+
+    for name, x in cases.items():
+        want = np.log(x)
+        for per_level in (False, True):
+            got = run(x, per_level)
+            err = np.abs(got - want) / np.spacing(np.abs(want))
+            assert float(err.max()) <= 1.0, (name, per_level, float(err.max()))
+    with np.errstate(all="ignore"):
+        want = np.log(special)
+    for per_level in (False, True):
+        got = run(special, per_level)
+        assert np.array_equal(got[:7], want[:7], equal_nan=True), (got[:7], want[:7])
+        assert np.all(np.abs(got[7:] - want[7:]) <= np.spacing(np.abs(want[7:])))
+    assert run(special)[0] == 0.0  # log(1) is exactly 0
+
+
 @pytest.mark.parametrize("tdtype,np_dtype", DTYPES)
 @pytest.mark.parametrize("in_place", [False, True])
 @pytest.mark.parametrize("program", ["uniform_1", "uniform_4", "uniform_5", "two_pieces", "two_pieces_one_idle", "masked_uniform", "masked_piece",
