@@ -85,6 +85,8 @@ def random_program(rng, n_stage, n_lev):
             stage = [pick() if l in active else (native.OP_COPY, 0, 0.0, 0.0) for l in range(n_lev)]
         else:
             stage = [pick() for _ in range(n_lev)]
+        if rng.random() < 0.5:  # the same operators with parameters of their own on every level (normalisation per level)
+            stage = [(op, m, p0 * (1.0 + 0.03125 * (l % 7)), p1 + 0.5 * (l % 5)) for l, (op, m, p0, p1) in enumerate(stage)]
         ops.append(stage)
     return ops
 
@@ -238,6 +240,27 @@ def test_random_pointwise_and_level_gather_cases(dev, seed):
         assert np.array_equal(same.values().view(itype), x.view(itype)) and same.padding_untouched(), what + " pitched copy"
         # pitched reduction ignores the poisoned padding
         assert native.reduce_stack(src2.data, native.RED_NANCOUNT, n_pts=n_pts, n_lev=n_lev, pitch=src2.pitch, layout=layout) == float(np.isnan(x).sum())
+
+
+@pytest.mark.parametrize("np_dtype", [np.float32, np.float64])
+def test_per_level_programs_on_very_tall_stacks(dev, np_dtype):
+    """2001 levels x 2 stages with parameters of their own on every level: the per-level operator tables no longer fit the 64 KB of
+    LDS the per-point kernel may use in float64 (68 KB) and the launch falls back to the older chunked kernel — same values either way."""
+    rng = np.random.default_rng(5)
+    n_lev, n_pts = 2001, 37
+    x = (280 + 30 * rng.standard_normal((n_lev, n_pts))).astype(np_dtype)
+    ops = [[(native.OP_AFFINE, 0, 1.0 + 0.001 * l, -0.25 * l) for l in range(n_lev)],
+           [(native.OP_CLIP, l % 2, 100.0 + 0.1 * l, 300.0) if l % 3 else (native.OP_MUL, 0, 1.0 + 1.0 / (1 + l), 0.0) for l in range(n_lev)]]
+    prog = native.level_program(ops, dev)
+    mask_host = rng.random(n_pts) < 0.3
+    mask_dev = torch.from_numpy(mask_host.astype(np.uint8)).to(dev)
+    src, dst = Loose(x, COLUMNS, 0, dev, True), Loose(np.zeros_like(x), COLUMNS, 0, dev, True)
+    kw = dict(n_pts=n_pts, n_lev=n_lev, layout=COLUMNS, prog=prog, n_stage=2, point_mask=mask_dev)
+    native.pointwise_stack(src.data, dst.data, x_pitch=src.pitch, y_pitch=dst.pitch, **kw)
+    want = apply_program_host(x, ops, mask_host)
+    check(dst.values(), want, "out of place")
+    native.pointwise_stack(src.data, src.data, x_pitch=src.pitch, y_pitch=src.pitch, **kw)
+    check(src.values(), want, "in place")
 
 
 COMBINE_SEEDS = range(_FIRST, _FIRST + _COUNT) if _COUNT else range(12)
