@@ -311,6 +311,99 @@ __device__ __forceinline__ void apply_level_op_params(int op, bool use_mask, con
     }
 }
 
+// ---- the operators of EVERY LEVEL of a program, staged in LDS -------------------------------------------------------------
+// p0[stage][Lp], p1[stage][Lp] in the stack's type and one code byte (op | use_mask << 7) per level, Lp = C * VEC levels (the
+// padding of the last vector repeats the last level): a lane reads the parameters of the VEC levels of its vector with two
+// conflict-free LDS reads and their codes with one 1- / 2- / 4-byte read per stage.  (An array of LevelOp structs per level costs
+// four-way bank conflicts; per-VECTOR operators — build_vector_ops below — send every vector of a program with a scale per level
+// through the global program, VEC x 24 bytes per stage and vector.)
+template <int VEC>
+struct OpWordOf {
+    using type = uint32_t;
+};
+template <>
+struct OpWordOf<2> {
+    using type = uint16_t;
+};
+template <>
+struct OpWordOf<1> {
+    using type = uint8_t;
+};
+
+template <typename T>
+struct LevelTablesLds {
+    const T* p0;
+    const T* p1;
+    const uint8_t* code;
+    int Lp;
+};
+
+template <typename T>
+__host__ __device__ static inline size_t level_tables_lds_bytes(int n_stage, int C, int vec) {
+    return (((size_t)n_stage * C * vec * (2 * sizeof(T) + 1)) + 15) & ~size_t(15);
+}
+
+// Fill the tables at `smem` (16-byte aligned) from the global program; the caller's barrier follows.
+template <typename T, int VEC>
+__device__ __forceinline__ LevelTablesLds<T> build_level_tables(const atx_level_op* __restrict__ prog, unsigned char* smem, int n_stage,
+                                                                int n_lev, int C, int tid, int n_threads) {
+    const int Lp = C * VEC;
+    T* p0 = reinterpret_cast<T*>(smem);
+    T* p1 = p0 + (size_t)n_stage * Lp;
+    uint8_t* code = reinterpret_cast<uint8_t*>(p1 + (size_t)n_stage * Lp);
+    for (int i = tid; i < n_stage * Lp; i += n_threads) {
+        const int s = i / Lp, l = i - s * Lp;
+        const atx_level_op o = prog[(int64_t)s * n_lev + (l < n_lev ? l : n_lev - 1)];
+        p0[i] = static_cast<T>(o.p0);
+        p1[i] = static_cast<T>(o.p1);
+        code[i] = (uint8_t)((o.op & 0x7f) | (o.use_mask ? 0x80 : 0));
+    }
+    LevelTablesLds<T> t;
+    t.p0 = p0;
+    t.p1 = p1;
+    t.code = code;
+    t.Lp = Lp;
+    return t;
+}
+
+// Does any stage do something to vector column c?  (ATX_OP_COPY without the mask is the zero byte.)
+template <typename T, int VEC>
+__device__ __forceinline__ bool level_tables_active(const LevelTablesLds<T>& t, int n_stage, int c) {
+    using OpWord = typename OpWordOf<VEC>::type;
+    unsigned any = 0;
+    for (int s = 0; s < n_stage; ++s) any |= *reinterpret_cast<const OpWord*>(t.code + (size_t)s * t.Lp + c * VEC);
+    return any != 0;
+}
+
+// All stages applied to the vector of column c.
+template <typename T, int VEC, bool TRANS = true>
+__device__ __forceinline__ void apply_level_tables(const LevelTablesLds<T>& t, int n_stage, int c, Pack<T, VEC>& v, bool masked) {
+    using V = Pack<T, VEC>;
+    using OpWord = typename OpWordOf<VEC>::type;
+    constexpr unsigned kRep = VEC == 4 ? 0x01010101u : (VEC == 2 ? 0x0101u : 0x01u);
+    for (int s = 0; s < n_stage; ++s) {
+        const unsigned wd = *reinterpret_cast<const OpWord*>(t.code + (size_t)s * t.Lp + c * VEC);
+        if (wd == 0) continue;
+        const V a = *reinterpret_cast<const V*>(t.p0 + (size_t)s * t.Lp + c * VEC);
+        const V b = *reinterpret_cast<const V*>(t.p1 + (size_t)s * t.Lp + c * VEC);
+        const unsigned first = wd & 0xffu;
+        if (wd == first * kRep) {  // one operator kind over the vector's levels (their parameters may differ)
+            apply_level_op_params<T, VEC, TRANS>((int)(first & 0x7fu), (first & 0x80u) != 0, a, b, v, masked);
+        } else {
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) {
+                const unsigned code = (wd >> (8 * e)) & 0xffu;
+                LevelOp<T> o;
+                o.op = (int)(code & 0x7fu);
+                o.use_mask = (int)(code >> 7);
+                o.p0 = a.v[e];
+                o.p1 = b.v[e];
+                v.v[e] = apply_level_op<T, TRANS>(o, v.v[e], masked);
+            }
+        }
+    }
+}
+
 constexpr int kOpMixed = -1;  // marker in a per-vector operator table: the vector's levels differ
 
 __device__ __forceinline__ bool same_bits(float a, float b) { return __float_as_uint(a) == __float_as_uint(b); }

@@ -78,9 +78,8 @@ pointwise_cols_kernel(const T* __restrict__ x, T* __restrict__ y, int64_t n_pts,
                       const uint8_t* __restrict__ point_mask, int in_place) {
     using V = Pack<T, VEC>;
     extern __shared__ __align__(16) unsigned char smem[];
-    LevelOp<T>* vec_ops = reinterpret_cast<LevelOp<T>*>(smem);  // [n_stage][C]
     const int tid = threadIdx.x;
-    build_vector_ops<T, VEC>(prog, vec_ops, n_stage, n_lev, C, tid, kBlock);
+    const LevelTablesLds<T> tab = build_level_tables<T, VEC>(prog, smem, n_stage, n_lev, C, tid, kBlock);
     __syncthreads();
 
     const int Cg = C < kBlock ? C : kBlock;
@@ -91,11 +90,7 @@ pointwise_cols_kernel(const T* __restrict__ x, T* __restrict__ y, int64_t n_pts,
     const int64_t chunk = (int64_t)rows_per_pass * kPwUnroll;
 
     for (int c = cl; c < C; c += Cg) {
-        bool act = false;
-        for (int s = 0; s < n_stage; ++s) {
-            const LevelOp<T> o = vec_ops[s * C + c];
-            act = act || o.op != ATX_OP_COPY || o.use_mask != 0;
-        }
+        const bool act = level_tables_active<T, VEC>(tab, n_stage, c);
         if (!act && in_place) continue;  // untouched levels of an in-place call: nothing to move
         for (int64_t row0 = (int64_t)blockIdx.x * chunk; row0 < n_pts; row0 += (int64_t)gridDim.x * chunk) {
             V v[kPwUnroll];
@@ -113,7 +108,7 @@ pointwise_cols_kernel(const T* __restrict__ x, T* __restrict__ y, int64_t n_pts,
                 if (!ok[u]) continue;
                 if (act) {
                     const bool masked = point_mask ? (point_mask[pp[u]] != 0) : false;
-                    apply_program_vec<T, VEC>(vec_ops, prog, n_stage, n_lev, C, c, v[u], masked);
+                    apply_level_tables<T, VEC>(tab, n_stage, c, v[u], masked);
                 }
                 pw_store<T, VEC>(y + pp[u] * y_pitch + (int64_t)c * VEC, v[u]);
             }
@@ -212,29 +207,12 @@ pointwise_cols_levels_kernel(const T* __restrict__ x, T* __restrict__ y, int64_t
                              const atx_level_op* __restrict__ prog, int n_stage,
                              const uint8_t* __restrict__ point_mask, int in_place) {
     using V = Pack<T, VEC>;
-    using OpWord = typename std::conditional<VEC == 4, uint32_t, uint16_t>::type;
-    static_assert(VEC == 4 || VEC == 2, "16-byte vectors of float or double");
-    constexpr unsigned kRep = VEC == 4 ? 0x01010101u : 0x0101u;
     extern __shared__ __align__(16) unsigned char smem[];
-    const int Lp = C * VEC;  // levels incl. the padding of the last vector (it repeats the last level's operator)
-    T* lp0 = reinterpret_cast<T*>(smem);                             // [n_stage][Lp]
-    T* lp1 = lp0 + (size_t)n_stage * Lp;                             // [n_stage][Lp]
-    uint8_t* opb = reinterpret_cast<uint8_t*>(lp1 + (size_t)n_stage * Lp);  // [n_stage][Lp]
-    uint8_t* active = opb + (size_t)n_stage * Lp;                    // [C]: the vector has a level that is not a plain COPY
     const int tid = threadIdx.x;
-    for (int i = tid; i < n_stage * Lp; i += kBlock) {
-        const int s = i / Lp, l = i - s * Lp;
-        const atx_level_op o = prog[(int64_t)s * n_lev + (l < n_lev ? l : n_lev - 1)];
-        lp0[i] = static_cast<T>(o.p0);
-        lp1[i] = static_cast<T>(o.p1);
-        opb[i] = (uint8_t)((o.op & 0x7f) | (o.use_mask ? 0x80 : 0));
-    }
+    const LevelTablesLds<T> tab = build_level_tables<T, VEC>(prog, smem, n_stage, n_lev, C, tid, kBlock);
+    uint8_t* active = smem + level_tables_lds_bytes<T>(n_stage, C, VEC);  // [C]: the vector has a level that is not a plain COPY
     __syncthreads();
-    for (int c = tid; c < C; c += kBlock) {
-        unsigned any = 0;
-        for (int s = 0; s < n_stage; ++s) any |= *reinterpret_cast<const OpWord*>(opb + (size_t)s * Lp + c * VEC);
-        active[c] = any ? 1 : 0;  // ATX_OP_COPY without the mask is the zero byte
-    }
+    for (int c = tid; c < C; c += kBlock) active[c] = level_tables_active<T, VEC>(tab, n_stage, c) ? 1 : 0;
     __syncthreads();
 
     const int64_t n_vec = n_pts * C;
@@ -263,27 +241,7 @@ pointwise_cols_levels_kernel(const T* __restrict__ x, T* __restrict__ y, int64_t
             if (!ok[u]) continue;
             if (act[u]) {
                 const bool masked = point_mask ? (point_mask[row[u]] != 0) : false;
-                for (int s = 0; s < n_stage; ++s) {
-                    const unsigned wd = *reinterpret_cast<const OpWord*>(opb + (size_t)s * Lp + col[u] * VEC);
-                    if (wd == 0) continue;
-                    const V a = *reinterpret_cast<const V*>(lp0 + (size_t)s * Lp + col[u] * VEC);
-                    const V b = *reinterpret_cast<const V*>(lp1 + (size_t)s * Lp + col[u] * VEC);
-                    const unsigned first = wd & 0xffu;
-                    if (wd == first * kRep) {  // one operator kind over the vector's levels (their parameters may differ)
-                        apply_level_op_params<T, VEC, TRANS>((int)(first & 0x7fu), (first & 0x80u) != 0, a, b, v[u], masked);
-                    } else {
-#pragma unroll
-                        for (int e = 0; e < VEC; ++e) {
-                            const unsigned code = (wd >> (8 * e)) & 0xffu;
-                            LevelOp<T> o;
-                            o.op = (int)(code & 0x7fu);
-                            o.use_mask = (int)(code >> 7);
-                            o.p0 = a.v[e];
-                            o.p1 = b.v[e];
-                            v[u].v[e] = apply_level_op<T, TRANS>(o, v[u].v[e], masked);
-                        }
-                    }
-                }
+                apply_level_tables<T, VEC, TRANS>(tab, n_stage, col[u], v[u], masked);
             }
             if (NT) pw_store_nt<T, VEC>(y + (base + u * kBlock + tid) * VEC, v[u]);
             else pw_store<T, VEC>(y + (base + u * kBlock + tid) * VEC, v[u]);
@@ -886,8 +844,7 @@ static int pointwise_typed(const void* x_, void* y_, int64_t n_pts, int n_lev, i
         const int64_t covered = ((int64_t)(n_lev + VEC - 1) / VEC) * VEC;
         const bool wide = vec_ok && covered <= xp && covered <= yp;
         const int C = wide ? (n_lev + VEC - 1) / VEC : n_lev;
-        const size_t lds = (size_t)n_stage * C * sizeof(LevelOp<T>);
-        ATX_REQUIRE(lds <= 64 * 1024, ATX_ENOTIMPL, "pointwise: program needs %zu B of LDS", lds);
+        const size_t lds = (size_t)n_stage * C * sizeof(LevelOp<T>);  // (the older chunked kernel's per-vector table)
 #ifndef ATX_PW_SPARSE
 #define ATX_PW_SPARSE 1
 #endif
@@ -993,7 +950,7 @@ static int pointwise_typed(const void* x_, void* y_, int64_t n_pts, int n_lev, i
 #ifndef ATX_PW_LEVELS
 #define ATX_PW_LEVELS 1  // 0: round 2's chunked kernel (per-vector operators in LDS, mixed vectors from the global program)
 #endif
-            const size_t lds_levels = (size_t)n_stage * C * VEC * (2 * sizeof(T) + 1) + (size_t)C;
+            const size_t lds_levels = level_tables_lds_bytes<T>(n_stage, C, VEC) + (size_t)C;
             if (ATX_PW_LEVELS && lds_levels <= 64 * 1024) {
 #ifndef ATX_PW_LEVELS_NT
 #define ATX_PW_LEVELS_NT 1
@@ -1021,6 +978,7 @@ static int pointwise_typed(const void* x_, void* y_, int64_t n_pts, int n_lev, i
                 return ATX_OK;
             }
             const size_t lds_flat = lds + (size_t)C;
+            ATX_REQUIRE(lds_flat <= 64 * 1024, ATX_ENOTIMPL, "pointwise: program needs %zu B of LDS", lds_flat);
             if (program_has_transcendental(host_prog, n_stage, n_lev))
                 hipLaunchKernelGGL((pointwise_cols_flat_kernel<T, VEC, true>), dim3((unsigned)blocks), dim3(kBlock), lds_flat, st, x, y, n_pts, n_lev,
                                    C, prog, n_stage, mask, in_place);
@@ -1030,15 +988,17 @@ static int pointwise_typed(const void* x_, void* y_, int64_t n_pts, int n_lev, i
             ATX_LAUNCH_CHECK("pointwise_stack");
             return ATX_OK;
         }
+        const size_t lds_rows = level_tables_lds_bytes<T>(n_stage, C, wide ? VEC : 1);
+        ATX_REQUIRE(lds_rows <= 64 * 1024, ATX_ENOTIMPL, "pointwise: program needs %zu B of LDS", lds_rows);
         const int Cg = C < kBlock ? C : kBlock;
         const int64_t chunk = (int64_t)(kBlock / Cg) * kPwUnroll;  // rows one workgroup moves per iteration
         int64_t blocks = (n_pts + chunk - 1) / chunk;
         if (blocks > kMaxGrid) blocks = kMaxGrid;
         if (wide)
-            hipLaunchKernelGGL((pointwise_cols_kernel<T, VEC>), dim3((unsigned)blocks), dim3(kBlock), lds, st, x, y, n_pts, n_lev, C, xp,
+            hipLaunchKernelGGL((pointwise_cols_kernel<T, VEC>), dim3((unsigned)blocks), dim3(kBlock), lds_rows, st, x, y, n_pts, n_lev, C, xp,
                                yp, prog, n_stage, mask, in_place);
         else
-            hipLaunchKernelGGL((pointwise_cols_kernel<T, 1>), dim3((unsigned)blocks), dim3(kBlock), lds, st, x, y, n_pts, n_lev, C, xp,
+            hipLaunchKernelGGL((pointwise_cols_kernel<T, 1>), dim3((unsigned)blocks), dim3(kBlock), lds_rows, st, x, y, n_pts, n_lev, C, xp,
                                yp, prog, n_stage, mask, in_place);
     } else {
         ATX_REQUIRE(n_lev <= 65535, ATX_ENOTIMPL, "pointwise: n_lev=%d exceeds grid.y", n_lev);

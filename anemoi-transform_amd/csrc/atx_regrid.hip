@@ -130,8 +130,7 @@ regrid_cols_ell_kernel(EllBatch batch,
     // LDS carve: weights (widest type first), indices, then the level program
     T* w_s = reinterpret_cast<T*>(smem);
     int32_t* idx_s = reinterpret_cast<int32_t*>(w_s + (WEIGHTED ? (size_t)tile * k : 0));
-    LevelOp<T>* prog_s = reinterpret_cast<LevelOp<T>*>(
-        smem + (((WEIGHTED ? (size_t)tile * k * sizeof(T) : 0) + (size_t)tile * k * sizeof(int32_t) + 15) & ~size_t(15)));
+    unsigned char* prog_s = smem + (((WEIGHTED ? (size_t)tile * k * sizeof(T) : 0) + (size_t)tile * k * sizeof(int32_t) + 15) & ~size_t(15));
 
 #if ATX_NO_XCD
     const unsigned tile_id = blockIdx.x;
@@ -146,8 +145,8 @@ regrid_cols_ell_kernel(EllBatch batch,
         idx_s[i] = load_once(idx + t0 * k + i);
         if (WEIGHTED) w_s[i] = load_once(w + t0 * k + i);
     }
-    LevelOp<T>* vops_s = prog_s;  // [n_stage][C] vector-column operators
-    if (EPI) build_vector_ops<T, VEC>(prog, vops_s, n_stage, n_lev, C, tid, kEllBlock);
+    LevelTablesLds<T> tab{};  // the operators of every level (atx_common.hpp)
+    if (EPI) tab = build_level_tables<T, VEC>(prog, prog_s, n_stage, n_lev, C, tid, kEllBlock);
     __syncthreads();
 
     const int items = nt * C;
@@ -251,7 +250,7 @@ regrid_cols_ell_kernel(EllBatch batch,
                 const int64_t row = tgt_rows ? (int64_t)tgt_rows[t0 + tt[u]] : t0 + tt[u];  // (uniform branch)
                 if (EPI) {
                     const bool masked = tgt_mask ? (tgt_mask[row] != 0) : false;
-                    apply_program_vec<T, VEC>(vops_s, prog, n_stage, n_lev, C, cc[u], acc[u], masked);
+                    apply_level_tables<T, VEC>(tab, n_stage, cc[u], acc[u], masked);
                 }
                 store_out(reinterpret_cast<V*>(out + row * out_pitch + (int64_t)cc[u] * VEC), acc[u]);
             }
@@ -415,8 +414,7 @@ regrid_cols_csr_kernel(const T* __restrict__ src, T* __restrict__ out,
     T* w_s = reinterpret_cast<T*>(smem);
     int32_t* idx_s = reinterpret_cast<int32_t*>(w_s + cap);
     int32_t* rp_s = idx_s + cap;
-    LevelOp<T>* prog_s = reinterpret_cast<LevelOp<T>*>(
-        smem + (((size_t)cap * (sizeof(T) + sizeof(int32_t)) + (size_t)(tile + 1) * sizeof(int32_t) + 15) & ~size_t(15)));
+    unsigned char* prog_s = smem + (((size_t)cap * (sizeof(T) + sizeof(int32_t)) + (size_t)(tile + 1) * sizeof(int32_t) + 15) & ~size_t(15));
 
     const unsigned tile_id = xcd_tile(blockIdx.x, n_tiles);
     const int64_t t0 = (int64_t)tile_id * tile;
@@ -424,8 +422,8 @@ regrid_cols_csr_kernel(const T* __restrict__ src, T* __restrict__ out,
     const int tid = threadIdx.x;
 
     for (int i = tid; i <= nt; i += kBlock) rp_s[i] = indptr[t0 + i];
-    LevelOp<T>* vops_s = prog_s;  // [n_stage][C] vector-column operators
-    if (EPI) build_vector_ops<T, VEC>(prog, vops_s, n_stage, n_lev, C, tid, kBlock);
+    LevelTablesLds<T> tab{};  // the operators of every level (atx_common.hpp)
+    if (EPI) tab = build_level_tables<T, VEC>(prog, prog_s, n_stage, n_lev, C, tid, kBlock);
     __syncthreads();
     const int64_t base = rp_s[0];
     const int nnz_tile = rp_s[nt] - rp_s[0];
@@ -474,7 +472,7 @@ regrid_cols_csr_kernel(const T* __restrict__ src, T* __restrict__ out,
         const int64_t row = tgt_rows ? (int64_t)tgt_rows[t0 + t] : t0 + t;  // ordered traversal: CSR row t is output row tgt_rows[t]
         if (EPI) {
             const bool masked = tgt_mask ? (tgt_mask[row] != 0) : false;
-            apply_program_vec<T, VEC>(vops_s, prog, n_stage, n_lev, C, c, acc, masked);
+            apply_level_tables<T, VEC>(tab, n_stage, c, acc, masked);
         }
         store_out(reinterpret_cast<V*>(out + row * out_pitch + (int64_t)c * VEC), acc);
     }
@@ -701,7 +699,7 @@ static int launch_cols_ell(const EllBatch& batch, const int32_t* idx, const T* w
     const unsigned n_tiles = (unsigned)((n_tgt + tile - 1) / tile);
     size_t lds = (size_t)tile * k * (sizeof(int32_t) + (WEIGHTED ? sizeof(T) : 0));
     lds = (lds + 15) & ~size_t(15);
-    if (prog) lds += (size_t)n_stage * C * sizeof(LevelOp<T>);
+    if (prog) lds += level_tables_lds_bytes<T>(n_stage, C, VEC);
     ATX_REQUIRE(lds <= 64 * 1024, ATX_ENOTIMPL, "regrid_ell: tile needs %zu B of LDS (k=%d, n_lev=%d, stages=%d)", lds, k, n_lev, n_stage);
     constexpr int KT = K > 4 ? 0 : K;  // the tiled kernel keeps k > 4 on its runtime-k loop (compile-time k would hold 4 x k vectors per lane)
     if (prog) {
@@ -851,7 +849,7 @@ static int launch_cols_csr(const T* src, T* out, const int32_t* indptr, const in
     if (cap > 4096) cap = 4096;
     size_t lds = (size_t)cap * (sizeof(T) + sizeof(int32_t)) + (size_t)(tile + 1) * sizeof(int32_t);
     lds = (lds + 15) & ~size_t(15);
-    if (prog) lds += (size_t)n_stage * C * sizeof(LevelOp<T>);
+    if (prog) lds += level_tables_lds_bytes<T>(n_stage, C, VEC);
     ATX_REQUIRE(lds <= 64 * 1024, ATX_ENOTIMPL, "regrid_csr: tile needs %zu B of LDS", lds);
     if (prog) {
         hipLaunchKernelGGL((regrid_cols_csr_kernel<T, VEC, true>), dim3(n_tiles), dim3(kBlock), lds, st, src, out, indptr,

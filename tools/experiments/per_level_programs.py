@@ -46,6 +46,8 @@ def main():
     tgt = lookup("0.25")
     idx, w = interp.knn_inverse_distance(src, tgt, k=4)
     plan = GatherPlan(n, len(tgt["latitudes"]), index=idx, weights=w)
+    keep = (np.arange(idx.size) % 9 != 0).reshape(idx.shape)
+    csr = GatherPlan(n, len(tgt["latitudes"]), csr=(w[keep], idx[keep], np.concatenate([[0], np.cumsum(keep.sum(axis=1))])))
     for L in (137, 13):
         for tdt, B, tag in ((torch.float32, 4, "f32"), (torch.float64, 8, "f64")):
             x = bench.synth_stack(src, L, tdt, dev, 0, COLUMNS)
@@ -77,6 +79,14 @@ def main():
                     ms0 = launches(lambda: plan.apply(x))
                     ms = launches(lambda: plan.apply(x, prog=prog, n_stage=len(stages)))
                     print(f"L={L:3d} {tag} regrid k=4 + {name:46s} {ms:7.3f} ms  (no epilogue {ms0:.3f} ms)", flush=True)
+                # the same epilogues on the general CSR kernel (ragged rows 3-4, forced off the padded route) and a general operator (tiled kernel)
+                prog = native.level_program(cases["a scale per level"], dev)
+                ms0 = launches(lambda: csr.apply(x))
+                ms = launches(lambda: csr.apply(x, prog=prog, n_stage=1))
+                print(f"L={L:3d} {tag} regrid_csr ragged(3-4) + a scale per level                       {ms:7.3f} ms  (no epilogue {ms0:.3f} ms)", flush=True)
+                prog = native.level_program(cases["scale / clip alternating"], dev)
+                ms = launches(lambda: plan.apply(x, prog=prog, n_stage=1))
+                print(f"L={L:3d} {tag} regrid k=4 + scale / clip alternating (general operators: tiled kernel) {ms:7.3f} ms", flush=True)
             del x, y
             torch.cuda.empty_cache()
 
