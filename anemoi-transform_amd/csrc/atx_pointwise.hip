@@ -10,6 +10,7 @@
 // HBM-bound: 16-byte loads/stores, grid-strided over up to kStreamGrid short workgroups; levels whose program is all-COPY are not touched when the
 // operation is in place.
 #include "atx_common.hpp"
+#include <algorithm>
 #include <type_traits>
 
 namespace atx {
@@ -474,6 +475,114 @@ pointwise_fields_kernel(const T* __restrict__ x, T* __restrict__ y, int64_t n_pt
                 for (int s = 0; s < n_stage; ++s) v = apply_level_op(ops[s], v, masked);
             }
             ys[i] = v;
+        }
+    }
+}
+
+// ATX_FIELDS, round 3: one 16-byte vector per lane, no loop — grid.x = 1 KB-per-wave pieces of a field, grid.y = field.  The field's
+// operators (uniform over the workgroup: scalar loads, scalar branches) stay in registers because the stage loop is fully unrolled
+// — the kernel above indexes ops[] with a run-time stage count, which put the array in scratch memory: 137 fields of O1280 ran at
+// 0.40-0.44 of the HBM peak, two stages at 0.29 (tools/experiments/fields_pointwise.py).  The mask bytes of a vector's VEC points
+// come as one 2- / 4-byte load (mask_vec: the mask base is aligned for it); non-temporal accesses when no mask is read.
+// Measured on 137 fields of O1280 (profiles/r03_fields_pointwise.log; run-to-run noise ~3 %): requesting the data before the field's
+// operators are known (out of place only — in place an untouched field must not be read) f32 0.78 -> 0.83, f64 neutral; two vectors
+// per lane f64 0.75-0.77 -> 0.78-0.80 (and an in-place call that skips two fields in three 1.25 -> 0.95 ms), f32 in place 0.78 -> 0.75.
+#ifndef ATX_PW_FIELDS_U32
+#define ATX_PW_FIELDS_U32 1  // vectors per lane (kBlock apart), float32
+#endif
+#ifndef ATX_PW_FIELDS_U64
+#define ATX_PW_FIELDS_U64 2  // float64
+#endif
+#ifndef ATX_PW_FIELDS_EARLY
+#define ATX_PW_FIELDS_EARLY 1
+#endif
+template <typename T>
+constexpr int fields_vectors_per_lane() {
+    return sizeof(T) == 4 ? ATX_PW_FIELDS_U32 : ATX_PW_FIELDS_U64;
+}
+template <typename T, int VEC, bool TRANS, bool NT>
+__global__ void __launch_bounds__(kBlock)
+pointwise_fields_rows_kernel(const T* __restrict__ x, T* __restrict__ y, int64_t n_pts, int n_lev,
+                             int64_t x_pitch, int64_t y_pitch, const atx_level_op* __restrict__ prog, int n_stage,
+                             const uint8_t* __restrict__ point_mask, int in_place, int mask_vec) {
+    using V = Pack<T, VEC>;
+    using MaskWord = typename OpWordOf<VEC>::type;
+    constexpr int U = fields_vectors_per_lane<T>();
+    const int l = blockIdx.y;
+    const T* xs = x + (int64_t)l * x_pitch;
+    T* ys = y + (int64_t)l * y_pitch;
+    const int64_t n_vec = n_pts / VEC;
+    const int64_t base = (int64_t)blockIdx.x * (kBlock * U) + threadIdx.x;
+    V v[U];
+    const bool early = ATX_PW_FIELDS_EARLY && !in_place;
+    if (early) {
+#pragma unroll
+        for (int k = 0; k < U; ++k)
+            if (base + k * kBlock < n_vec) v[k] = NT ? pw_load_nt<T, VEC>(xs + (base + k * kBlock) * VEC) : pw_load<T, VEC>(xs + (base + k * kBlock) * VEC);
+    }
+    LevelOp<T> ops[8];
+    bool act = false, need_mask = false;
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+        ops[s].op = ATX_OP_COPY;
+        ops[s].use_mask = 0;
+        ops[s].p0 = ops[s].p1 = T(0);
+        if (s < n_stage) {
+            ops[s] = load_level_op<T>(prog, (int64_t)s * n_lev + l);
+            act = act || ops[s].op != ATX_OP_COPY || ops[s].use_mask != 0;
+            need_mask = need_mask || ops[s].use_mask != 0;
+        }
+    }
+    if (!act && in_place) return;  // untouched field: identity (R: filter.py:193-194)
+    if (!early) {
+#pragma unroll
+        for (int k = 0; k < U; ++k)
+            if (base + k * kBlock < n_vec) v[k] = NT ? pw_load_nt<T, VEC>(xs + (base + k * kBlock) * VEC) : pw_load<T, VEC>(xs + (base + k * kBlock) * VEC);
+    }
+#pragma unroll
+    for (int k = 0; k < U; ++k) {
+        const int64_t vi = base + k * kBlock;
+        if (vi >= n_vec) continue;
+        if (act) {
+            unsigned mbits = 0;  // byte e: the mask of point vi * VEC + e
+            if (need_mask && point_mask) {
+                if (mask_vec) {
+                    mbits = *reinterpret_cast<const MaskWord*>(point_mask + vi * VEC);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) mbits |= (unsigned)point_mask[vi * VEC + e] << (8 * e);
+                }
+            }
+#pragma unroll
+            for (int s = 0; s < 8; ++s) {
+                if (s < n_stage) {
+                    LevelOp<T> o = ops[s];
+                    const bool use_mask = o.use_mask != 0;
+                    o.use_mask = 0;
+                    apply_level_op_vec<T, VEC, TRANS>(o, v[k], false);
+                    if (use_mask) {
+#pragma unroll
+                        for (int e = 0; e < VEC; ++e)
+                            if ((mbits >> (8 * e)) & 0xffu) v[k].v[e] = quiet_nan<T>();
+                    }
+                }
+            }
+        }
+        if (NT) pw_store_nt<T, VEC>(ys + vi * VEC, v[k]);
+        else pw_store<T, VEC>(ys + vi * VEC, v[k]);
+    }
+    // tail points (n_pts % VEC) by the first lanes of block 0
+    if (VEC > 1 && blockIdx.x == 0) {
+        const int64_t i = n_vec * VEC + threadIdx.x;
+        if (threadIdx.x < VEC && i < n_pts) {
+            T t = xs[i];
+            if (act) {
+                const bool masked = point_mask ? (point_mask[i] != 0) : false;
+#pragma unroll
+                for (int s = 0; s < 8; ++s)
+                    if (s < n_stage) t = apply_level_op<T, TRANS>(ops[s], t, masked);
+            }
+            ys[i] = t;
         }
     }
 }
@@ -1002,6 +1111,38 @@ static int pointwise_typed(const void* x_, void* y_, int64_t n_pts, int n_lev, i
                                yp, prog, n_stage, mask, in_place);
     } else {
         ATX_REQUIRE(n_lev <= 65535, ATX_ENOTIMPL, "pointwise: n_lev=%d exceeds grid.y", n_lev);
+#ifndef ATX_PW_FIELDS_ROWS
+#define ATX_PW_FIELDS_ROWS 1  // 0: round 1's grid-stride kernel
+#endif
+        {
+            const int vec = vec_ok ? VEC : 1;
+            const int64_t per_block = (int64_t)kBlock * fields_vectors_per_lane<T>();
+            const int64_t gx_rows = (std::max<int64_t>(n_pts / vec, 1) + per_block - 1) / per_block;
+            if (ATX_PW_FIELDS_ROWS && gx_rows <= 0x7fffffffll) {
+                bool uses_mask = mask != nullptr;  // unknown program: assume it reads the mask it was given
+                if (host_prog && mask) {
+                    uses_mask = false;
+                    for (int64_t i = 0; i < (int64_t)n_stage * n_lev; ++i) uses_mask = uses_mask || host_prog[i].use_mask != 0;
+                }
+                const bool trans = program_has_transcendental(host_prog, n_stage, n_lev);
+                const bool nt = !uses_mask;
+                const int mask_vec = (reinterpret_cast<uintptr_t>(mask) % (uintptr_t)vec) == 0 ? 1 : 0;
+                const dim3 grid((unsigned)gx_rows, (unsigned)n_lev);
+#define ATX_PW_ROWS_LAUNCH(V_, TR_, NT_)                                                                                                 \
+    hipLaunchKernelGGL((pointwise_fields_rows_kernel<T, V_, TR_, NT_>), grid, dim3(kBlock), 0, st, x, y, n_pts, n_lev, xp, yp, prog, n_stage, \
+                       mask, in_place, mask_vec)
+                if (vec_ok) {
+                    if (trans) { if (nt) ATX_PW_ROWS_LAUNCH(VEC, true, true); else ATX_PW_ROWS_LAUNCH(VEC, true, false); }
+                    else { if (nt) ATX_PW_ROWS_LAUNCH(VEC, false, true); else ATX_PW_ROWS_LAUNCH(VEC, false, false); }
+                } else {
+                    if (trans) ATX_PW_ROWS_LAUNCH(1, true, false);
+                    else ATX_PW_ROWS_LAUNCH(1, false, false);
+                }
+#undef ATX_PW_ROWS_LAUNCH
+                ATX_LAUNCH_CHECK("pointwise_stack_fields");
+                return ATX_OK;
+            }
+        }
         unsigned gx = grid_for((n_pts + VEC - 1) / VEC);
         // grid.x * n_lev workgroups in all: about kStreamGrid
         const unsigned cap = (unsigned)((kMaxGrid + n_lev - 1) / n_lev);

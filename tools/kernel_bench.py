@@ -198,6 +198,12 @@ def main():
                dst_pitch=one_lev.pitch, layout=COLUMNS)), 2 * n_src * B, "one field out of a column stack: a 64-byte sector per point is the least that can move")
         del half, one_lev
         # ---- regrid on field-major
+        pf = native.level_program([[(native.OP_AFFINE, 0, 1.0 + 0.001 * l, -273.15) for l in range(L)]], dev)
+        g = f.new_like()
+        kwf = dict(n_pts=n_src, n_lev=L, x_pitch=f.pitch, y_pitch=g.pitch, layout=FIELDS)
+        record(f"pointwise affine, a scale per field {tag} fields (the reference's array order)",
+               timeit(lambda: native.pointwise_stack(f.data, g.data, prog=pf, n_stage=1, **kwf)), 2 * stack_bytes, "one vector per lane, grid.y = field")
+        del g
         record(f"regrid_ell k=4 {tag} fields", timeit(lambda: plan4.apply(f)), bench.algorithmic_bytes(L, B, U4, n_tgt, 4))
         # ---- masks / reductions on one field
         first = f.data[0].contiguous()
