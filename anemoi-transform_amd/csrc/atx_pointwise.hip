@@ -422,66 +422,9 @@ pointwise_cols_sparse_kernel(T* __restrict__ y, int64_t n_items, int n_lev, int 
     pw_store<T, VEC>(at, v);
 }
 
-// ATX_FIELDS: grid.y = level (operator uniform per workgroup), lanes along points.
-template <typename T, int VEC>
-__global__ void __launch_bounds__(kBlock)
-pointwise_fields_kernel(const T* __restrict__ x, T* __restrict__ y, int64_t n_pts, int n_lev,
-                        int64_t x_pitch, int64_t y_pitch, const atx_level_op* __restrict__ prog, int n_stage,
-                        const uint8_t* __restrict__ point_mask, int in_place) {
-    using V = Pack<T, VEC>;
-    const int l = blockIdx.y;
-    LevelOp<T> ops[8];
-    bool act = false;
-    for (int s = 0; s < n_stage; ++s) {
-        ops[s] = load_level_op<T>(prog, (int64_t)s * n_lev + l);
-        act = act || ops[s].op != ATX_OP_COPY || ops[s].use_mask != 0;
-    }
-    if (!act && in_place) return;  // untouched field: identity (R: filter.py:193-194)
-    const T* xs = x + (int64_t)l * x_pitch;
-    T* ys = y + (int64_t)l * y_pitch;
-    const int64_t n_vec = n_pts / VEC;
-    const int64_t stride = (int64_t)gridDim.x * kBlock;
-    for (int64_t i0 = (int64_t)blockIdx.x * kBlock + threadIdx.x; i0 < n_vec; i0 += stride * kPwUnroll) {
-        V v[kPwUnroll];
-        int64_t ii[kPwUnroll];
-        bool ok[kPwUnroll];
-#pragma unroll
-        for (int u = 0; u < kPwUnroll; ++u) {
-            ii[u] = i0 + (int64_t)u * stride;
-            ok[u] = ii[u] < n_vec;
-            if (!ok[u]) ii[u] = i0;
-            v[u] = *reinterpret_cast<const V*>(xs + ii[u] * VEC);
-        }
-#pragma unroll
-        for (int u = 0; u < kPwUnroll; ++u) {
-            if (!ok[u]) continue;
-            if (act) {
-#pragma unroll
-                for (int e = 0; e < VEC; ++e) {
-                    const bool masked = point_mask ? (point_mask[ii[u] * VEC + e] != 0) : false;
-                    for (int s = 0; s < n_stage; ++s) v[u].v[e] = apply_level_op(ops[s], v[u].v[e], masked);
-                }
-            }
-            *reinterpret_cast<V*>(ys + ii[u] * VEC) = v[u];
-        }
-    }
-    // tail points (n_pts % VEC) by the first lanes of block 0
-    if (blockIdx.x == 0) {
-        const int64_t i = n_vec * VEC + threadIdx.x;
-        if (threadIdx.x < VEC && i < n_pts) {
-            T v = xs[i];
-            if (act) {
-                const bool masked = point_mask ? (point_mask[i] != 0) : false;
-                for (int s = 0; s < n_stage; ++s) v = apply_level_op(ops[s], v, masked);
-            }
-            ys[i] = v;
-        }
-    }
-}
-
 // ATX_FIELDS, round 3: one 16-byte vector per lane, no loop — grid.x = 1 KB-per-wave pieces of a field, grid.y = field.  The field's
 // operators (uniform over the workgroup: scalar loads, scalar branches) stay in registers because the stage loop is fully unrolled
-// — the kernel above indexes ops[] with a run-time stage count, which put the array in scratch memory: 137 fields of O1280 ran at
+// — round 1's grid-stride kernel indexed ops[] with a run-time stage count, which put the array in scratch memory: 137 fields of O1280 ran at
 // 0.40-0.44 of the HBM peak, two stages at 0.29 (tools/experiments/fields_pointwise.py).  The mask bytes of a vector's VEC points
 // come as one 2- / 4-byte load (mask_vec: the mask base is aligned for it); non-temporal accesses when no mask is read.
 // Measured on 137 fields of O1280 (profiles/r03_fields_pointwise.log; run-to-run noise ~3 %): requesting the data before the field's
@@ -1111,14 +1054,12 @@ static int pointwise_typed(const void* x_, void* y_, int64_t n_pts, int n_lev, i
                                yp, prog, n_stage, mask, in_place);
     } else {
         ATX_REQUIRE(n_lev <= 65535, ATX_ENOTIMPL, "pointwise: n_lev=%d exceeds grid.y", n_lev);
-#ifndef ATX_PW_FIELDS_ROWS
-#define ATX_PW_FIELDS_ROWS 1  // 0: round 1's grid-stride kernel
-#endif
         {
             const int vec = vec_ok ? VEC : 1;
             const int64_t per_block = (int64_t)kBlock * fields_vectors_per_lane<T>();
             const int64_t gx_rows = (std::max<int64_t>(n_pts / vec, 1) + per_block - 1) / per_block;
-            if (ATX_PW_FIELDS_ROWS && gx_rows <= 0x7fffffffll) {
+            ATX_REQUIRE(gx_rows <= 0x7fffffffll, ATX_ENOTIMPL, "pointwise: %lld points per field exceed one launch", (long long)n_pts);
+            {
                 bool uses_mask = mask != nullptr;  // unknown program: assume it reads the mask it was given
                 if (host_prog && mask) {
                     uses_mask = false;
@@ -1142,17 +1083,6 @@ static int pointwise_typed(const void* x_, void* y_, int64_t n_pts, int n_lev, i
                 ATX_LAUNCH_CHECK("pointwise_stack_fields");
                 return ATX_OK;
             }
-        }
-        unsigned gx = grid_for((n_pts + VEC - 1) / VEC);
-        // grid.x * n_lev workgroups in all: about kStreamGrid
-        const unsigned cap = (unsigned)((kMaxGrid + n_lev - 1) / n_lev);
-        if (gx > cap) gx = cap < 1 ? 1 : cap;
-        if (vec_ok) {
-            hipLaunchKernelGGL((pointwise_fields_kernel<T, VEC>), dim3(gx, (unsigned)n_lev), dim3(kBlock), 0, st, x, y, n_pts,
-                               n_lev, xp, yp, prog, n_stage, mask, in_place);
-        } else {
-            hipLaunchKernelGGL((pointwise_fields_kernel<T, 1>), dim3(gx, (unsigned)n_lev), dim3(kBlock), 0, st, x, y, n_pts,
-                               n_lev, xp, yp, prog, n_stage, mask, in_place);
         }
     }
     ATX_LAUNCH_CHECK("pointwise_stack");

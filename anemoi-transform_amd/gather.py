@@ -247,11 +247,21 @@ class GatherPlan:
                 )
         return self._device[key]
 
+    def _long_rows(self) -> bool:
+        """More than 8 entries per row (on average, for ragged matrices)."""
+        if self.kind == "ell":
+            return self.k > 8
+        return len(self.indices) > 8 * max(self.n_tgt, 1)
+
     def apply(self, src: Stack, *, prog: torch.Tensor | None = None, n_stage: int = 0,
               tgt_mask: torch.Tensor | None = None) -> Stack:
         """Run the gather over every level of ``src``; returns a new stack on the target points."""
         # R: regrid.py:377-378 — the field must live on the plan's source grid
         assert src.n_pts == self.n_src, (src.n_pts, self.n_src)
+        if src.layout != COLUMNS and self.n_tgt > 0 and self._long_rows():
+            # field-major stacks and rows beyond 8 entries: through column stacks and back — the field-major gather re-fetches a source
+            # point once per row that uses it (O1280 -> 0.25 deg, k = 16, 137 fields: 11.5 ms direct, 2.5 ms with both conversions)
+            return self.apply(src.to_layout(COLUMNS), prog=prog, n_stage=n_stage, tgt_mask=tgt_mask).to_layout(src.layout)
         out = src.new_like(n_pts=self.n_tgt, zero=False)
         if self.n_tgt == 0:
             return out

@@ -146,6 +146,11 @@ int atx_set_tuning(int tile);
  *               (together with host_prog) for programs made of COPY / AFFINE / MUL with or without the mask, <= 4 stages.
  * Requirements: ATX_COLUMNS with 16-byte aligned bases and pitches that are
  *   multiples of 16 bytes take the vector path; anything else a scalar path.
+ * Layouts (MI355X, O1280 -> 0.25 deg, 137 levels, fraction of the HBM peak on algorithmic bytes): ATX_COLUMNS is the gather's
+ *   layout — k = 4: 0.68-0.70, k = 16: 0.52-0.59.  ATX_FIELDS (the reference's array order) runs k <= 4 and short ragged rows at
+ *   0.35-0.42, but a row of more than ~8 entries re-fetches every source point once per row that uses it (k = 16: 11.5 ms against
+ *   0.93 ms): convert such stacks with atx_relayout first — both conversions included that is still 4x faster (what
+ *   GatherPlan.apply does by itself).  The per-point entry points run field-major stacks at full speed (0.79-0.84).
  */
 #define ATX_ELL_PADDED 1
 int atx_regrid_ell(const void* src, void* out, const int32_t* idx, const void* w,

@@ -625,6 +625,35 @@ def test_shard_bounds_invariants_on_random_plans(monkeypatch):
         assert np.array_equal(np.concatenate(parts, axis=1), full, equal_nan=True), (case, kind, world)
 
 
+def test_long_rows_on_field_major_stacks_go_through_columns(monkeypatch):
+    """A field-major stack and rows of more than 8 entries: GatherPlan.apply converts to columns, gathers and converts back (4x faster
+    than the field-major gather on MI355X) — same values, same layout as what came in; short rows stay on the field-major kernel."""
+    import native_double
+    import torch
+    from anemoi_transform_amd.stack import COLUMNS, FIELDS, Stack
+
+    native_double.install(monkeypatch)
+    seen = []
+    real = native.relayout
+    monkeypatch.setattr(native, "relayout", lambda *a, **k: (seen.append((k["src_layout"], k["dst_layout"])), real(*a, **k))[1])
+    rng = np.random.default_rng(3)
+    n_src, n_tgt = 200, 90
+    fields = rng.standard_normal((5, n_src))
+    x_f = Stack.from_fields(fields, dev=torch.device("cpu")).to_layout(FIELDS)
+    seen.clear()
+    for k, converts in ((4, False), (12, True)):
+        plan = GatherPlan(n_src, n_tgt, index=rng.integers(0, n_src, (n_tgt, k)), weights=rng.random((n_tgt, k)))
+        out = plan.apply(x_f)
+        assert out.layout == FIELDS and seen == ([(FIELDS, COLUMNS), (COLUMNS, FIELDS)] if converts else []), (k, seen)
+        assert np.array_equal(out.numpy(), plan.apply(x_f.to_layout(COLUMNS)).numpy())
+        seen.clear()
+    lengths = rng.integers(6, 20, n_tgt)
+    indptr = np.concatenate([[0], np.cumsum(lengths)])
+    csr = GatherPlan(n_src, n_tgt, csr=(rng.random(int(indptr[-1])), rng.integers(0, n_src, int(indptr[-1])).astype(np.int32), indptr.astype(np.int32)))
+    out = csr.apply(x_f)
+    assert out.layout == FIELDS and seen[0] == (FIELDS, COLUMNS) and seen[-1] == (COLUMNS, FIELDS)
+
+
 def test_design_tables_are_generated():
     """DESIGN.md's measured tables come from the tracked JSON records (tools/design_tables.py): hand-copied cells drifted in round 2."""
     import subprocess
