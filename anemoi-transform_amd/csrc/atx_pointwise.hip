@@ -995,6 +995,9 @@ static int pointwise_typed(const void* x_, void* y_, int64_t n_pts, int n_lev, i
                 ATX_LAUNCH_CHECK("pointwise_stack");
                 return ATX_OK;
             }
+            // (A no-loop kernel reading the typed per-level part of vec_prog — the shape of the by-value kernel — was measured against
+            // the per-level LDS kernel below and dropped: one stage f64 +3-4 %, f32 in place +7 %, but f32 out of place -5 %, vectors of
+            // mixed operator kinds -10 to -15 %, two stages -23 %; profiles/r03_per_level_programs.log.)
             const int64_t n_chunks = (n_vec + (int64_t)kBlock * kPwUnroll - 1) / ((int64_t)kBlock * kPwUnroll);
             int64_t blocks = n_chunks > kMaxGrid ? kMaxGrid : n_chunks;
             const int64_t per = (n_chunks + blocks - 1) / blocks;
