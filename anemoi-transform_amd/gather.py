@@ -289,7 +289,7 @@ class GatherPlan:
         first = stacks[0]
         same = all((s.n_pts, s.n_lev, s.dtype, s.layout, s.pitch) == (first.n_pts, first.n_lev, first.dtype, first.layout, first.pitch)
                    for s in stacks)
-        if self.kind != "ell" or not same or self.n_tgt == 0 or len(stacks) == 1:
+        if self.kind != "ell" or not same or self.n_tgt == 0 or len(stacks) == 1 or (first.layout != COLUMNS and self._long_rows()):
             return [self.apply(s) for s in stacks]
         assert first.n_pts == self.n_src, (first.n_pts, self.n_src)
         outs = [first.new_like(n_pts=self.n_tgt, zero=False) for _ in stacks]
