@@ -204,9 +204,10 @@ pointwise_cols_flat_kernel(const T* __restrict__ x, T* __restrict__ y, int64_t n
 // in place with skipped vectors 0.71 -> 0.48).
 template <typename T, int VEC, bool TRANS, bool NT>
 __global__ void __launch_bounds__(kBlock)
-pointwise_cols_levels_kernel(const T* __restrict__ x, T* __restrict__ y, int64_t n_pts, int n_lev, int C,
+pointwise_cols_levels_kernel(const T* __restrict__ x, T* __restrict__ y, int64_t n_pts, int n_lev, int C, int Cp,
                              const atx_level_op* __restrict__ prog, int n_stage,
                              const uint8_t* __restrict__ point_mask, int in_place) {
+    // Cp >= C: vector slots per row (pitch / VEC) — slots beyond the C that hold levels are padding: neither read nor written
     using V = Pack<T, VEC>;
     extern __shared__ __align__(16) unsigned char smem[];
     const int tid = threadIdx.x;
@@ -216,23 +217,24 @@ pointwise_cols_levels_kernel(const T* __restrict__ x, T* __restrict__ y, int64_t
     for (int c = tid; c < C; c += kBlock) active[c] = level_tables_active<T, VEC>(tab, n_stage, c) ? 1 : 0;
     __syncthreads();
 
-    const int64_t n_vec = n_pts * C;
+    const int64_t n_vec = n_pts * Cp;
     constexpr int64_t kChunk = (int64_t)kBlock * kPwUnroll;
     for (int64_t base = (int64_t)blockIdx.x * kChunk; base < n_vec; base += (int64_t)gridDim.x * kChunk) {
-        const int64_t row_b = base / C;  // uniform: scalar unit
-        const int col_b = (int)(base - row_b * C);
+        const int64_t row_b = base / Cp;  // uniform: scalar unit
+        const int col_b = (int)(base - row_b * Cp);
         V v[kPwUnroll];
         int64_t row[kPwUnroll];
         int col[kPwUnroll];
         bool ok[kPwUnroll], act[kPwUnroll];
 #pragma unroll
         for (int u = 0; u < kPwUnroll; ++u) {
-            const int off = col_b + u * kBlock + tid;  // < C + kChunk: 32-bit arithmetic
-            const int dr = off / C;
-            col[u] = off - dr * C;
+            const int off = col_b + u * kBlock + tid;  // < Cp + kChunk: 32-bit arithmetic
+            const int dr = off / Cp;
+            col[u] = off - dr * Cp;
             row[u] = row_b + dr;
             const int64_t vi = base + u * kBlock + tid;
-            ok[u] = vi < n_vec;
+            ok[u] = vi < n_vec && col[u] < C;
+            if (col[u] >= C) col[u] = 0;
             act[u] = active[col[u]] != 0;
             if (in_place && !act[u]) ok[u] = false;  // untouched levels of an in-place call: nothing to move
             if (ok[u]) v[u] = NT ? pw_load_nt<T, VEC>(x + vi * VEC) : pw_load<T, VEC>(x + vi * VEC);
@@ -315,8 +317,9 @@ pointwise_cols_table_kernel(const T* __restrict__ x, T* __restrict__ y, int64_t 
 // by the ~35-69 lanes of a point, live in the same caches), so masked programs keep plain accesses; profiles/r03_pointwise_ab.log.
 template <typename T, int VEC, bool TRANS, int U, bool NT>
 __global__ void __launch_bounds__(kBlock)
-pointwise_cols_uniform_kernel(const T* __restrict__ x, T* __restrict__ y, int64_t n_vec, int C, UniformOps<T> u,
+pointwise_cols_uniform_kernel(const T* __restrict__ x, T* __restrict__ y, int64_t n_vec, int C, int Cp, UniformOps<T> u,
                               const uint8_t* __restrict__ point_mask, int need_rc, int in_place, unsigned act_bits) {
+    // Cp >= C: vector slots per row (pitch / VEC); n_vec = n_pts * Cp; slots beyond C are padding (need_rc is set when Cp > C)
     using V = Pack<T, VEC>;
     // U vectors per lane, kBlock apart: a workgroup covers kBlock * U consecutive vectors (no loop)
     const int64_t base = (int64_t)blockIdx.x * (kBlock * U) + threadIdx.x;
@@ -332,13 +335,14 @@ pointwise_cols_uniform_kernel(const T* __restrict__ x, T* __restrict__ y, int64_
         if (go[k] && need_rc) {  // uniform: a two-piece stage or the point mask — the lane needs its (row, vector column)
             int64_t row;
             if (n_vec <= 0xffffffffll) {
-                const unsigned r = (unsigned)vi / (unsigned)C;
+                const unsigned r = (unsigned)vi / (unsigned)Cp;
                 row = r;
-                c[k] = (int)((unsigned)vi - r * (unsigned)C);
+                c[k] = (int)((unsigned)vi - r * (unsigned)Cp);
             } else {
-                row = vi / C;
-                c[k] = (int)(vi - row * C);
+                row = vi / Cp;
+                c[k] = (int)(vi - row * Cp);
             }
+            if (c[k] >= C) go[k] = false;  // padding slot of a loose pitch
             if (in_place) {  // untouched columns of an in-place call: nothing to move.  `act_bits` (host-built): bit s = the first
                 // piece of stage s does something, bit 4 + s = its second piece.  (Selecting between u.stage[s].op and u.second[s].op
                 // here made the compiler select between their ADDRESSES and load per lane from the kernel-argument segment, two
@@ -346,7 +350,7 @@ pointwise_cols_uniform_kernel(const T* __restrict__ x, T* __restrict__ y, int64_
                 unsigned act = 0;
 #pragma unroll
                 for (int s = 0; s < kMaxUniform; ++s) act |= (c[k] >= u.split[s]) ? (act_bits >> (4 + s)) : (act_bits >> s);
-                go[k] = (act & 1u) != 0;
+                go[k] = go[k] && (act & 1u) != 0;
             }
             if (go[k] && point_mask) masked[k] = point_mask[row] != 0;
         }
@@ -929,8 +933,13 @@ static int pointwise_typed(const void* x_, void* y_, int64_t n_pts, int n_lev, i
 #ifndef ATX_PW_FLAT
 #define ATX_PW_FLAT 1
 #endif
-        if (ATX_PW_FLAT && wide && xp == (int64_t)C * VEC && yp == xp) {  // one contiguous run of vectors: line-aligned chunks
-            const int64_t n_vec = n_pts * C;
+        // one contiguous run of vector slots (tight pitch), or — round 3 — equal loose pitches (columns aligned to 128 bytes, a spare
+        // vector): the same kernels walk the pitch / VEC slots of a row and leave the padding slots alone (the row-chunk kernel below:
+        // 0.51-0.57 f32, 0.69 f64 on such stacks)
+        const bool tight = xp == (int64_t)C * VEC;
+        if (ATX_PW_FLAT && wide && yp == xp && xp % VEC == 0 && xp / VEC <= 0x7fffffffll / 2) {
+            const int Cp = (int)(xp / VEC);
+            const int64_t n_vec = n_pts * Cp;
             // (1) programs uniform over the levels: operators by value, one vector per lane, no loop (pointwise_cols_uniform_kernel)
 #ifndef ATX_PW_UNIFORM
 #define ATX_PW_UNIFORM 1
@@ -945,7 +954,7 @@ static int pointwise_typed(const void* x_, void* y_, int64_t n_pts, int n_lev, i
                     if (uni.stage[s].op != ATX_OP_COPY || uni.stage[s].use_mask) act_bits |= 1u << s;
                     if (uni.second[s].op != ATX_OP_COPY || uni.second[s].use_mask) act_bits |= 1u << (4 + s);
                 }
-                const int need_rc = (two_pieces || (uses_mask && mask)) ? 1 : 0;
+                const int need_rc = (two_pieces || (uses_mask && mask) || !tight) ? 1 : 0;
                 const bool trans = program_has_transcendental(host_prog, n_stage, n_lev);
 #ifndef ATX_PW_UNIFORM_U_IN
 #define ATX_PW_UNIFORM_U_IN 1
@@ -961,7 +970,7 @@ static int pointwise_typed(const void* x_, void* y_, int64_t n_pts, int n_lev, i
 #endif
 #define ATX_PW_UNIFORM_LAUNCH(TR_, U_, NT_)                                                                                                \
     hipLaunchKernelGGL((pointwise_cols_uniform_kernel<T, VEC, TR_, U_, NT_>), dim3((unsigned)((n_vec + kBlock * U_ - 1) / (kBlock * U_))), \
-                       dim3(kBlock), 0, st, x, y, n_vec, C, uni, uses_mask ? mask : nullptr, need_rc, in_place, act_bits)
+                       dim3(kBlock), 0, st, x, y, n_vec, C, Cp, uni, uses_mask ? mask : nullptr, need_rc, in_place, act_bits)
                 const bool nt = ATX_PW_UNIFORM_NT && !(uses_mask && mask);
                 if (in_place) {
                     if (trans && nt && ATX_PW_TRANS_NT) ATX_PW_UNIFORM_LAUNCH(true, ATX_PW_UNIFORM_U_IN, true);
@@ -988,7 +997,7 @@ static int pointwise_typed(const void* x_, void* y_, int64_t n_pts, int n_lev, i
 #endif
             const bool table_narrow = !mask && sizeof(T) == 4 && n_stage == 1 && !in_place;
             const bool table_wide = ATX_PW_TABLE_RULE == 1 && !mask && sizeof(T) == 4 && n_stage == 1;
-            if (vec_prog && (table_narrow || table_wide) && (n_vec + kBlock - 1) / kBlock <= 0x7fffffffll &&
+            if (tight && vec_prog && (table_narrow || table_wide) && (n_vec + kBlock - 1) / kBlock <= 0x7fffffffll &&
                 !program_has_mixed_vectors<T>(host_prog, n_stage, n_lev, VEC)) {  // (mixed vectors: the chunked kernel serves them better)
                 hipLaunchKernelGGL((pointwise_cols_table_kernel<T, VEC>), dim3((unsigned)((n_vec + kBlock - 1) / kBlock)), dim3(kBlock), 0, st,
                                    x, y, n_vec, n_lev, C, prog, vec_prog, n_stage, mask, in_place);
@@ -1006,7 +1015,9 @@ static int pointwise_typed(const void* x_, void* y_, int64_t n_pts, int n_lev, i
 #define ATX_PW_LEVELS 1  // 0: round 2's chunked kernel (per-vector operators in LDS, mixed vectors from the global program)
 #endif
             const size_t lds_levels = level_tables_lds_bytes<T>(n_stage, C, VEC) + (size_t)C;
-            if (ATX_PW_LEVELS && lds_levels <= 64 * 1024) {
+            // (loose pitches: measured slower here than on the row-chunk kernel below — f64 0.57 against 0.69 — so only the by-value
+            // kernel above takes them; tools/experiments/loose_pitch.py)
+            if (ATX_PW_LEVELS && tight && lds_levels <= 64 * 1024) {
 #ifndef ATX_PW_LEVELS_NT
 #define ATX_PW_LEVELS_NT 1
 #endif
@@ -1022,26 +1033,28 @@ static int pointwise_typed(const void* x_, void* y_, int64_t n_pts, int n_lev, i
                 }
                 if (program_has_transcendental(host_prog, n_stage, n_lev))
                     hipLaunchKernelGGL((pointwise_cols_levels_kernel<T, VEC, true, false>), dim3((unsigned)blocks), dim3(kBlock), lds_levels, st, x, y,
-                                       n_pts, n_lev, C, prog, n_stage, mask, in_place);
+                                       n_pts, n_lev, C, Cp, prog, n_stage, mask, in_place);
                 else if (nt)
                     hipLaunchKernelGGL((pointwise_cols_levels_kernel<T, VEC, false, true>), dim3((unsigned)blocks), dim3(kBlock), lds_levels, st, x, y,
-                                       n_pts, n_lev, C, prog, n_stage, mask, in_place);
+                                       n_pts, n_lev, C, Cp, prog, n_stage, mask, in_place);
                 else
                     hipLaunchKernelGGL((pointwise_cols_levels_kernel<T, VEC, false, false>), dim3((unsigned)blocks), dim3(kBlock), lds_levels, st, x, y,
-                                       n_pts, n_lev, C, prog, n_stage, mask, in_place);
+                                       n_pts, n_lev, C, Cp, prog, n_stage, mask, in_place);
                 ATX_LAUNCH_CHECK("pointwise_stack_levels");
                 return ATX_OK;
             }
-            const size_t lds_flat = lds + (size_t)C;
-            ATX_REQUIRE(lds_flat <= 64 * 1024, ATX_ENOTIMPL, "pointwise: program needs %zu B of LDS", lds_flat);
-            if (program_has_transcendental(host_prog, n_stage, n_lev))
-                hipLaunchKernelGGL((pointwise_cols_flat_kernel<T, VEC, true>), dim3((unsigned)blocks), dim3(kBlock), lds_flat, st, x, y, n_pts, n_lev,
-                                   C, prog, n_stage, mask, in_place);
-            else  // no exp / log anywhere in the program: the low-register instantiation (8 instead of 4 waves per SIMD in float64)
-                hipLaunchKernelGGL((pointwise_cols_flat_kernel<T, VEC, false>), dim3((unsigned)blocks), dim3(kBlock), lds_flat, st, x, y, n_pts, n_lev,
-                                   C, prog, n_stage, mask, in_place);
-            ATX_LAUNCH_CHECK("pointwise_stack");
-            return ATX_OK;
+            if (tight) {  // very tall stacks: round 2's chunked kernel, whose per-VECTOR table is smaller (tight pitches only)
+                const size_t lds_flat = lds + (size_t)C;
+                ATX_REQUIRE(lds_flat <= 64 * 1024, ATX_ENOTIMPL, "pointwise: program needs %zu B of LDS", lds_flat);
+                if (program_has_transcendental(host_prog, n_stage, n_lev))
+                    hipLaunchKernelGGL((pointwise_cols_flat_kernel<T, VEC, true>), dim3((unsigned)blocks), dim3(kBlock), lds_flat, st, x, y, n_pts,
+                                       n_lev, C, prog, n_stage, mask, in_place);
+                else  // no exp / log anywhere in the program: the low-register instantiation (8 instead of 4 waves per SIMD in float64)
+                    hipLaunchKernelGGL((pointwise_cols_flat_kernel<T, VEC, false>), dim3((unsigned)blocks), dim3(kBlock), lds_flat, st, x, y, n_pts,
+                                       n_lev, C, prog, n_stage, mask, in_place);
+                ATX_LAUNCH_CHECK("pointwise_stack");
+                return ATX_OK;
+            }
         }
         const size_t lds_rows = level_tables_lds_bytes<T>(n_stage, C, wide ? VEC : 1);
         ATX_REQUIRE(lds_rows <= 64 * 1024, ATX_ENOTIMPL, "pointwise: program needs %zu B of LDS", lds_rows);
