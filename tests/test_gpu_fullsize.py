@@ -156,6 +156,43 @@ def test_pointwise_round_trip_and_mask_count(case, dev):
     assert torch.equal(y.data[keep].view(torch.int32), x.data[keep].view(torch.int32))
 
 
+def test_per_level_programs_agree_across_kernels_and_layouts(case, dev):
+    """137 levels of O1280, a scale / clip / mask of its own on every level, two stages: the per-level LDS kernel (column stacks), the
+    field-major rows kernel and the fused regrid epilogue (typed per-level table) evaluate the same statements — bit for bit the same
+    values wherever the same numbers go in."""
+    x, n = case["x"], case["n_src"]
+    stages = [[(native.OP_AFFINE, 0, 1.0 + 0.001 * l, -273.15 + 0.5 * l) for l in range(N_LEV)],
+              [(native.OP_CLIP, l % 2, -60.0 + 0.1 * l, 45.0) if l % 3 else (native.OP_MUL, 0, 1.0 + 1.0 / (1 + l), 0.0) for l in range(N_LEV)]]
+    prog = native.level_program(stages, dev)
+    pm = (torch.rand(n, device=dev) < 0.2).to(torch.uint8)
+    cols = x.new_like()
+    native.pointwise_stack(x.data, cols.data, n_pts=n, n_lev=N_LEV, x_pitch=x.pitch, y_pitch=cols.pitch, layout=COLUMNS, prog=prog, n_stage=2,
+                           point_mask=pm)
+    xf = x.to_layout(FIELDS)
+    yf = xf.new_like()
+    native.pointwise_stack(xf.data, yf.data, n_pts=n, n_lev=N_LEV, x_pitch=xf.pitch, y_pitch=yf.pitch, layout=FIELDS, prog=prog, n_stage=2,
+                           point_mask=pm)
+    back = yf.to_layout(COLUMNS)
+    assert torch.equal(back.data[:, :N_LEV].contiguous().view(torch.int32), cols.data[:, :N_LEV].contiguous().view(torch.int32))
+    # oracle spot check on three levels
+    for l in (0, 77, 136):
+        want = x.level_numpy(l)
+        for stage in stages:
+            op, use_mask, p0, p1 = stage[l]
+            p0, p1 = np.float32(p0), np.float32(p1)
+            want = oracle.rescale_forward(want, p0, p1) if op == native.OP_AFFINE else (want * p0 if op == native.OP_MUL else oracle.clip(want, p0, p1))
+            if use_mask:
+                want = oracle.apply_mask_values(want.copy(), pm.cpu().numpy().astype(bool))
+        assert np.array_equal(cols.level_numpy(l), want, equal_nan=True), l
+    # the fused epilogue of the regrid (multiply-add stage only: the direct kernel's typed table) against regrid-then-program
+    madd = native.level_program([stages[0]], dev)
+    fused = case["plan"].apply(x, prog=madd, n_stage=1)
+    plain = case["plan"].apply(x)
+    native.pointwise_stack(plain.data, plain.data, n_pts=case["n_tgt"], n_lev=N_LEV, x_pitch=plain.pitch, y_pitch=plain.pitch, layout=COLUMNS,
+                           prog=madd, n_stage=1)
+    assert torch.equal(fused.data[:, :N_LEV].contiguous().view(torch.int32), plain.data[:, :N_LEV].contiguous().view(torch.int32))
+
+
 def test_empty_and_tiny_inputs(dev):
     """Edge cases: zero targets, one target, one level, one source point."""
     x = Stack.from_fields(np.arange(12.0).reshape(3, 4), dev=dev)
