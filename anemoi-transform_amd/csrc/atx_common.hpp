@@ -78,6 +78,19 @@ __device__ __forceinline__ unsigned xcd_tile(unsigned b, unsigned n_tiles) {
     return start + r;
 }
 
+// The same deal in STRIPES: XCD x takes tiles x*G .. x*G+G-1 of every group of 8*G consecutive tiles.  Neighbouring tiles still meet
+// in one L2 (within a stripe), and rows whose cost varies slowly along the tile order — a conservative matrix whose boxes hold ~20
+// source points at the poles and ~200 at the equator — spread over all XCDs instead of loading the equatorial ones 2.5x (xcd_tile
+// gives every XCD one latitude band).  Bijective for any tile count (the tail beyond the last whole group maps to itself).
+__device__ __forceinline__ unsigned xcd_stripe(unsigned b, unsigned n_tiles, unsigned G) {
+    const unsigned group = kXcds * G;
+    const unsigned n_full = n_tiles / group * group;
+    if (b >= n_full) return b;
+    const unsigned x = b % kXcds;
+    const unsigned r = b / kXcds;
+    return (r / G) * group + x * G + (r % G);
+}
+
 template <typename T>
 __device__ __forceinline__ T quiet_nan();
 template <>

@@ -408,7 +408,7 @@ regrid_cols_csr_kernel(const T* __restrict__ src, T* __restrict__ out,
                        const T* __restrict__ data, int64_t n_tgt, int n_lev, int C,
                        int64_t src_pitch, int64_t out_pitch, int tile, unsigned n_tiles, int cap,
                        const atx_level_op* __restrict__ prog, int n_stage,
-                       const uint8_t* __restrict__ tgt_mask, const int32_t* __restrict__ tgt_rows) {
+                       const uint8_t* __restrict__ tgt_mask, const int32_t* __restrict__ tgt_rows, int stripe) {
     using V = Pack<T, VEC>;
     extern __shared__ __align__(16) unsigned char smem[];
     T* w_s = reinterpret_cast<T*>(smem);
@@ -416,7 +416,7 @@ regrid_cols_csr_kernel(const T* __restrict__ src, T* __restrict__ out,
     int32_t* rp_s = idx_s + cap;
     unsigned char* prog_s = smem + (((size_t)cap * (sizeof(T) + sizeof(int32_t)) + (size_t)(tile + 1) * sizeof(int32_t) + 15) & ~size_t(15));
 
-    const unsigned tile_id = xcd_tile(blockIdx.x, n_tiles);
+    const unsigned tile_id = stripe > 0 ? xcd_stripe(blockIdx.x, n_tiles, (unsigned)stripe) : xcd_tile(blockIdx.x, n_tiles);
     const int64_t t0 = (int64_t)tile_id * tile;
     const int nt = (int)min((int64_t)tile, n_tgt - t0);
     const int tid = threadIdx.x;
@@ -940,12 +940,20 @@ static int launch_cols_csr(const T* src, T* out, const int32_t* indptr, const in
     lds = (lds + 15) & ~size_t(15);
     if (prog) lds += level_tables_lds_bytes<T>(n_stage, C, VEC);
     ATX_REQUIRE(lds <= 64 * 1024, ATX_ENOTIMPL, "regrid_csr: tile needs %zu B of LDS", lds);
+    // long rows in natural order: stripes of tiles per XCD (atx_common.hpp: xcd_stripe) — their cost may drift along the rows
+#ifndef ATX_CSR_STRIPE
+#define ATX_CSR_STRIPE 16
+#endif
+#ifndef ATX_CSR_STRIPE_MIN_MEAN
+#define ATX_CSR_STRIPE_MIN_MEAN 8.0
+#endif
+    const int stripe = (!rows && mean >= ATX_CSR_STRIPE_MIN_MEAN) ? ATX_CSR_STRIPE : 0;
     if (prog) {
         hipLaunchKernelGGL((regrid_cols_csr_kernel<T, VEC, true>), dim3(n_tiles), dim3(kBlock), lds, st, src, out, indptr,
-                           indices, data, n_tgt, n_lev, C, sp, op, tile, n_tiles, cap, prog, n_stage, m, rows);
+                           indices, data, n_tgt, n_lev, C, sp, op, tile, n_tiles, cap, prog, n_stage, m, rows, stripe);
     } else {
         hipLaunchKernelGGL((regrid_cols_csr_kernel<T, VEC, false>), dim3(n_tiles), dim3(kBlock), lds, st, src, out, indptr,
-                           indices, data, n_tgt, n_lev, C, sp, op, tile, n_tiles, cap, prog, n_stage, m, rows);
+                           indices, data, n_tgt, n_lev, C, sp, op, tile, n_tiles, cap, prog, n_stage, m, rows, stripe);
     }
     ATX_LAUNCH_CHECK("regrid_cols_csr");
     return ATX_OK;
