@@ -84,6 +84,14 @@ class GatherPlan:
             self.weights = None if weights is None else np.ascontiguousarray(weights, dtype=np.float64).reshape(index.shape)
             if self.weights is None and self.k != 1:
                 raise ValueError("a gather without weights needs exactly one index per target point")
+            if self.weights is not None and self.k in (9, 10, 11, 13, 14, 15):
+                # widths between the direct kernel's compile-time forms: absent entries (index -1, skipped in the sum, so the bits are
+                # those of the k given) up to 12 or 16 — all k source vectors in flight instead of the tiled kernel's run-time loop
+                wide = 12 if self.k < 12 else 16
+                fill = np.full((self.n_tgt, wide - self.k), -1, dtype=np.int32)
+                self.index = np.ascontiguousarray(np.concatenate([self.index, fill], axis=1))
+                self.weights = np.ascontiguousarray(np.concatenate([self.weights, np.zeros(fill.shape)], axis=1))
+                self.k, self.padded = wide, True
 
     # ---- construction helpers ----------------------------------------------------------
     def _check(self, idx: np.ndarray) -> np.ndarray:

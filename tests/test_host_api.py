@@ -625,6 +625,27 @@ def test_shard_bounds_invariants_on_random_plans(monkeypatch):
         assert np.array_equal(np.concatenate(parts, axis=1), full, equal_nan=True), (case, kind, world)
 
 
+def test_widths_between_the_compile_time_forms_are_padded(monkeypatch):
+    """k = 9-11 / 13-15: GatherPlan pads the table to 12 / 16 with absent entries (index -1, skipped in the sum) so that the direct
+    kernel's compile-time form runs it — the values are those of the k given."""
+    import native_double
+    import torch
+    from anemoi_transform_amd.stack import Stack
+    from oracle import oracle
+
+    native_double.install(monkeypatch)
+    rng = np.random.default_rng(9)
+    n_src, n_tgt = 300, 120
+    x = Stack.from_fields(rng.standard_normal((4, n_src)), dev=torch.device("cpu"))
+    for k, wide in ((9, 12), (11, 12), (12, 12), (13, 16), (15, 16), (16, 16), (8, 8), (17, 17)):
+        idx, w = rng.integers(0, n_src, (n_tgt, k)), rng.random((n_tgt, k))
+        plan = GatherPlan(n_src, n_tgt, index=idx, weights=w)
+        assert plan.k == wide and plan.padded == (wide != k)
+        want = np.stack([oracle.csr_apply(w.reshape(-1), idx.reshape(-1), np.arange(n_tgt + 1) * k, (n_tgt, n_src), f) for f in x.numpy()])
+        assert np.array_equal(plan.apply(x).numpy(), want)
+        assert np.array_equal(np.concatenate([plan.shard(r, 3).apply(x).numpy() for r in range(3)], axis=1), want)
+
+
 def test_long_rows_on_field_major_stacks_go_through_columns(monkeypatch):
     """A field-major stack and rows of more than 8 entries: GatherPlan.apply converts to columns, gathers and converts back (4x faster
     than the field-major gather on MI355X) — same values, same layout as what came in; short rows stay on the field-major kernel."""
