@@ -185,7 +185,10 @@ static int relayout_typed(const void* src_, void* dst_, int64_t n_pts, int n_lev
 #define ATX_TP_BYTES 256  // re-measured with the vector kernel (137 levels of O1280, ms c->f / f->c): 128 B: 1.65 / 1.47 f32, 2.69 / 2.92 f64;
 #endif                    // 256 B: 1.59-1.66 / 1.32-1.44 f32, 2.52 / 2.66 f64; 384 B and 512 B slower (LDS tiles cut the occupancy)
     const int TP = ATX_TP_BYTES / (int)sizeof(T);  // contiguous bytes per level on the fields side
-    int LC = n_lev < 160 ? n_lev : 128;
+#ifndef ATX_TP_LC
+#define ATX_TP_LC 0  // levels per tile; 0: all of them up to 160, else 128
+#endif
+    int LC = ATX_TP_LC > 0 ? (n_lev < ATX_TP_LC ? n_lev : ATX_TP_LC) : (n_lev < 160 ? n_lev : 128);
     const int LCpad = LC | 1;
     const size_t lds = (size_t)TP * LCpad * sizeof(T);
     const unsigned gx = (unsigned)((n_pts + TP - 1) / TP);
