@@ -136,6 +136,31 @@ def test_regrid_csr_very_long_rows(dev, layout):
     assert np.array_equal(out.numpy(), want)
 
 
+@pytest.mark.parametrize("n_tgt", [1, 1023, 2031, 2032, 2048, 2049, 4097, 6001])
+def test_regrid_csr_striped_tiles_cover_every_row(dev, n_tgt):
+    """Rows of 8 entries or more (on average) have their tiles dealt to the XCDs in stripes (xcd_stripe): whatever the tile count —
+    below one group of stripes, exactly one, a tail beyond the last whole group — every row is computed once, with scipy's bits."""
+    rng = np.random.default_rng(n_tgt)
+    n_src, n_lev = 1500, 5  # 5 float64 levels: tiles of a few hundred targets at most, many tiles
+    x = make_fields(rng, n_lev, n_src, np.float64)
+    lengths = rng.integers(6, 30, size=n_tgt)
+    indptr = np.concatenate([[0], np.cumsum(lengths)]).astype(np.int32)
+    indices = rng.integers(0, n_src, size=int(indptr[-1])).astype(np.int32)
+    data = rng.random(int(indptr[-1]))
+    src = Stack.from_fields(x, dev=dev, layout=COLUMNS)
+    want = np.stack([oracle.csr_apply(data, indices, indptr, (n_tgt, n_src), f) for f in x])
+    for tile in (0, 8):  # the heuristic's tile and a forced small one (many tiles)
+        native.set_tuning(tile)
+        try:
+            out = src.new_like(n_pts=n_tgt)
+            out.data.fill_(float("nan"))
+            native.regrid_csr(src.data, out.data, to_dev(indptr, dev), to_dev(indices, dev), to_dev(data, dev), n_src=n_src,
+                              n_tgt=n_tgt, nnz=len(indices), n_lev=n_lev, src_pitch=src.pitch, out_pitch=out.pitch, layout=COLUMNS)
+        finally:
+            native.set_tuning(0)
+        assert np.array_equal(out.numpy(), want), tile
+
+
 def test_regrid_unaligned_columns_take_scalar_path(dev):
     """A columns stack whose pitch is not a 16-byte multiple still regrids correctly."""
     rng = np.random.default_rng(7)
