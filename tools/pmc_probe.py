@@ -36,7 +36,7 @@ def main():
     ap.add_argument("--k", type=int, default=4)
     ap.add_argument("--levels", type=int, default=137)
     ap.add_argument("--layout", default="columns", choices=["columns", "fields"])
-    ap.add_argument("--case", default="ell", choices=["ell", "csr34", "csr916", "box"],
+    ap.add_argument("--case", default="ell", choices=["ell", "csr34", "csr916", "box", "perlevel", "fieldspw"],
                     help="ell: fixed k (--k); csr34 / csr916: general CSR with ragged rows of 3-4 / 9-16 entries; box: O1280 -> 1 degree box averages (~100 per row)")
     ap.add_argument("--ordered", action="store_true", help="ell only: visit the targets in column blocks (atx_regrid_ell_ordered)")
     ap.add_argument("--chunk", type=int, default=0, help="ell only: one launch per chunk of this many levels (the level-chunk-major traversal, emulated)")
@@ -111,6 +111,19 @@ def main():
                 s_, o_ = (regrid_src.data[:, a:], regrid_out.data[:, a:]) if len(cuts) > 2 else (regrid_src.data, regrid_out.data)
                 native.regrid_ell(s_, o_, idx, w, n_src=n_src, n_tgt=n_tgt, k=args.k, n_lev=b - a,
                                   src_pitch=regrid_src.pitch, out_pitch=regrid_out.pitch, layout=regrid_src.layout, tgt_rows=rows)
+    elif args.case in ("perlevel", "fieldspw"):  # per-point kernels of round 3 (reported under the "regrid" keys of the summary)
+        L = args.levels
+        if args.case == "perlevel":  # a scale per level on a column stack: pointwise_cols_levels_kernel
+            kernel, x_in, layout = "pointwise_cols_levels_kernel", src, COLUMNS
+        else:  # the same program on a field-major stack: pointwise_fields_rows_kernel
+            kernel, x_in, layout = "pointwise_fields_rows_kernel", src.to_layout(FIELDS), FIELDS
+        y_out = x_in.new_like()
+        per = native.level_program([[(native.OP_AFFINE, 0, 1.0 + 0.001 * l, -273.15) for l in range(L)]], dev)
+        alg = 2 * n_src * L * itemsize
+        config = f"o1280 {args.case} L={L} {args.dtype} gpus=1"
+        for _ in range(args.launches):
+            native.pointwise_stack(x_in.data, y_out.data, n_pts=n_src, n_lev=L, x_pitch=x_in.pitch, y_pitch=y_out.pitch, layout=layout, prog=per,
+                                   n_stage=1)
     else:
         kernel = "regrid_cols_csr_kernel"
         if args.case == "box":  # every 1-degree cell averages the O1280 points inside it: each source column is read exactly once

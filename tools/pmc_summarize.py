@@ -31,7 +31,7 @@ def counters(directory: str, counter: str) -> dict[str, list[float]]:
                 name = row["Kernel_Name"]
                 for key in ("stream_copy_kernel", "pointwise_cols_kernel", "pointwise_cols_flat_kernel", "pointwise_cols_table_kernel", "pointwise_fields_kernel",
                             "pointwise_cols_uniform_kernel", "regrid_cols_ell_direct_kernel", "regrid_cols_ell_kernel", "regrid_fields_ell_kernel",
-                            "regrid_cols_csr_kernel"):
+                            "regrid_cols_csr_kernel", "pointwise_cols_levels_kernel", "pointwise_fields_rows_kernel"):
                     if key in name:
                         out.setdefault(key, []).append(float(row["Counter_Value"]))
     return out
