@@ -44,7 +44,9 @@
 extern "C" {
 #endif
 
-#define ATX_VERSION 200 /* 0.2.0 */
+#define ATX_VERSION 300 /* 0.3.0 — round 3: atx_reduce* take a workspace, atx_regrid_*_ordered, two more multi-input operators, and the
+                           * table written by atx_vector_program grew a typed per-level part (size it with the out == NULL query; a table
+                           * built by a 0.2 library is too short for 0.3 kernels) */
 
 /* ---- status codes --------------------------------------------------------- */
 enum {
