@@ -374,6 +374,47 @@ pointwise_cols_uniform_kernel(const T* __restrict__ x, T* __restrict__ y, int64_
     }
 }
 
+// ONE stage whose 16-byte vectors each hold one operator KIND (the parameters may differ from level to level: a scale per level): one
+// vector per lane, no loop, the parameters from the typed per-level part of the host-built table (level_tables_layout; two 16-byte
+// loads and one code word per lane, L1 / L2 resident) — the launch shape of the by-value kernel.  Measured against the per-level LDS
+// kernel, same box, interleaved (profiles/r03_per_level_programs.log): f64 +4 to +8 % (0.75-0.76 -> 0.78-0.80 on a fast box, 0.67-0.70 ->
+// 0.71-0.75 on a slow one), f32 in place 0.70-0.74 -> 0.74-0.78, f32 out of place 0.81 -> 0.77 and f32 with the point mask 0.73 -> 0.69
+// (those stay on the LDS kernel); two stages or vectors of mixed kinds lose 10-25 % here and stay there too.
+template <typename T, int VEC, bool TRANS, bool NT>
+__global__ void __launch_bounds__(kBlock)
+pointwise_cols_typed_kernel(const T* __restrict__ x, T* __restrict__ y, int64_t n_vec, int C, const unsigned char* __restrict__ level_tables,
+                            const uint8_t* __restrict__ point_mask, int in_place) {
+    using V = Pack<T, VEC>;
+    using OpWord = typename OpWordOf<VEC>::type;
+    const int64_t vi = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (vi >= n_vec) return;
+    int64_t row;
+    int c;
+    if (n_vec <= 0xffffffffll) {  // uniform: 32-bit division
+        const unsigned r = (unsigned)vi / (unsigned)C;
+        row = r;
+        c = (int)((unsigned)vi - r * (unsigned)C);
+    } else {
+        row = vi / C;
+        c = (int)(vi - row * C);
+    }
+    const int Lp = C * VEC;
+    const T* tp0 = reinterpret_cast<const T*>(level_tables);
+    const T* tp1 = tp0 + Lp;
+    const uint8_t* tcd = reinterpret_cast<const uint8_t*>(tp1 + Lp);
+    const unsigned code = *reinterpret_cast<const OpWord*>(tcd + c * VEC) & 0xffu;  // (the host checked: every level of the vector has this code)
+    if (in_place && code == 0) return;  // untouched levels of an in-place call: nothing to move
+    const V a = *reinterpret_cast<const V*>(tp0 + c * VEC);
+    const V b = *reinterpret_cast<const V*>(tp1 + c * VEC);
+    V v = NT ? pw_load_nt<T, VEC>(x + vi * VEC) : pw_load<T, VEC>(x + vi * VEC);
+    if (code != 0) {
+        const bool masked = ((code & 0x80u) && point_mask) ? (point_mask[row] != 0) : false;
+        apply_level_op_params<T, VEC, TRANS>((int)(code & 0x7fu), (code & 0x80u) != 0, a, b, v, masked);
+    }
+    if (NT) pw_store_nt<T, VEC>(y + vi * VEC, v);
+    else pw_store<T, VEC>(y + vi * VEC, v);
+}
+
 // In place with FEW active levels (1 of 137: one variable of a stack converted, a mask applied to one field): only the
 // vector columns that hold an active level are visited — one (point, active column) item per lane, the column list by value in
 // the kernel arguments.  The kernels above skip the loads of untouched columns too, but still walk all n_pts*C vector slots
@@ -1004,9 +1045,35 @@ static int pointwise_typed(const void* x_, void* y_, int64_t n_pts, int n_lev, i
                 ATX_LAUNCH_CHECK("pointwise_stack");
                 return ATX_OK;
             }
-            // (A no-loop kernel reading the typed per-level part of vec_prog — the shape of the by-value kernel — was measured against
-            // the per-level LDS kernel below and dropped: one stage f64 +3-4 %, f32 in place +7 %, but f32 out of place -5 %, vectors of
-            // mixed operator kinds -10 to -15 %, two stages -23 %; profiles/r03_per_level_programs.log.)
+            // (3) one stage, one operator kind per vector (a scale per level), float64 or in place: the no-loop kernel on the typed
+            // per-level part of vec_prog (pointwise_cols_typed_kernel; everything else measured faster on the per-level LDS kernel below)
+#ifndef ATX_PW_TYPED
+#define ATX_PW_TYPED 1
+#endif
+            if (ATX_PW_TYPED && tight && n_stage == 1 && (sizeof(T) == 8 || in_place) && vec_prog && aligned16(vec_prog) && host_prog &&
+                (n_vec + kBlock - 1) / kBlock <= 0x7fffffffll) {
+                bool one_kind = true, uses_mask = false;
+                for (int l0 = 0; l0 < n_lev && one_kind; l0 += VEC)
+                    for (int l = l0; l < n_lev && l < l0 + VEC; ++l) {
+                        one_kind = one_kind && host_prog[l].op == host_prog[l0].op && (host_prog[l].use_mask != 0) == (host_prog[l0].use_mask != 0);
+                        uses_mask = uses_mask || host_prog[l].use_mask != 0;
+                    }
+                if (one_kind && (sizeof(T) == 8 || !(uses_mask && mask))) {  // (float32 with the point mask: 0.69 here against 0.71-0.75)
+                    const unsigned char* level_tables = reinterpret_cast<const unsigned char*>(vec_prog) +
+                                                        level_tables_layout(1, n_lev, sizeof(T) == 4 ? ATX_F32 : ATX_F64).levels_offset;
+                    const bool trans = program_has_transcendental(host_prog, n_stage, n_lev);
+                    const bool nt = !(uses_mask && mask);
+                    const dim3 grid((unsigned)((n_vec + kBlock - 1) / kBlock));
+#define ATX_PW_TYPED_LAUNCH(TR_, NT_)                                                                                               \
+    hipLaunchKernelGGL((pointwise_cols_typed_kernel<T, VEC, TR_, NT_>), grid, dim3(kBlock), 0, st, x, y, n_vec, C, level_tables, \
+                       uses_mask ? mask : nullptr, in_place)
+                    if (trans) { if (nt) ATX_PW_TYPED_LAUNCH(true, true); else ATX_PW_TYPED_LAUNCH(true, false); }
+                    else { if (nt) ATX_PW_TYPED_LAUNCH(false, true); else ATX_PW_TYPED_LAUNCH(false, false); }
+#undef ATX_PW_TYPED_LAUNCH
+                    ATX_LAUNCH_CHECK("pointwise_stack_typed");
+                    return ATX_OK;
+                }
+            }
             const int64_t n_chunks = (n_vec + (int64_t)kBlock * kPwUnroll - 1) / ((int64_t)kBlock * kPwUnroll);
             int64_t blocks = n_chunks > kMaxGrid ? kMaxGrid : n_chunks;
             const int64_t per = (n_chunks + blocks - 1) / blocks;
