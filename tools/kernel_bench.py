@@ -151,7 +151,7 @@ def main():
                "operators by value")
         pl = native.level_program([[(native.OP_AFFINE, 0, 1.0 + 0.001 * l, -273.15) for l in range(L)]], dev)
         record(f"pointwise affine, a different operator per level {tag} out-of-place", timeit(lambda: native.pointwise_stack(x.data, y.data, prog=pl, n_stage=1, **kw)), 2 * stack_bytes,
-               "operators of every level staged in LDS (pointwise_cols_levels_kernel)")
+               "per-level tables: LDS kernel (f32 out of place), typed no-loop kernel (f64)")
         pe = native.level_program([[(native.OP_LOG, 0, 0.0, 0.0)] * L, [(native.OP_EXP, 0, 0.0, 0.0)] * L], dev)
         record(f"pointwise log then exp (sp_to_lnsp | lnsp_to_sp) {tag} out-of-place", timeit(lambda: native.pointwise_stack(x.data, y.data, prog=pe, n_stage=2, **kw)), 2 * stack_bytes,
                "device-library log and exp on every element")
