@@ -32,8 +32,12 @@ def main():
         back = c.new_like()
         ms_fc = launches(lambda: native.relayout(f.data, back.data, src_pitch=f.pitch, dst_pitch=back.pitch, src_layout=FIELDS, dst_layout=COLUMNS, **kw))
         assert torch.equal(back.data[:, :L], c.data[:, :L])
-        out.append(f"{tag} c->f {ms_cf:.3f} ms {2 * n * L * B / (ms_cf * 1e-3) / 8e12:.3f} | f->c {ms_fc:.3f} ms {2 * n * L * B / (ms_fc * 1e-3) / 8e12:.3f}")
-        del c, f, back
+        half = Stack.empty(n, 68, tdt, dev, COLUMNS)
+        ms_sel = launches(lambda: native.select_levels(c.data, half.data, list(range(0, L - 1, 2)), n_pts=n, n_src_lev=L, src_pitch=c.pitch,
+                                                       dst_pitch=half.pitch, layout=COLUMNS))
+        assert torch.equal(half.data[:, :68], c.data[:, 0:136:2])
+        out.append(f"{tag} c->f {ms_cf:.3f} ms {2 * n * L * B / (ms_cf * 1e-3) / 8e12:.3f} | f->c {ms_fc:.3f} ms {2 * n * L * B / (ms_fc * 1e-3) / 8e12:.3f} | select 68 of 137 {ms_sel:.3f} ms {2 * n * 68 * B / (ms_sel * 1e-3) / 8e12:.3f}")
+        del c, f, back, half
         torch.cuda.empty_cache()
     print(os.path.basename(native.lib_path()), " || ".join(out), flush=True)
 
