@@ -36,7 +36,7 @@ def main():
     ap.add_argument("--k", type=int, default=4)
     ap.add_argument("--levels", type=int, default=137)
     ap.add_argument("--layout", default="columns", choices=["columns", "fields"])
-    ap.add_argument("--case", default="ell", choices=["ell", "csr34", "csr916", "box", "perlevel", "fieldspw"],
+    ap.add_argument("--case", default="ell", choices=["ell", "csr34", "csr916", "box", "perlevel", "fieldspw", "pad916"],
                     help="ell: fixed k (--k); csr34 / csr916: general CSR with ragged rows of 3-4 / 9-16 entries; box: O1280 -> 1 degree box averages (~100 per row)")
     ap.add_argument("--ordered", action="store_true", help="ell only: visit the targets in column blocks (atx_regrid_ell_ordered)")
     ap.add_argument("--chunk", type=int, default=0, help="ell only: one launch per chunk of this many levels (the level-chunk-major traversal, emulated)")
@@ -111,6 +111,22 @@ def main():
                 s_, o_ = (regrid_src.data[:, a:], regrid_out.data[:, a:]) if len(cuts) > 2 else (regrid_src.data, regrid_out.data)
                 native.regrid_ell(s_, o_, idx, w, n_src=n_src, n_tgt=n_tgt, k=args.k, n_lev=b - a,
                                   src_pitch=regrid_src.pitch, out_pitch=regrid_out.pitch, layout=regrid_src.layout, tgt_rows=rows)
+    elif args.case == "pad916":  # ragged rows of 9-16 entries the way regrid(matrix=...) runs them: padded to 16, targets in column blocks
+        from anemoi_transform_amd.gather import GatherPlan, target_order_for
+
+        i64, w64k = knn_inverse_distance(src_grid, tgt_grid, k=16, device=True, ties="index")
+        keep = np.random.default_rng(16).random(i64.shape) < 0.75
+        keep[:, :9] = True
+        indptr = np.concatenate([[0], np.cumsum(keep.sum(axis=1))])
+        plan = GatherPlan.from_matrix(dict(matrix_data=w64k[keep], matrix_indices=i64[keep], matrix_indptr=indptr, matrix_shape=(n_tgt, n_src)))
+        assert plan.padded and plan.k == 16
+        if args.ordered:
+            plan.order_targets(target_order_for(tgt_grid["latitudes"], tgt_grid["longitudes"], 16))
+        kernel = "regrid_cols_ell_direct_kernel"
+        alg = args.levels * itemsize * (int(np.unique(i64[keep]).size) + n_tgt) + int(keep.sum()) * (4 + itemsize) + 4 * n_tgt
+        config = f"o1280 rows of 9-16 padded to 16 L={args.levels} {args.dtype} columns gpus=1" + (" column-block order" if args.ordered else "")
+        for _ in range(args.launches):
+            plan.apply(src)
     elif args.case in ("perlevel", "fieldspw"):  # per-point kernels of round 3 (reported under the "regrid" keys of the summary)
         L = args.levels
         if args.case == "perlevel":  # a scale per level on a column stack: pointwise_cols_levels_kernel
