@@ -48,6 +48,10 @@ def summarize(directory: str) -> None:
             line.append(f"UTCL1 translation misses per request {v['TCP_UTCL1_TRANSLATION_MISS'] / v['TCP_UTCL1_REQUEST']:.4f}")
         if "TCP_TCC_READ_REQ_LATENCY" in v and "TCP_TCC_READ_REQ" in per_case[c]:
             line.append(f"mean L1->L2 read latency {v['TCP_TCC_READ_REQ_LATENCY'] / per_case[c]['TCP_TCC_READ_REQ']:.0f} cycles")
+        if "TCC_HIT" in v and "TCC_MISS" in v:
+            line.append(f"L2 hit rate {v['TCC_HIT'] / (v['TCC_HIT'] + v['TCC_MISS']):.3f}")
+        if "TA_TA_BUSY" in v and "GRBM_GUI_ACTIVE" in v:
+            line.append(f"TA busy / GPU active cycles {v['TA_TA_BUSY'] / v['GRBM_GUI_ACTIVE']:.1f} (summed over the sampled TAs), TA address stalled by TC {v['TA_ADDR_STALLED_BY_TC_CYCLES'] / v['TA_TA_BUSY']:.3f} of its busy cycles")
         if "SQ_WAVE_CYCLES" in v:
             line.append(f"waves parked on memory {v['SQ_WAIT_ANY'] / v['SQ_WAVE_CYCLES']:.3f}, issuing {v['SQ_ACTIVE_INST_ANY'] / v['SQ_WAVE_CYCLES']:.3f}")
         print("  ".join(line))
