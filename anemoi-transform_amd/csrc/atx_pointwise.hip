@@ -679,10 +679,34 @@ compact_scan_kernel(int32_t* __restrict__ block_counts, int n_blocks, long long*
     if (tid == 1023) *total = part[1023];
 }
 
+// SELF_SCAN (few thousand workgroups at most): `block_offsets` holds the raw per-workgroup COUNTS and every workgroup sums the counts before
+// its own by itself (a few KB out of L2) — the single-workgroup scan launch between count and scatter goes away (three launches -> two);
+// the last workgroup writes the total.
+template <bool SELF_SCAN>
 __global__ void __launch_bounds__(kBlock)
 compact_scatter_kernel(const uint8_t* __restrict__ mask, int64_t n, const int32_t* __restrict__ block_offsets,
-                       int32_t* __restrict__ index) {
+                       int32_t* __restrict__ index, long long* __restrict__ total) {
     __shared__ int wsum[kBlock / kWave];
+    __shared__ long long before_s;
+    long long before = 0;
+    if (SELF_SCAN) {
+        __shared__ unsigned long long psum[kBlock / kWave];
+        unsigned long long mine = 0;
+        for (int b = threadIdx.x; b < (int)blockIdx.x; b += kBlock) mine += (unsigned long long)block_offsets[b];
+        mine = wave_sum(mine);
+        if ((threadIdx.x & (kWave - 1)) == 0) psum[threadIdx.x / kWave] = mine;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            unsigned long long t = 0;
+            for (int i = 0; i < kBlock / kWave; ++i) t += psum[i];
+            before_s = (long long)t;
+            if (blockIdx.x == gridDim.x - 1) *total = (long long)t + block_offsets[blockIdx.x];
+        }
+        __syncthreads();
+        before = before_s;
+    } else {
+        before = block_offsets[blockIdx.x];
+    }
     uint32_t bits;
     const int64_t base = (int64_t)blockIdx.x * kChunk + (int64_t)threadIdx.x * kPerLane;
     const int cnt = lane_count(mask, base, n, bits);
@@ -698,7 +722,7 @@ compact_scatter_kernel(const uint8_t* __restrict__ mask, int64_t n, const int32_
     __syncthreads();
     int wave_base = 0;
     for (int i = 0; i < (int)(threadIdx.x / kWave); ++i) wave_base += wsum[i];
-    int64_t o = (int64_t)block_offsets[blockIdx.x] + wave_base + (incl - cnt);
+    int64_t o = (int64_t)before + wave_base + (incl - cnt);
     while (bits) {
         const int e = __ffs(bits) - 1;
         bits &= bits - 1;
@@ -1245,9 +1269,17 @@ extern "C" int atx_mask_to_index(const uint8_t* mask, int64_t n, int32_t* index,
     int32_t* block_counts = static_cast<int32_t*>(workspace);
     hipLaunchKernelGGL(compact_count_kernel, dim3(n_blocks), dim3(kBlock), 0, s, mask, n, block_counts);
     ATX_LAUNCH_CHECK("compact_count");
+#ifndef ATX_COMPACT_SELF_SCAN
+#define ATX_COMPACT_SELF_SCAN 4096  // workgroups up to which the scatter sums the counts before it by itself (16 M points); 0: never
+#endif
+    if (n_blocks <= ATX_COMPACT_SELF_SCAN) {
+        hipLaunchKernelGGL(compact_scatter_kernel<true>, dim3(n_blocks), dim3(kBlock), 0, s, mask, n, block_counts, index, reinterpret_cast<long long*>(count));
+        ATX_LAUNCH_CHECK("compact_scatter");
+        return ATX_OK;
+    }
     hipLaunchKernelGGL(compact_scan_kernel, dim3(1), dim3(1024), 0, s, block_counts, n_blocks, reinterpret_cast<long long*>(count));
     ATX_LAUNCH_CHECK("compact_scan");
-    hipLaunchKernelGGL(compact_scatter_kernel, dim3(n_blocks), dim3(kBlock), 0, s, mask, n, block_counts, index);
+    hipLaunchKernelGGL(compact_scatter_kernel<false>, dim3(n_blocks), dim3(kBlock), 0, s, mask, n, block_counts, index, nullptr);
     ATX_LAUNCH_CHECK("compact_scatter");
     return ATX_OK;
 }

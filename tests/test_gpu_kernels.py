@@ -654,7 +654,7 @@ def test_mask_build_from_stack_level(dev):
     assert native.mask_count(mask, 999) == int(oracle.not_nan_mask(x[2]).sum())
 
 
-@pytest.mark.parametrize("n", [0, 1, 15, 4096, 4097, 1_000_003])
+@pytest.mark.parametrize("n", [0, 1, 15, 4096, 4097, 1_000_003, 16_777_216, 16_777_217 + 4096])  # the last two: around the 4096-workgroup limit of the self-scanning scatter
 @pytest.mark.parametrize("density", [0.0, 0.37, 1.0])
 def test_mask_to_index_is_stable_compaction(dev, n, density):
     """R: remove_nans.py:113 / regrid.py:420 — boolean indexing == gather by ascending index list."""
