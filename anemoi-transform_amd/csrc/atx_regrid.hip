@@ -304,7 +304,11 @@ regrid_cols_ell_direct_kernel(EllBatch batch, const int32_t* __restrict__ idx, c
     using V = Pack<T, VEC>;
     const T* __restrict__ src = static_cast<const T*>(batch.src[blockIdx.y]);
     T* __restrict__ out = static_cast<T*>(batch.out[blockIdx.y]);
-    const unsigned b = xcd_tile(blockIdx.x, n_blocks);
+#ifndef ATX_DIRECT_STRIPE
+#define ATX_DIRECT_STRIPE 0  // 0: one contiguous range of workgroups per XCD; > 0: stripes of that many (A/B knob); < 0: plain round-robin
+#endif
+    const unsigned b = ATX_DIRECT_STRIPE > 0 ? xcd_stripe(blockIdx.x, n_blocks, (unsigned)ATX_DIRECT_STRIPE)
+                                             : (ATX_DIRECT_STRIPE < 0 ? blockIdx.x : xcd_tile(blockIdx.x, n_blocks));
     for (int it = 0; it < items_per_lane; ++it) {
         const int64_t q = ((int64_t)b * items_per_lane + it) * kEllBlock + threadIdx.x;
         if (q >= n_items) return;
