@@ -145,10 +145,11 @@ def test_integration_md_ctypes_stub_runs(tmp_path):
 
     text = open(os.path.join(ROOT, "INTEGRATION.md")).read()
     blocks = re.findall(r"```python\n(.*?)```", text, flags=re.S)
-    stub = next(b for b in blocks if "class MIRMatrixHBM" in b)
+    stub = next(b for b in blocks if "class MIRMatrixHBM:" in b)
     stub = stub.replace('ctypes.CDLL("libatx.so")', f'ctypes.CDLL({native.lib_path()!r})')
     scope: dict = {}
     exec(compile(stub, "INTEGRATION.md", "exec"), scope)
+    exec(compile(next(b for b in blocks if "class MIRMatrixHBMColumns" in b), "INTEGRATION.md", "exec"), scope)  # the column-stack variant
 
     src, tgt = lookup("o32"), lookup([5.0, 5.0])
     idx, w = interp.knn_inverse_distance(src, tgt, k=4)
@@ -170,3 +171,4 @@ def test_integration_md_ctypes_stub_runs(tmp_path):
     m = csr_array((matrix["matrix_data"], matrix["matrix_indices"], matrix["matrix_indptr"]), shape=tuple(matrix["matrix_shape"]))
     for f, got in zip(fields, out.cpu().numpy()):
         assert np.array_equal(got, m @ f.values)
+    assert torch.equal(scope["MIRMatrixHBMColumns"](path)(fields), out)
