@@ -24,6 +24,11 @@ CASES = ["k=4 natural", "k=16 natural", "k=16 column blocks"]
 
 def summarize(directory: str) -> None:
     per_case: dict[str, dict[str, float]] = {c: {} for c in CASES}
+    n_xcd, n_cu = 8, 256
+    for path in glob.glob(os.path.join(directory, "**", "*_agent_info.csv"), recursive=True):
+        for a in csv.DictReader(open(path, newline="")):
+            if a.get("Agent_Type") == "GPU":
+                n_xcd, n_cu = int(a["Num_Xcc"]), int(a["Cu_Count"])
     for path in glob.glob(os.path.join(directory, "**", "*_counter_collection.csv"), recursive=True):
         rows = [r for r in csv.DictReader(open(path, newline="")) if "regrid_cols_ell_direct_kernel" in r["Kernel_Name"]]
         by_dispatch: dict[int, dict[str, float]] = {}
@@ -35,6 +40,8 @@ def summarize(directory: str) -> None:
             group = order[i * reps:(i + 1) * reps]
             for key in group[0]:
                 per_case[case][key] = sum(g[key] for g in group) / len(group)
+                if "GRBM_GUI_ACTIVE" in group[0] and key != "GRBM_GUI_ACTIVE":  # normalised by the GPU-active cycles of ITS OWN pass (run-to-run drift)
+                    per_case[case][key + " / active"] = sum(g[key] / (g["GRBM_GUI_ACTIVE"] / n_xcd) for g in group) / len(group)
     keys = sorted({k for c in per_case.values() for k in c})
     print(f"{'counter':34s}" + "".join(f"{c:>22s}" for c in CASES))
     for k in keys:
@@ -51,7 +58,21 @@ def summarize(directory: str) -> None:
         if "TCC_HIT" in v and "TCC_MISS" in v:
             line.append(f"L2 hit rate {v['TCC_HIT'] / (v['TCC_HIT'] + v['TCC_MISS']):.3f}")
         if "TA_TA_BUSY" in v and "GRBM_GUI_ACTIVE" in v:
-            line.append(f"TA busy / GPU active cycles {v['TA_TA_BUSY'] / v['GRBM_GUI_ACTIVE']:.1f} (summed over the sampled TAs), TA address stalled by TC {v['TA_ADDR_STALLED_BY_TC_CYCLES'] / v['TA_TA_BUSY']:.3f} of its busy cycles")
+            # raw counters arrive summed over their instances: GRBM_GUI_ACTIVE over the XCDs, TA_* / TD_* over the TAs / TDs (one per active CU)
+            active = v["GRBM_GUI_ACTIVE"] / n_xcd
+            busy = v.get("TA_TA_BUSY / active", v["TA_TA_BUSY"] / active) / n_cu
+            line.append(f"GPU-active cycles per XCD {active:.4g}; TA busy / GPU active, mean over the {n_cu} TAs {busy:.3f}")
+            if "TA_BUSY_max / active" in v:
+                line.append(f"busiest TA {v['TA_BUSY_max / active']:.3f}, idlest {v.get('TA_BUSY_min / active', float('nan')):.3f}")
+            if "TA_ADDR_STALLED_BY_TC_CYCLES / active" in v:
+                line.append(f"TA address stalled by TC {v['TA_ADDR_STALLED_BY_TC_CYCLES / active'] / n_cu:.3f} of GPU-active cycles, "
+                            f"data stalled by TC {v['TA_DATA_STALLED_BY_TC_CYCLES / active'] / n_cu:.3f}")
+            if "TA_ADDR_STALLED_BY_TD_CYCLES / active" in v:
+                line.append(f"address stalled by TD {v['TA_ADDR_STALLED_BY_TD_CYCLES / active'] / n_cu:.3f}")
+            if "TA_FLAT_READ_WAVEFRONTS / active" in v:
+                line.append(f"GPU-active cycles per read wavefront-instruction and TA {n_cu / v['TA_FLAT_READ_WAVEFRONTS / active']:.1f}")
+            if "TD_TD_BUSY / active" in v:
+                line.append(f"TD busy / GPU active {v['TD_TD_BUSY / active'] / n_cu:.3f}, TD stalled by TC {v['TD_TC_STALL / active'] / n_cu:.3f} of GPU-active cycles")
         if "SQ_WAVE_CYCLES" in v:
             line.append(f"waves parked on memory {v['SQ_WAIT_ANY'] / v['SQ_WAVE_CYCLES']:.3f}, issuing {v['SQ_ACTIVE_INST_ANY'] / v['SQ_WAVE_CYCLES']:.3f}")
         print("  ".join(line))

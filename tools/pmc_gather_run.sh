@@ -8,8 +8,9 @@ for SET in "TCP_TOTAL_CACHE_ACCESSES TCP_TCC_READ_REQ TCP_PENDING_STALL_CYCLES T
            "TCP_UTCL1_REQUEST TCP_UTCL1_TRANSLATION_HIT TCP_UTCL1_TRANSLATION_MISS" \
            "TCP_TCC_READ_REQ_LATENCY TCP_TCP_LATENCY TCP_TCR_TCP_STALL_CYCLES" \
            "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAVES SQ_BUSY_CYCLES"; do
-  # (a fifth pass with TA_TA_BUSY TA_ADDR_STALLED_BY_TC_CYCLES TA_DATA_STALLED_BY_TC_CYCLES TA_FLAT_READ_WAVEFRONTS GRBM_GUI_ACTIVE never
-  #  returned on this pool — rocprofv3 sat silent for 7 minutes and was killed: do not add those counters back)
+  # (round 3 tried a fifth pass with FOUR TA_* counters + GRBM_GUI_ACTIVE: rocprofiler_create_counter_config error 38, "Request exceeds the capabilities of
+  #  the hardware to collect" — the TA block has two slots per pass — SIGABRT, and rocprofv3's signal handler never returned.  An oversubscribed pass, not the
+  #  pool: tools/pmc_ta_run.sh collects them two at a time, profiles/r04_pmc_gather_counters.txt)
   i=$((i+1))
   rocprofv3 --pmc $SET --kernel-trace --output-format csv -d $R/gpurun_out/pmc_gather/$i -- python3 $R/tools/pmc_gather_probe.py > $R/gpurun_out/pmc_gather_$i.log 2>&1 || { tail -5 $R/gpurun_out/pmc_gather_$i.log; exit 1; }
   echo "pass $i done"
