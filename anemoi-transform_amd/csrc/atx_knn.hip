@@ -226,17 +226,19 @@ static unsigned blocks_for(int64_t n) {
 using namespace atx;
 
 // ---- cutout mask: ray / triangle tests for every global point -------------------------------
-// np.cross / np.dot of 3-vectors, in the reference's operation order (no contraction).
+// np.cross / np.dot of 3-vectors as the reference's per-point loop evaluates them (R: spatial.py:211-231).  np.cross is numpy
+// ufuncs: products and differences, each rounded (no contraction).  np.dot of two 1-D arrays is cblas_ddot, and the x86-64
+// OpenBLAS kernels numpy ships run a 3-element dot through their scalar tail loop `dot += y[i] * x[i]`, compiled with FMA:
+// fma(a2, b2, fma(a1, b1, a0 * b0)).  Round 4's reference-run vectors (tests/golden/spatial_vectors.npz) caught the difference:
+// two O96 points lying exactly on a triangle edge of a regular limited-area grid were classified differently by the
+// two-roundings-per-term form this kernel (and the host builder) used before.
 __device__ __forceinline__ void cross3(const double a[3], const double b[3], double c[3]) {
     c[0] = a[1] * b[2] - a[2] * b[1];
     c[1] = a[2] * b[0] - a[0] * b[2];
     c[2] = a[0] * b[1] - a[1] * b[0];
 }
 __device__ __forceinline__ double dot3(const double a[3], const double b[3]) {
-    double s = a[0] * b[0];
-    s = s + a[1] * b[1];
-    s = s + a[2] * b[2];
-    return s;
+    return __builtin_fma(a[2], b[2], __builtin_fma(a[1], b[1], a[0] * b[0]));
 }
 
 __global__ void __launch_bounds__(kBlock)

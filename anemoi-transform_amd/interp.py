@@ -12,6 +12,7 @@ generates k-NN inverse-distance and bilinear matrices in the same npz format.
 
 from __future__ import annotations
 
+import logging
 from collections import OrderedDict
 from typing import Any
 
@@ -34,6 +35,7 @@ __all__ = [
 ]
 
 
+LOG = logging.getLogger(__name__)
 _knn_engine: str | None = None
 
 
@@ -77,6 +79,18 @@ _TREES: "OrderedDict[str, Any]" = OrderedDict()
 _TREES_MAX = 2
 _DISK_MIN_ENTRIES = 100_000  # smaller tables are rebuilt faster than a file is found
 _cache_stats = {"memory_hits": 0, "disk_hits": 0, "misses": 0, "trees_built": 0}
+KNN_TABLE_FORMAT = 2  # bump when the file layout OR the device search's tie / ordering logic changes: older files are then ignored
+_cache_dir_announced = False
+
+
+def _library_version() -> int:
+    """``ATX_VERSION`` of the loaded libatx.so, 0 when the library has not been loaded (host-only use)."""
+    try:
+        from . import native
+
+        return int(native._lib.atx_version()) if native._lib is not None else 0
+    except Exception:  # noqa: BLE001 - the version is a label in the file, never a reason to fail a table build
+        return 0
 
 
 def points_hash(*arrays: np.ndarray) -> str:
@@ -143,14 +157,19 @@ def host_tree(src_xyz: np.ndarray, key: str | None = None):
     return tree
 
 
-def _remembered_table(src_lat, src_lon, tgt_lat, tgt_lon, k: int, max_distance, order: str, compute):
+def _remembered_table(src_lat, src_lon, tgt_lat, tgt_lon, k: int, max_distance, order: str, compute, producer: str = "host"):
     """``(indices [n, k] int64, distances [n, k] float64)`` from the process memo, the disk cache or ``compute(src_hash)``;
-    the arrays handed back are the caller's own copies."""
+    the arrays handed back are the caller's own copies.
+
+    Entries are kept per PRODUCER (``"host"``: cKDTree itself; ``"device"``: ``atx_knn_*`` with cKDTree settling the ties) and per
+    ``KNN_TABLE_FORMAT``: a table the device search built is never served to the host path (or the other way round), and a
+    change to the kernel's tie handling or to the file layout is a bump of that constant, which orphans the old files instead
+    of trusting them.  Files also record producer, format and library version and are re-checked on load."""
     import os
 
     src_h, tgt_h = points_hash(src_lat, src_lon), points_hash(tgt_lat, tgt_lon)
     bound = "none" if max_distance is None else repr(float(max_distance))
-    key = (src_h, tgt_h, int(k), bound, order)
+    key = (src_h, tgt_h, int(k), bound, order, producer, KNN_TABLE_FORMAT)
     hit = _TABLES.get(key)
     if hit is not None:
         _TABLES.move_to_end(key)
@@ -161,12 +180,13 @@ def _remembered_table(src_lat, src_lon, tgt_lat, tgt_lon, k: int, max_distance, 
     path = None
     table = None
     if directory:
-        tag = "" if order == "ckdtree" else f"-{order}"
-        path = os.path.join(directory, f"knn-{src_h}-{tgt_h}-k{k}-d{bound}{tag}.npz")
+        path = os.path.join(directory, f"knn-v{KNN_TABLE_FORMAT}-{producer}-{order}-{src_h}-{tgt_h}-k{k}-d{bound}.npz")
         if os.path.exists(path):
             try:
                 with np.load(path) as f:
-                    if tuple(f["matrix_shape"]) == (n_tgt, n_src) and f["matrix_indices"].size == n_tgt * k:
+                    if (tuple(f["matrix_shape"]) == (n_tgt, n_src) and f["matrix_indices"].size == n_tgt * k
+                            and int(f["format"]) == KNN_TABLE_FORMAT and str(f["producer"]) == producer and str(f["tie_order"]) == order
+                            and str(f["in_grid_hash"]) == src_h and str(f["out_grid_hash"]) == tgt_h):
                         table = (f["matrix_indices"].astype(np.int64).reshape(n_tgt, k), f["matrix_data"].reshape(n_tgt, k))
                         _cache_stats["disk_hits"] += 1
             except Exception:  # a damaged file is a miss (and is rewritten below)
@@ -182,8 +202,13 @@ def _remembered_table(src_lat, src_lon, tgt_lat, tgt_lon, k: int, max_distance, 
                 np.savez(tmp, matrix_data=table[1].reshape(-1), matrix_indices=table[0].astype(np.int32).reshape(-1),
                          matrix_indptr=np.arange(n_tgt + 1, dtype=np.int64) * k, matrix_shape=np.array([n_tgt, n_src]),
                          kind=np.array("k-NN table: matrix_data holds chord distances on the unit sphere, not weights"),
-                         in_grid_hash=np.array(src_h), out_grid_hash=np.array(tgt_h))
+                         in_grid_hash=np.array(src_h), out_grid_hash=np.array(tgt_h), format=np.array(KNN_TABLE_FORMAT),
+                         producer=np.array(producer), tie_order=np.array(order), library_version=np.array(_library_version()))
                 os.replace(tmp, path)
+                global _cache_dir_announced
+                if not _cache_dir_announced:
+                    _cache_dir_announced = True
+                    LOG.info("k-NN tables are remembered under %s (ATX_CACHE_DIR=off disables the files)", directory)
             except OSError:  # a read-only or full cache directory must not fail the filter
                 pass
     _TABLES[key] = table
@@ -278,7 +303,7 @@ def nearest_grid_points_device(
         return indices, distances
 
     indices, distances = _remembered_table(source_latitudes, source_longitudes, target_latitudes, target_longitudes, k, max_distance,
-                                           ties, compute)
+                                           ties, compute, producer="device")
     if k == 1:
         indices, distances = indices[:, 0], distances[:, 0]
     if return_distances:

@@ -62,23 +62,32 @@ def _distance_km_to_resolution(distance_km: Any, lam_points, global_points) -> f
     return _resolution({"lam": lam_points, "global": global_points, None: global_points}[distance_km])
 
 
+def _row_dots(a: np.ndarray, b: np.ndarray) -> np.ndarray:
+    """``np.dot(a[i], b[i])`` for every row, with np.dot's OWN bits: a batched ``matmul`` of ``[1, 3] @ [3, 1]`` goes through the
+    same ``cblas_ddot`` as the reference's per-point ``np.dot`` (R: spatial.py:213,218,222,225) — on x86-64 OpenBLAS that is a
+    chain of fused multiply-adds, which ``einsum`` / ``(a * b).sum(1)`` do not reproduce.  A point lying exactly on a triangle
+    edge (regular LAM grid, global point on one of its meridians) is decided by that last bit."""
+    return np.matmul(a[:, None, :], b[:, :, None])[:, 0, 0]
+
+
 def rays_hit_triangles(directions: np.ndarray, v0: np.ndarray, v1: np.ndarray, v2: np.ndarray) -> np.ndarray:
     """Möller–Trumbore for rays from the origin: ``directions [N, 3]`` against triangles ``[N, 3]`` each
-    (R: spatial.py:186-233, evaluated for all N at once)."""
+    (R: spatial.py:186-233, evaluated for all N at once with the per-point arithmetic of np.cross / np.dot)."""
     epsilon = 0.0000001
+    directions = np.ascontiguousarray(directions, dtype=np.float64)
     e1, e2 = v1 - v0, v2 - v0
     h = np.cross(directions, e2)
-    a = np.einsum("ij,ij->i", e1, h)
+    a = _row_dots(e1, h)
     ok = ~((-epsilon < a) & (a < epsilon))
     with np.errstate(divide="ignore", invalid="ignore"):
         f = 1.0 / a
-        s = -v0
-        u = f * np.einsum("ij,ij->i", s, h)
+        s = 0.0 - v0
+        u = f * _row_dots(s, h)
         ok &= ~((u < 0.0) | (u > 1.0))
         q = np.cross(s, e1)
-        v = f * np.einsum("ij,ij->i", directions, q)
+        v = f * _row_dots(directions, q)
         ok &= ~((v < 0.0) | (u + v > 1.0))
-        t = f * np.einsum("ij,ij->i", e2, q)
+        t = f * _row_dots(e2, q)
     return ok & (t > epsilon)
 
 

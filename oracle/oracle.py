@@ -429,6 +429,11 @@ def _distance_km_to_resolution(distance_km, lam_points, global_points) -> float:
 def cutout_mask(lats, lons, global_lats, global_lons, cropping_distance=2.0, neighbours=5, min_distance_km=None,
                 max_distance_km=None):
     """R: spatial.py:294-440."""
+    # R: spatial.py:334-337 (a str distance such as "lam" fails the comparison itself: TypeError)
+    assert cropping_distance >= 0.0, "cropping_distance must be non-negative"
+    assert min_distance_km is None or min_distance_km >= 0.0, "min_distance_km must be non-negative"
+    assert max_distance_km is None or max_distance_km >= 0.0, "max_distance_km must be non-negative"
+    assert neighbours > 0, "neighbours must be positive"
     from scipy.spatial import cKDTree
 
     assert global_lats.ndim == 1 and global_lons.ndim == 1 and lats.ndim == 1 and lons.ndim == 1

@@ -110,13 +110,16 @@ def test_config4_batched_stacks_target_sharded_8_ways(dev):
         assert torch.equal(rebase_plan(shards[r], lo, hi).apply(slab).data, shards[r].apply(x).data)
 
 
-def test_config5_chained_filters_on_o2560(dev):
+@pytest.mark.parametrize("tdtype,np_dtype", [(torch.float32, np.float32), (torch.float64, np.float64)], ids=["f32", "f64"])
+def test_config5_chained_filters_on_o2560(dev, tdtype, np_dtype):
+    """BASELINE configs[4]: regrid + orog_to_z + unit convert on an ERA5-shape O2560 stack, fused into one launch — in float32
+    (14.4 GB) and in float64, the reference's own width (28.8 GB resident)."""
     src, tgt = lookup("o2560"), lookup("0.25")
     n_src, n_tgt, n_lev = len(src["latitudes"]), len(tgt["latitudes"]), 137
     assert n_src == 26306560
     idx, w = interp.knn_inverse_distance(src, tgt, k=4, device=True)  # the table cKDTree would build (tools/knn_table_parity.py shows it row by row); cKDTree alone needs ~1 min here
     plan = GatherPlan(n_src, n_tgt, index=idx, weights=w)
-    x = synth(src, n_lev, dev, 5)
+    x = synth(src, n_lev, dev, 5, dtype=tdtype)
     # levels 0..135: temperature -> degC; level 136: orography -> geopotential -> (no convert)
     s_orog = [(native.OP_COPY, 0, 0.0, 0.0)] * (n_lev - 1) + [(native.OP_MUL, 0, oracle.G, 0.0)]
     s_conv = [(native.OP_AFFINE, 0, 1.0, -273.15)] * (n_lev - 1) + [(native.OP_COPY, 0, 0.0, 0.0)]
@@ -126,12 +129,18 @@ def test_config5_chained_filters_on_o2560(dev):
     chained = plain.new_like()
     native.pointwise_stack(plain.data, chained.data, n_pts=n_tgt, n_lev=n_lev, x_pitch=plain.pitch, y_pitch=chained.pitch,
                            layout=COLUMNS, prog=prog, n_stage=2)
-    assert torch.equal(fused.data[:, :n_lev].contiguous().view(torch.int32), chained.data[:, :n_lev].contiguous().view(torch.int32))
+    bits = torch.int32 if tdtype == torch.float32 else torch.int64
+    assert fused.data.dtype == tdtype
+    assert torch.equal(fused.data[:, :n_lev].contiguous().view(bits), chained.data[:, :n_lev].contiguous().view(bits))
     indptr = np.arange(n_tgt + 1) * 4
-    w32 = w.astype(np.float32).reshape(-1)
-    for l, fn in ((0, lambda v: oracle.rescale_forward(v, np.float32(1.0), np.float32(-273.15))), (136, lambda v: v * np.float32(oracle.G))):
-        base = oracle.csr_apply(w32, idx.reshape(-1), indptr, (n_tgt, n_src), x.level_numpy(l))
-        assert np.array_equal(fused.level_numpy(l), fn(base))
+    weights = w.astype(np_dtype).reshape(-1)
+    for l, fn in ((0, lambda v: oracle.rescale_forward(v, np_dtype(1.0), np_dtype(-273.15))), (136, lambda v: v * np_dtype(oracle.G))):
+        base = oracle.csr_apply(weights, idx.reshape(-1), indptr, (n_tgt, n_src), x.level_numpy(l))
+        want = fn(base)
+        assert want.dtype == np_dtype
+        assert np.array_equal(fused.level_numpy(l), want)
+    del x, fused, plain, chained
+    torch.cuda.empty_cache()
 
 
 def test_kernels_on_a_stack_beyond_2_to_31_elements(dev):

@@ -48,6 +48,54 @@ def case(dev):
                 plan=GatherPlan(n_src, n_tgt, index=idx, weights=w))
 
 
+@pytest.fixture(scope="module")
+def case64(case, dev):
+    """The HEADLINE instantiation at the headline size: the float64 stack (the reference's own width, R: fields.py:178-202) that
+    `bench.py` times — `regrid_cols_ell_direct_kernel<double, 2, 4, true, false, 0>` over 71.6 M (target, vector) items."""
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(20260631)
+    lat = torch.from_numpy(np.deg2rad(case["src"]["latitudes"])).to(dev)
+    lon = torch.from_numpy(np.deg2rad(case["src"]["longitudes"])).to(dev)
+    x = Stack.empty(case["n_src"], N_LEV, torch.float64, dev, COLUMNS, zero=True)
+    base = 280.0 + 30.0 * torch.sin(lat) * torch.cos(2.0 * lon)
+    for l in range(N_LEV):
+        x.data[:, l] = base + 0.1 * l + torch.randn(case["n_src"], dtype=torch.float64, device=dev, generator=gen)
+    return dict(case, x=x)
+
+
+def test_headline_float64_sample_levels_are_scipys_bits(case64):
+    """R: regrid.py:310 `csr_array @ x` in float64 — BASELINE configs[2] in the width the bench line reports."""
+    out = case64["plan"].apply(case64["x"])
+    assert out.data.dtype == torch.float64 and out.n_pts == case64["n_tgt"] and out.n_lev == N_LEV
+    indptr = np.arange(case64["n_tgt"] + 1) * 4
+    for l in (0, 68, 136):
+        want = oracle.csr_apply(case64["w"].reshape(-1), case64["idx"].reshape(-1), indptr, (case64["n_tgt"], case64["n_src"]),
+                                case64["x"].level_numpy(l))
+        assert want.dtype == np.float64
+        assert np.array_equal(out.level_numpy(l), want), l  # bit-exact: scipy's summation order, no FMA
+
+
+def test_headline_float64_nearest_is_a_bit_copy(case64):
+    """R: regrid.py:380 `x[..., nearest_grid_points]` at full size in float64 (the `extras.nearest_k1` launch of the bench)."""
+    nearest = np.ascontiguousarray(case64["idx"][:, 0])
+    plan = GatherPlan(case64["n_src"], case64["n_tgt"], index=nearest)
+    out = plan.apply(case64["x"])
+    for l in (0, 68, 136):
+        want = oracle.gather_nn(case64["x"].level_numpy(l), nearest)
+        assert np.array_equal(out.level_numpy(l).view(np.uint64), want.view(np.uint64)), l
+    # and the whole stack against torch's own indexing, bit for bit
+    picked = case64["x"].data[torch.from_numpy(nearest).to(out.data.device)]
+    assert torch.equal(out.data[:, :N_LEV].contiguous().view(torch.int64), picked[:, :N_LEV].contiguous().view(torch.int64))
+
+
+def test_headline_float64_shards_concatenate_bit_exact(case64):
+    """The 8 traffic-balanced target shards of the float64 job (what ranks 0..7 of the 8-GPU run compute) against the one launch."""
+    full = case64["plan"].apply(case64["x"]).data
+    parts = [case64["plan"].shard(r, 8).apply(case64["x"]).data for r in range(8)]
+    assert sum(p.shape[0] for p in parts) == case64["n_tgt"]
+    assert torch.equal(torch.cat(parts)[:, :N_LEV].contiguous().view(torch.int64), full[:, :N_LEV].contiguous().view(torch.int64))
+
+
 def test_sample_levels_match_oracle(case):
     out = case["plan"].apply(case["x"])
     indptr = np.arange(case["n_tgt"] + 1) * 4

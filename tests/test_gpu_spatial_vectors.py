@@ -1,0 +1,73 @@
+"""The DEVICE index / mask builders against vectors produced by running the reference's own ``spatial.py``
+(``tests/golden/spatial_vectors.npz``; generator ``tests/golden/make_spatial_vectors.py``, CPU counterpart
+``tests/test_spatial_vectors.py``): ``nearest_grid_points_device`` (``atx_knn_build`` / ``atx_knn_query``),
+``cutout_mask(device=True)`` (``atx_knn_*`` + ``atx_cutout_inside``), ``thinning_mask(device=True)``,
+``global_on_lam_mask(device=True)``.  Index / boolean work and float64 chord distances: ``array_equal``."""
+
+from __future__ import annotations
+
+import numpy as np
+import pytest
+
+from anemoi_transform_amd import interp, spatial
+from test_spatial_vectors import MANIFEST, VECTORS, ids
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(autouse=True)
+def no_remembered_tables():
+    """Every case searches on the device: nothing comes from a table an earlier test left in the memo or in the session's files."""
+    interp.knn_cache_clear(disk=True)
+    yield
+    interp.knn_cache_clear(disk=True)
+
+
+@pytest.mark.parametrize("case", MANIFEST["nearest_grid_points"], ids=ids(MANIFEST["nearest_grid_points"]))
+def test_nearest_grid_points_device(dev, case):
+    """R: spatial.py:587-635 — the regular -> regular pair is the tie-heavy one (every second target exactly between source
+    points, 36 coincident source points at each pole); the bounded variants carry cKDTree's "missing" marker (n_src, inf)."""
+    src, tgt = VECTORS.grid(case["source"]), VECTORS.grid(case["target"])
+    want_idx, want_dist = VECTORS.file[case["key"] + "/idx"], VECTORS.file[case["key"] + "/dist"]
+    idx, dist = interp.nearest_grid_points_device(src["latitudes"], src["longitudes"], tgt["latitudes"], tgt["longitudes"],
+                                                  max_distance=case["max_distance"], num_neighbours_to_return=case["k"],
+                                                  return_distances=True)
+    assert interp.knn_cache_info()["misses"] == 1 and interp.knn_cache_info()["memory_hits"] == 0  # searched, not remembered
+    assert list(idx.shape) == case["shape"] and idx.dtype == np.int64
+    assert np.array_equal(dist, want_dist), "chord distances must be the reference's bits"
+    assert np.array_equal(idx, want_idx), "the index table must be the reference's (ties in cKDTree's order)"
+    assert int(np.sum(idx == len(src["latitudes"]))) == case["missing"]
+
+
+@pytest.mark.parametrize("case", MANIFEST["cutout_mask"], ids=ids(MANIFEST["cutout_mask"]))
+def test_cutout_mask_device(dev, case):
+    """R: spatial.py:294-440 — neighbour search and Möller–Trumbore tests on the GPU; the unjittered patch inside the regular
+    2-degree grid has coincident points, equidistant neighbours and points exactly on triangle edges."""
+    lats, lons = VECTORS.lam(case["lam"])
+    glob = VECTORS.grid(case["global"])
+    mask = spatial.cutout_mask(lats, lons, glob["latitudes"].copy(), glob["longitudes"].copy(), device=True, **case["options"])
+    want = VECTORS.mask(case)
+    assert mask.dtype == bool and mask.shape == want.shape
+    differ = np.flatnonzero(mask != want)
+    assert differ.size == 0, (f"{differ.size} global points differ, first at index {differ[:5]}: "
+                              f"lat {glob['latitudes'][differ[:5]]}, lon {glob['longitudes'][differ[:5]]}")
+
+
+@pytest.mark.parametrize("case", MANIFEST["thinning_mask"], ids=ids(MANIFEST["thinning_mask"]))
+def test_thinning_mask_device(dev, case):
+    """R: spatial.py:443-503."""
+    lats, lons = VECTORS.lam(case["lam"])
+    glob = VECTORS.grid(case["global"])
+    indices = spatial.thinning_mask(lats, lons, glob["latitudes"], glob["longitudes"], cropping_distance=case["cropping_distance"], device=True)
+    assert np.array_equal(indices, VECTORS.file[case["key"]])
+
+
+@pytest.mark.parametrize("case", MANIFEST["global_on_lam_mask"], ids=ids(MANIFEST["global_on_lam_mask"]))
+def test_global_on_lam_mask_device(dev, case):
+    """R: spatial.py:506-536 — one k = 1 search from every global point instead of a ball query per LAM point; the distances
+    "lam" / "global" / None are the grids' own resolutions, so points sit EXACTLY at the radius."""
+    lats, lons = VECTORS.lam(case["lam"])
+    glob = VECTORS.grid(case["global"])
+    indices = spatial.global_on_lam_mask(lats, lons, glob["latitudes"], glob["longitudes"], distance_km=case["distance_km"], device=True)
+    want = VECTORS.file[case["key"]]
+    assert indices.shape == want.shape and np.array_equal(indices, want)

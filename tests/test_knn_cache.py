@@ -105,3 +105,37 @@ def test_regrid_filter_construction_reuses_the_table(cache, monkeypatch):
     info = interp.knn_cache_info()
     assert info["trees_built"] == 1 and info["misses"] == 1 and info["memory_hits"] == 1
     assert all(np.array_equal(a, b) for a, b in zip(*outs))
+
+
+def test_tables_are_kept_per_producer_and_format(cache, monkeypatch):
+    """A table the device search built is never served to the host path (or back), and a file of another format is ignored
+    (the advisor's round-3 finding: a retuned kernel must not leave trusted stale files behind)."""
+    src, tgt = _grids()
+    args = (src["latitudes"], src["longitudes"], tgt["latitudes"], tgt["longitudes"])
+    calls = []
+
+    def compute_marked(marker):
+        def compute(src_hash):
+            calls.append(marker)
+            n = len(tgt["latitudes"])
+            return np.full((n, 2), marker, dtype=np.int64), np.full((n, 2), float(marker))
+        return compute
+
+    host = interp._remembered_table(*args, 2, None, "ckdtree", compute_marked(1), producer="host")
+    device = interp._remembered_table(*args, 2, None, "ckdtree", compute_marked(2), producer="device")
+    assert calls == [1, 2] and host[0][0, 0] == 1 and device[0][0, 0] == 2  # same grids, k, bound, tie order: two entries
+    assert interp._remembered_table(*args, 2, None, "ckdtree", compute_marked(3), producer="host")[0][0, 0] == 1
+    files = sorted(os.path.basename(f) for f in glob.glob(os.path.join(str(cache), "knn", "knn-*.npz")))
+    assert len(files) == 2 and f"knn-v{interp.KNN_TABLE_FORMAT}-device-ckdtree-" in files[0] and f"knn-v{interp.KNN_TABLE_FORMAT}-host-ckdtree-" in files[1]
+    with np.load(os.path.join(str(cache), "knn", files[0])) as f:
+        assert str(f["producer"]) == "device" and int(f["format"]) == interp.KNN_TABLE_FORMAT and "library_version" in f
+    # a new format number: memory and files of the old one are not consulted
+    interp.knn_cache_clear()
+    monkeypatch.setattr(interp, "KNN_TABLE_FORMAT", interp.KNN_TABLE_FORMAT + 1)
+    assert interp._remembered_table(*args, 2, None, "ckdtree", compute_marked(4), producer="host")[0][0, 0] == 4
+    # a file whose recorded producer does not match its name (copied by hand) is a miss
+    interp.knn_cache_clear()
+    newest = [f for f in glob.glob(os.path.join(str(cache), "knn", "knn-*.npz")) if f"knn-v{interp.KNN_TABLE_FORMAT}-host" in f]
+    assert len(newest) == 1
+    os.replace(newest[0], newest[0].replace("-host-", "-device-"))
+    assert interp._remembered_table(*args, 2, None, "ckdtree", compute_marked(5), producer="device")[0][0, 0] == 5
