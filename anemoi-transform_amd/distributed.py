@@ -153,6 +153,17 @@ def rebase_plan(plan: GatherPlan, lo: int, hi: int) -> GatherPlan:
     return based
 
 
+def _band_layout(plan: GatherPlan, rank: int, world: int) -> tuple[list[tuple[int, int]], GatherPlan]:
+    """``(source band of every rank's target slice, this rank's slice rebased onto its own band)`` — host work over the whole index
+    table (17 ms for O1280 -> 0.25 degree), remembered on the plan: a job exchanges bands at every step with the same plan."""
+    cached = plan.__dict__.setdefault("_bands", {})
+    key = (int(rank), int(world))
+    if key not in cached:
+        ranges = [source_band(plan.shard(r, world)) for r in range(world)]  # same on every rank: the plan is replicated
+        cached[key] = (ranges, rebase_plan(plan.shard(rank, world), *ranges[rank]))
+    return cached[key]
+
+
 def exchange_source_bands(mine: Stack, plan: GatherPlan, comm=None) -> tuple[list[Stack], GatherPlan]:
     """Band-limited source exchange: every rank contributes one source stack and receives, from every
     rank, only the slab of source columns its own target slice references.
@@ -165,13 +176,13 @@ def exchange_source_bands(mine: Stack, plan: GatherPlan, comm=None) -> tuple[lis
     """
     assert mine.layout == COLUMNS, "a band is a contiguous row range of a column stack"
     rank, world = _rank_world(comm)
-    ranges = [source_band(plan.shard(r, world)) for r in range(world)]  # same on every rank: the plan is replicated
+    ranges, local_plan = _band_layout(plan, rank, world)
     lo, hi = ranges[rank]
     bands = [Stack.empty(hi - lo, mine.n_lev, mine.dtype, mine.device, COLUMNS) for _ in range(world)]
     if comm is not None:  # atx_exchange: one grouped send/recv, the own slab a device copy
         comm.exchange([mine.data[r_lo:r_hi] if r_hi > r_lo else None for r_lo, r_hi in ranges],
                       [b.data if hi > lo else None for b in bands])
-        return bands, rebase_plan(plan.shard(rank, world), lo, hi)
+        return bands, local_plan
     bands[rank].data.copy_(mine.data[lo:hi])
     # Host-side backends (gloo: rehearsals, CPU tests) get the slabs through pinned host memory.  Handed a device tensor, gloo's
     # point-to-point path lets its TCP transport read HBM through the PCIe BAR — uncached host reads of device memory — and
@@ -199,7 +210,7 @@ def exchange_source_bands(mine: Stack, plan: GatherPlan, comm=None) -> tuple[lis
             work.wait()
     for device_side, host_side in landing:
         device_side.copy_(host_side, non_blocking=True)
-    return bands, rebase_plan(plan.shard(rank, world), lo, hi)
+    return bands, local_plan
 
 
 def sharded_regrid(plan: GatherPlan, src: Stack, rank: int | None = None, world: int | None = None) -> Stack:

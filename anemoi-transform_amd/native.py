@@ -225,15 +225,46 @@ def regrid_ell(src, out, idx, w, *, n_src, n_tgt, k, n_lev, src_pitch, out_pitch
     if tgt_rows is not None:
         return regrid_ell_batch([src], [out], idx, w, n_src=n_src, n_tgt=n_tgt, k=k, n_lev=n_lev, src_pitch=src_pitch, out_pitch=out_pitch,
                                 layout=layout, prog=prog, n_stage=n_stage, tgt_mask=tgt_mask, padded=padded, tgt_rows=tgt_rows)
+    _call("atx_regrid_ell", *_regrid_ell_args(src, out, idx, w, n_src, n_tgt, k, n_lev, src_pitch, out_pitch, layout, prog, n_stage, tgt_mask,
+                                              padded), _stream())
+
+
+def _regrid_ell_args(src, out, idx, w, n_src, n_tgt, k, n_lev, src_pitch, out_pitch, layout, prog, n_stage, tgt_mask, padded) -> tuple:
+    """The arguments of ``atx_regrid_ell`` up to (not including) the stream, checked and converted."""
     assert src.dtype == out.dtype, (src.dtype, out.dtype)
     assert idx.dtype == torch.int32
     if w is not None:
         assert w.dtype == src.dtype, (w.dtype, src.dtype)
     vec, host = _program_companions(prog, src.dtype)
-    _call(
-        "atx_regrid_ell", _ptr(src), _ptr(out), _ptr(idx), _ptr(w), n_src, n_tgt, k, n_lev, src_pitch, out_pitch,
-        dtype_code(src.dtype), layout, ELL_PADDED if padded else 0, _ptr(prog), vec, host, n_stage, _ptr(tgt_mask), _stream(),
-    )
+    return (_ptr(src), _ptr(out), _ptr(idx), _ptr(w), n_src, n_tgt, k, n_lev, src_pitch, out_pitch, dtype_code(src.dtype), layout,
+            ELL_PADDED if padded else 0, _ptr(prog), vec, host, n_stage, _ptr(tgt_mask))
+
+
+class BoundCall:
+    """One libatx entry point with its arguments checked and converted ONCE, for call sites that repeat the same launch on the same
+    buffers (a one-field regrid per time step is launch-bound: its kernel runs 3 us, the Python marshalling of 19 arguments costs
+    more than that).  ``__call__`` enqueues on the stream that was current when the call was bound, or on ``stream=`` given then.
+    The object keeps the tensors it points into alive."""
+
+    __slots__ = ("_fn", "_name", "_args", "_keep")
+
+    def __init__(self, name: str, args: tuple, keep: tuple, stream: int | None = None) -> None:
+        self._fn = getattr(load(), name)
+        self._name = name
+        self._args = (*args, _stream() if stream is None else stream)
+        self._keep = keep
+
+    def __call__(self) -> None:
+        code = self._fn(*self._args)
+        if code != OK:
+            _raise(code, self._name)
+
+
+def bind_regrid_ell(src, out, idx, w, *, n_src, n_tgt, k, n_lev, src_pitch, out_pitch, layout, prog=None, n_stage=0, tgt_mask=None,
+                    padded: bool = False, stream: int | None = None) -> BoundCall:
+    """``regrid_ell`` (natural target order) as a ``BoundCall``."""
+    args = _regrid_ell_args(src, out, idx, w, n_src, n_tgt, k, n_lev, src_pitch, out_pitch, layout, prog, n_stage, tgt_mask, padded)
+    return BoundCall("atx_regrid_ell", args, (src, out, idx, w, prog, tgt_mask), stream)
 
 
 def regrid_ell_batch(srcs, outs, idx, w, *, n_src, n_tgt, k, n_lev, src_pitch, out_pitch, layout, prog=None, n_stage=0,

@@ -131,9 +131,12 @@ class Stack:
     def device(self) -> torch.device:
         return self.data.device
 
+    @property
+    def layout_name(self) -> str:
+        return "columns" if self.layout == COLUMNS else "fields"
+
     def __repr__(self) -> str:
-        name = "columns" if self.layout == COLUMNS else "fields"
-        return f"Stack({self.n_lev} levels x {self.n_pts} points, {name}, {self.dtype}, pitch={self.pitch})"
+        return f"Stack({self.n_lev} levels x {self.n_pts} points, {self.layout_name}, {self.dtype}, pitch={self.pitch})"
 
     # ---- construction ----------------------------------------------------------------
     @classmethod

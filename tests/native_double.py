@@ -96,6 +96,11 @@ def regrid_ell(src, out, idx, w, *, n_src, n_tgt, k, n_lev, src_pitch, out_pitch
     _epilogue(y, prog, n_stage, tgt_mask, n_lev)
 
 
+def bind_regrid_ell(src, out, idx, w, *, stream=None, **kw):
+    """``native.BoundCall`` stand-in: the same launch, repeated on the same buffers."""
+    return lambda: regrid_ell(src, out, idx, w, **kw)
+
+
 def regrid_ell_batch(srcs, outs, idx, w, **kw):
     for src, out in zip(srcs, outs):
         regrid_ell(src, out, idx, w, **kw)
@@ -255,7 +260,7 @@ def cutout_inside(global_xyz, lam_xyz, neighbours):
     return torch.from_numpy(inside)
 
 
-PATCHED = ["KnnIndex", "cutout_inside", "regrid_ell", "regrid_ell_batch", "regrid_csr", "check_indices", "pointwise_stack", "combine_stack", "mask_build", "mask_count", "mask_to_index",
+PATCHED = ["KnnIndex", "cutout_inside", "regrid_ell", "bind_regrid_ell", "regrid_ell_batch", "regrid_csr", "check_indices", "pointwise_stack", "combine_stack", "mask_build", "mask_count", "mask_to_index",
            "reduce", "relayout", "reduce_stack", "select_levels"]
 
 

@@ -41,6 +41,15 @@ def test_single_gpu_line():
     # both reference statements (csr_array @ x, x[..., idx]) in both widths
     assert set(c["variants"]) == {"csr_f64", "csr_f32", "k1_f64", "k1_f32"} and all(v["value"] > 0 for v in c["variants"].values())
     assert c["value"] == c["variants"]["csr_f64"]["value"]
+    # what the CPU figures were measured on, inside `cpu_baseline` so that the driver's record keeps it
+    host = c["host"]
+    assert {"model", "nproc", "cpu_quota_cores", "numpy", "scipy", "python"} <= set(host)
+    assert isinstance(host["model"], str) and host["model"] and host["nproc"] >= 1
+    import numpy
+    import scipy
+
+    assert host["numpy"] == numpy.__version__ and host["scipy"] == scipy.__version__
+    assert "multi_gpu" not in d["config"]  # N = 1: nothing to mirror
     assert d["parity_max_rel_err"] == 0.0  # float64: scipy's bits
 
 
@@ -64,6 +73,22 @@ def test_two_ranks_without_a_launcher():
     assert run.returncode == 0, run.stderr[-2000:]
     d = last_json(run.stdout)
     assert KEYS <= set(d) and d["n_gpus"] == 2 and d["value"] > 0 and d["config"]["stacks_per_step"] == 2
+    # --no-extras: the mirror is there (the driver's record keeps `config` whole) and says that nothing was measured
+    m = d["config"]["multi_gpu"]
+    assert m["strong"] is None and m["end_to_end"] is None and m["source_exchange_ms"] == {"broadcast": None, "bands": None}
+
+
+def assert_mirrored(d: dict) -> None:
+    """`config.multi_gpu` repeats the numbers of the top-level sections (which the driver's record reduces to their names) and
+    `config.sharding` says which of them answers north_star's ">= 6x at 8 GPUs"."""
+    m = d["config"]["multi_gpu"]
+    for section in ("strong", "end_to_end", "end_to_end_bands", "field_axis_sharding"):
+        assert m[section]["value"] == d[section]["value"] > 0 and m[section]["ms_per_step"] == d[section]["ms_per_step"], section
+    assert m["source_exchange_ms"] == {k: d["source_exchange_ms"][k] for k in ("broadcast", "bands")}
+    assert m["end_to_end"]["verified_bit_equal"] is True and m["end_to_end_bands"]["verified_bit_equal"] is True
+    assert m["secondary_timed_out_in"] is None
+    text = d["config"]["sharding"]
+    assert "end_to_end" in text and "strong" in text and "north_star" in text and "WEAK" in text
 
 
 def test_two_ranks_rehearsal_over_gloo():
@@ -91,6 +116,8 @@ def test_two_ranks_rehearsal_over_gloo():
     assert d["config5"]["value"] > 0 and d["config5"]["scaling"] == "strong"
     assert d["field_axis_sharding"]["value"] > 0  # the no-exchange comparison point rides along
     assert "cpu_baseline" not in d and "secondary_timed_out_in" not in d  # rank 0 at N = 1 only
+    assert_mirrored(d)
+    assert d["config"]["multi_gpu"]["config4"]["value"] == d["config4"]["value"] and d["config"]["multi_gpu"]["config5"]["value"] == d["config5"]["value"]
 
 
 def test_secondary_lines_cannot_cost_the_value():
@@ -105,6 +132,7 @@ def test_secondary_lines_cannot_cost_the_value():
     assert run.returncode != 0  # the line is out, but a collective that never returned is a failure the launcher must see
     d = last_json(run.stdout)
     assert d["value"] > 0 and d["n_gpus"] == 2 and "secondary_timed_out_in" in d
+    assert d["config"]["multi_gpu"]["secondary_timed_out_in"] == d["secondary_timed_out_in"]  # the cut is visible in `config` too
 
 
 def test_multi_gpu_sections_on_real_rccl_at_world_1():
@@ -125,6 +153,7 @@ def test_multi_gpu_sections_on_real_rccl_at_world_1():
     assert ex["broadcast"]["verified_bit_equal"] is True and ex["bands"]["verified_bit_equal"] is True
     assert d["end_to_end"]["verified_bit_equal"] is True and d["strong"]["value"] > 0
     assert d["end_to_end_bands"]["verified_bit_equal"] is True
+    assert_mirrored(d)
     c = ex["c_abi"]
     assert c["init"]["rccl_version"] >= 20000
     for name in ("broadcast", "bands", "end_to_end"):

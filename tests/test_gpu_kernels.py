@@ -13,6 +13,7 @@ import pytest
 import torch
 
 from anemoi_transform_amd import native
+from anemoi_transform_amd.gather import GatherPlan
 from anemoi_transform_amd.stack import COLUMNS, FIELDS, Stack
 from oracle import oracle
 
@@ -823,3 +824,36 @@ def test_padded_ragged_rows_run_on_the_fixed_k_kernel(dev, tdtype, np_dtype, lay
     long_rows = GatherPlan.from_matrix(dict(matrix_data=np.ones(39), matrix_indices=np.arange(39, dtype=np.int32),
                                             matrix_indptr=np.array([0, 20, 39], dtype=np.int32), matrix_shape=(2, 100)))
     assert long_rows.kind == "csr"
+
+
+@pytest.mark.parametrize("tdtype,np_dtype", DTYPES)
+@pytest.mark.parametrize("layout", LAYOUTS)
+def test_gather_into_a_kept_stack_and_bound_launch(dev, tdtype, np_dtype, layout):
+    """`GatherPlan.apply(out=)` and `GatherPlan.bind` (native.BoundCall: arguments converted once, the stream captured) launch the
+    same kernel as `apply` — same bits — and a bound launch sees new contents of the source buffer."""
+    rng = np.random.default_rng(21)
+    n_src, n_tgt, n_lev, k = 4000, 2500, 3, 4
+    x = make_fields(rng, n_lev, n_src, np_dtype)
+    idx, w = random_ell(rng, n_src, n_tgt, k, np_dtype)
+    plan = GatherPlan(n_src, n_tgt, index=idx, weights=w.astype(np.float64))
+    src = Stack.from_fields(x, dev=dev, layout=layout)
+    indptr = np.arange(n_tgt + 1) * k
+    want = np.stack([oracle.csr_apply(w.reshape(-1), idx.reshape(-1), indptr, (n_tgt, n_src), f) for f in x])
+    out = src.new_like(n_pts=n_tgt)
+    out.data.fill_(float("nan"))
+    assert plan.apply(src, out=out) is out
+    assert_interp(out.numpy(), want, np_dtype)
+    launch, kept = plan.bind(src)
+    assert isinstance(launch, native.BoundCall)
+    launch()
+    assert torch.equal(kept.data, out.data)
+    src.data.mul_(2.0)  # exact in binary: every product doubles, so does every sum
+    launch()
+    torch.cuda.synchronize()
+    assert_interp(kept.numpy(), (2.0 * want).astype(np_dtype), np_dtype)
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):  # a call bound under another stream enqueues there
+        launch2, kept2 = plan.bind(src)
+        launch2()
+    side.synchronize()
+    assert torch.equal(kept2.data, kept.data)

@@ -675,6 +675,44 @@ def test_long_rows_on_field_major_stacks_go_through_columns(monkeypatch):
     assert out.layout == FIELDS and seen[0] == (FIELDS, COLUMNS) and seen[-1] == (COLUMNS, FIELDS)
 
 
+def test_gather_into_a_caller_kept_stack_and_bound_launches(monkeypatch):
+    """`GatherPlan.apply(out=)` writes into a stack the caller keeps (no allocation per call) and refuses one of the wrong shape;
+    `GatherPlan.bind` gives a launch that repeats the gather on the same buffers and sees new CONTENTS of the source."""
+    import native_double
+    import torch
+    from anemoi_transform_amd.stack import COLUMNS, FIELDS, Stack
+    from oracle import oracle
+
+    native_double.install(monkeypatch)
+    rng = np.random.default_rng(4)
+    n_src, n_tgt, k = 150, 64, 4
+    fields = rng.standard_normal((3, n_src))
+    idx, w = rng.integers(0, n_src, (n_tgt, k)), rng.random((n_tgt, k))
+    want = lambda f: np.stack([oracle.csr_apply(w.reshape(-1), idx.reshape(-1), np.arange(n_tgt + 1) * k, (n_tgt, n_src), x) for x in f])  # noqa: E731
+    for layout in (COLUMNS, FIELDS):
+        x = Stack.from_fields(fields, dev=torch.device("cpu"), layout=layout)
+        for plan in (GatherPlan(n_src, n_tgt, index=idx, weights=w),
+                     GatherPlan(n_src, n_tgt, csr=(w.reshape(-1), idx.reshape(-1).astype(np.int32), (np.arange(n_tgt + 1) * k).astype(np.int32)))):
+            out = x.new_like(n_pts=n_tgt)
+            assert plan.apply(x, out=out) is out and np.array_equal(out.numpy(), want(fields))
+            with pytest.raises(ValueError, match="out= must be"):
+                plan.apply(x, out=x.new_like(n_pts=n_tgt + 1))
+            with pytest.raises(ValueError, match="out= must be"):
+                plan.apply(x, out=Stack.empty(n_tgt, 3, torch.float32, torch.device("cpu"), layout))
+            launch, kept = plan.bind(x)
+            launch()
+            assert np.array_equal(kept.numpy(), want(fields))
+            x.data.mul_(2.0)  # new contents, same storage
+            launch()
+            assert np.array_equal(kept.numpy(), want(2.0 * fields))
+            x.data.mul_(0.5)
+    # a field-major stack and long rows: apply(out=) still lands in the caller's stack (through columns and back)
+    wide = GatherPlan(n_src, n_tgt, index=rng.integers(0, n_src, (n_tgt, 12)), weights=rng.random((n_tgt, 12)))
+    x_f = Stack.from_fields(fields, dev=torch.device("cpu"), layout=FIELDS)
+    out = x_f.new_like(n_pts=n_tgt)
+    assert wide.apply(x_f, out=out) is out and np.array_equal(out.numpy(), wide.apply(x_f).numpy())
+
+
 def test_no_streaming_kernel_uses_scratch_memory():
     """Read from the code objects inside libatx.so (tools/kernel_resources.py; no GPU): only the k-NN traversal (its per-lane stack) and
     rocPRIM's radix sort may use private scratch memory.  A private array indexed with a run-time subscript lands there — the field-major

@@ -4,10 +4,12 @@
 
     python tools/design_tables.py [--check]
 
-Blocks between `<!-- BEGIN generated: NAME (source) -->` and `<!-- END generated: NAME -->` are replaced:
-  kernel-table   profiles/r03_kernel_bench.json   (tools/kernel_bench.py --out)
-  bench-line     profiles/r03_bench_latest.json   (python bench.py)
-`--check` exits 1 if DESIGN.md is not up to date (used by tests/test_host_api.py)."""
+Blocks between `<!-- BEGIN generated: NAME (source) -->` and `<!-- END generated: NAME -->` in DESIGN.md, README.md and
+INTEGRATION.md are replaced (the newest round's record of each kind is used):
+  kernel-table   profiles/rNN_kernel_bench.json   (tools/kernel_bench.py --out)
+  bench-line     profiles/rNN_bench_latest.json   (python bench.py)
+  host-fed       profiles/rNN_host_fed_path.json  (tools/host_path_bench.py) + the bench record's all-core CPU line
+`--check` exits 1 if a document is not up to date (used by tests/test_host_api.py)."""
 
 from __future__ import annotations
 
@@ -19,6 +21,15 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 DESIGN = os.path.join(ROOT, "DESIGN.md")
+DOCUMENTS = ["DESIGN.md", "README.md", "INTEGRATION.md"]
+
+
+def newest(kind: str) -> str:
+    """`profiles/rNN_<kind>` of the latest round that has one (relative path)."""
+    import glob
+
+    found = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r[0-9][0-9]_{kind}")))
+    return os.path.relpath(found[-1], ROOT) if found else f"profiles/r03_{kind}"
 
 
 def kernel_table(path: str) -> str:
@@ -61,7 +72,9 @@ def bench_line(path: str) -> str:
         f"{r['peak']:.0f} = **{r['frac']:.3f}** on {r['algorithmic_bytes_per_launch'] / 1e9:.3f} GB algorithmic bytes per launch "
         f"(HIP events: avg {r['avg_launch_ms']:.4f} ms, min {r['min_launch_ms']:.4f} ms); traffic {('%.3f GB' % (r['traffic'] / 1e9)) if r.get('traffic') else 'null'}",
     ]
-    shape_csv = os.path.join(ROOT, "profiles", "r03_bench_kernel_by_launch_shape.csv")
+    shape_rel = newest("bench_kernel_by_launch_shape.csv")
+    shape_csv = os.path.join(ROOT, shape_rel)
+    rocprof_rel = newest("bench_under_rocprof.json")
     if os.path.exists(shape_csv):
         import csv
 
@@ -70,7 +83,7 @@ def bench_line(path: str) -> str:
             h = rows[0]  # the shape with the most dispatches: the headline launch
             lines.append(f"* rocprofv3 `--kernel-trace` of the same command, headline launch shape (`{h['kernel'].replace('atx::', '')}`, {h['grid_x_lanes']} lanes): "
                          f"{h['calls']} dispatches, average **{float(h['average_ns']) / 1e3:.1f} µs**, min {float(h['min_ns']) / 1e3:.1f} µs "
-                         f"(`profiles/r03_bench_kernel_by_launch_shape.csv`; HIP events of the run under rocprof: `profiles/r03_bench_under_rocprof.json`)")
+                         f"(`{shape_rel}`; HIP events of the run under rocprof: `{rocprof_rel}`)")
     for name in ("f32_columns", "f64_columns", "nearest_k1", "nearest_k1_f32", "nearest_k1_f64", "fused_regrid_orog_to_z_convert", "f64_fields", "f32_fields"):
         if name in e:
             lines.append(f"* `extras.{name}`: {e[name]['value']:.4g} grid-points/s, {e[name]['avg_launch_ms']:.4f} ms, {e[name]['frac']:.3f}")
@@ -82,35 +95,70 @@ def bench_line(path: str) -> str:
     return "\n".join(lines)
 
 
-SOURCES = {"kernel-table": ("profiles/r03_kernel_bench.json", kernel_table), "bench-line": ("profiles/r03_bench_latest.json", bench_line)}
+def sci(v: float) -> str:
+    """1.04e9 rather than 1.04e+09."""
+    import math
+
+    if not v or v != v:
+        return "n/a"
+    e = int(math.floor(math.log10(abs(v))))
+    return f"{v / 10 ** e:.2f}e{e}"
+
+
+def host_fed(path: str) -> str:
+    """Where the speed-up lives: the host-fed job (PCIe-bound) against the CPU's best case and the HBM-resident rate."""
+    h = json.load(open(path))
+    bench_rel = newest("bench_latest.json")
+    b = json.load(open(os.path.join(ROOT, bench_rel)))
+    e = b.get("extras", {})
+    cpu = e.get("cpu_all_cores", {})
+    f32 = e.get("f32_columns", {}).get("value") if b["dtype"] == "f64" else b["value"]
+    cpu_txt = (f"the same statement on the {cpu['cores']} CPU cores the box grants runs at {sci(cpu['value'])} grid-points/s (float64; `extras.cpu_all_cores`)"
+               if "value" in cpu else "the all-core CPU line was not measured in that run")
+    return (f"**Where the speed-up lives.**  A FieldList that arrives in HOST memory is bound by PCIe, not by the kernel: 137 float32 O1280 fields "
+            f"→ `regrid` → 137 host arrays take {h['filter_forward_plus_to_numpy_ms']:.0f} ms end to end on a first call — upload {h['upload_ms']:.0f} ms "
+            f"({h['upload_GBs']:.0f} GB/s), kernel {h['kernel_ms']:.1f} ms, download {h['download_ms']:.0f} ms ({h['download_GBs']:.0f} GB/s) — i.e. "
+            f"**{sci(h['host_fed_grid_points_per_s'])} grid-points/s**, {sci(h['job_host_fed_grid_points_per_s_prefetch'])} in a steady job with "
+            f"`prefetch_to_device` staging the next list; {cpu_txt}, so a job that crosses PCIe for every filter call is no faster than — and "
+            f"can be SLOWER than — the reference on that box's CPU cores.  The same stack RESIDENT in HBM is regridded at **{sci(f32)} grid-points/s** in "
+            f"float32 ({sci(b['value'] if b['dtype'] == 'f64' else e.get('f64_columns', {}).get('value', float('nan')))} in float64): two orders of magnitude apart.  Upload once, keep chains on the "
+            f"device (fields expose `to_tensor()`; a `Pipeline` of GPU filters is fused and never leaves HBM between stages), download only the final "
+            f"result.  (`{os.path.relpath(path, ROOT)}`, `{bench_rel}`)")
+
+
+SOURCES = {"kernel-table": ("kernel_bench.json", kernel_table), "bench-line": ("bench_latest.json", bench_line), "host-fed": ("host_fed_path.json", host_fed)}
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--check", action="store_true")
     args = ap.parse_args()
-    text = open(DESIGN).read()
-    new = text
-    for name, (rel, fn) in SOURCES.items():
-        path = os.path.join(ROOT, rel)
-        pattern = re.compile(rf"(<!-- BEGIN generated: {name}[^\n]*-->\n)(.*?)(\n<!-- END generated: {name} -->)", re.S)
-        if not pattern.search(new):
-            continue
-        if not os.path.exists(path):
-            print(f"{rel} is missing: block {name} left alone", file=sys.stderr)
-            continue
-        body = fn(path)
-        new = pattern.sub(lambda m: m.group(1) + body + m.group(3), new)
-    if args.check:
+    stale = []
+    for doc in DOCUMENTS:
+        doc_path = os.path.join(ROOT, doc)
+        text = open(doc_path).read()
+        new = text
+        for name, (kind, fn) in SOURCES.items():
+            rel = newest(kind)
+            path = os.path.join(ROOT, rel)
+            pattern = re.compile(rf"(<!-- BEGIN generated: {name}[^\n]*-->\n)(.*?)(\n<!-- END generated: {name} -->)", re.S)
+            if not pattern.search(new):
+                continue
+            if not os.path.exists(path):
+                print(f"{rel} is missing: block {name} of {doc} left alone", file=sys.stderr)
+                continue
+            body = fn(path)
+            new = pattern.sub(lambda m: re.sub(r"\([^()]*\) -->", f"({rel}) -->", m.group(1)) + body + m.group(3), new)
         if new != text:
-            print("DESIGN.md is out of date: run python tools/design_tables.py", file=sys.stderr)
-            raise SystemExit(1)
-        return
-    if new != text:
-        open(DESIGN, "w").write(new)
-        print("DESIGN.md updated")
-    else:
-        print("DESIGN.md already up to date")
+            stale.append(doc)
+            if not args.check:
+                open(doc_path, "w").write(new)
+                print(f"{doc} updated")
+    if args.check and stale:
+        print(f"{', '.join(stale)} out of date: run python tools/design_tables.py", file=sys.stderr)
+        raise SystemExit(1)
+    if not stale:
+        print("documents already up to date")
 
 
 if __name__ == "__main__":
