@@ -55,7 +55,7 @@ extern "C" int atx_device_count(void) {
     return n;
 }
 
-extern "C" int64_t atx_vector_program(const atx_level_op* prog, int32_t n_stage, int64_t n_lev, int dtype, atx_level_op* out) {
+extern "C" int64_t atx_vector_program(const atx_level_op* prog, int32_t n_stage, int64_t n_lev, int dtype, atx_level_op* out, int64_t out_entries) {
     if (!prog || n_stage < 1 || n_stage > 8 || n_lev < 1 || (dtype != ATX_F32 && dtype != ATX_F64)) {
         atx::set_error("atx_vector_program: bad arguments (n_stage=%d, n_lev=%lld, dtype=%d)", n_stage, (long long)n_lev, dtype);
         return ATX_EINVAL;
@@ -65,6 +65,11 @@ extern "C" int64_t atx_vector_program(const atx_level_op* prog, int32_t n_stage,
     const atx::LevelTables lay = atx::level_tables_layout(n_stage, n_lev, dtype);
     const int64_t n_entries = (lay.total_bytes + (int64_t)sizeof(atx_level_op) - 1) / (int64_t)sizeof(atx_level_op);
     if (!out) return n_entries;
+    if (out_entries < n_entries) {  // never write past what the caller says it allocated (0.3 had no capacity argument)
+        atx::set_error("atx_vector_program: out holds %lld entries, the table needs %lld (size it with the out == NULL query)",
+                       (long long)out_entries, (long long)n_entries);
+        return ATX_EWORKSPACE;
+    }
     // the same rule as the kernels' own table build (build_vector_ops): equality of op, use_mask and of the parameters AS
     // THE KERNEL WILL SEE THEM, i.e. after rounding to the stack's arithmetic type
     auto same_param = [dtype](double a, double b) {

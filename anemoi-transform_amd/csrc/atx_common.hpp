@@ -17,6 +17,12 @@ namespace atx {
 void set_error(const char* fmt, ...);  // defined in atx_api.hip
 int hip_status(hipError_t e, const char* what);
 
+// Internal status, never returned across the C ABI: the per-level operator tables of this call do not fit the 64 KB a workgroup
+// may stage in LDS (tall stacks with long programs: float32, ~1000 levels, 8 stages = 72 KB).  The entry points answer it themselves:
+// atx_pointwise_stack runs the stages in two halves (stages compose, so the bits are the same), the regrid entry points run the gather
+// without the program and apply it to the output in place.  (Round 3 returned ATX_ENOTIMPL for shapes round 2 had served.)
+#define ATX_SPLIT_PROGRAM 1
+
 #define ATX_REQUIRE(cond, code, ...)  \
     do {                              \
         if (!(cond)) {                \

@@ -817,7 +817,7 @@ reduce_final_kernel(const RedWorkspace* __restrict__ ws, int n, int ra, int red,
 
 template <typename T>
 __global__ void __launch_bounds__(kBlock)
-reduce_kernel(const T* __restrict__ x, int64_t n_rows, int64_t row_len, int64_t pitch, int red, double* result, RedWorkspace* ws) {
+reduce_kernel(const T* __restrict__ x, int64_t n_rows, int64_t row_len, int64_t pitch, int red, double* result, double* partials) {
     const double identity = red == ATX_RED_MIN ? INFINITY : (red == ATX_RED_MAX ? -INFINITY : 0.0);
     double acc = identity;
     // rows of `row_len` elements `pitch` apart; (row, col) advances by the grid stride without a division per element
@@ -854,8 +854,8 @@ reduce_kernel(const T* __restrict__ x, int64_t n_rows, int64_t row_len, int64_t 
     if (threadIdx.x == 0) {
         double total = partial[0];
         for (int w = 1; w < kBlock / kWave; ++w) total = red_combine(total, partial[w], red);
-        if (ws) {
-            ws->a[blockIdx.x] = total;
+        if (partials) {  // one slot per workgroup of the caller's workspace (a[] — or b[] for the MAX pass of a two-pass MINMAX)
+            partials[blockIdx.x] = total;
         } else if (red == ATX_RED_NANCOUNT) {
             if (total != 0.0) atomicAdd(result, total);
         } else {
@@ -943,6 +943,28 @@ reduce_vec_kernel(const T* __restrict__ x, int64_t n_rows, int64_t row_len, int 
         }
     }
     (void)want_max;
+}
+
+// The <= 3 elements a flat array leaves after its last whole 16-byte vector, as ONE more pair of partials in the workspace
+// (slot `slot`), so that the two-level finish serves this shape too: no atomics on `result`, which may be a pinned host cell.
+template <typename T>
+__global__ void reduce_tail_kernel(const T* __restrict__ x, int n, int red, RedWorkspace* ws, int slot) {
+    double lo = INFINITY, hi = -INFINITY, count = 0.0;
+    bool seen_nan = false;
+    for (int i = 0; i < n; ++i) {
+        const double d = (double)x[i];
+        if (d != d) {
+            seen_nan = true;
+            count += 1.0;
+        } else {
+            lo = d < lo ? d : lo;
+            hi = d > hi ? d : hi;
+        }
+    }
+    if (seen_nan) lo = hi = NAN;
+    const bool want_min = red == ATX_RED_MIN || red == ATX_RED_MINMAX;
+    ws->a[slot] = red == ATX_RED_NANCOUNT ? count : (want_min ? lo : hi);
+    ws->b[slot] = hi;
 }
 
 static unsigned grid_for(int64_t items) {
@@ -1136,7 +1158,8 @@ static int pointwise_typed(const void* x_, void* y_, int64_t n_pts, int n_lev, i
             }
             if (tight) {  // very tall stacks: round 2's chunked kernel, whose per-VECTOR table is smaller (tight pitches only)
                 const size_t lds_flat = lds + (size_t)C;
-                ATX_REQUIRE(lds_flat <= 64 * 1024, ATX_ENOTIMPL, "pointwise: program needs %zu B of LDS", lds_flat);
+                if (lds_flat > 64 * 1024 && n_stage > 1) return ATX_SPLIT_PROGRAM;  // the entry point runs the stages in two halves
+                ATX_REQUIRE(lds_flat <= 64 * 1024, ATX_ENOTIMPL, "pointwise: one stage over %d levels needs %zu B of LDS", n_lev, lds_flat);
                 if (program_has_transcendental(host_prog, n_stage, n_lev))
                     hipLaunchKernelGGL((pointwise_cols_flat_kernel<T, VEC, true>), dim3((unsigned)blocks), dim3(kBlock), lds_flat, st, x, y, n_pts,
                                        n_lev, C, prog, n_stage, mask, in_place);
@@ -1148,7 +1171,8 @@ static int pointwise_typed(const void* x_, void* y_, int64_t n_pts, int n_lev, i
             }
         }
         const size_t lds_rows = level_tables_lds_bytes<T>(n_stage, C, wide ? VEC : 1);
-        ATX_REQUIRE(lds_rows <= 64 * 1024, ATX_ENOTIMPL, "pointwise: program needs %zu B of LDS", lds_rows);
+        if (lds_rows > 64 * 1024 && n_stage > 1) return ATX_SPLIT_PROGRAM;  // the entry point runs the stages in two halves
+        ATX_REQUIRE(lds_rows <= 64 * 1024, ATX_ENOTIMPL, "pointwise: one stage over %d levels needs %zu B of LDS", n_lev, lds_rows);
         const int Cg = C < kBlock ? C : kBlock;
         const int64_t chunk = (int64_t)(kBlock / Cg) * kPwUnroll;  // rows one workgroup moves per iteration
         int64_t blocks = (n_pts + chunk - 1) / chunk;
@@ -1215,9 +1239,18 @@ extern "C" int atx_pointwise_stack(const void* x, void* y, int64_t n_pts, int64_
                 (long long)x_pitch, (long long)y_pitch, (long long)need);
     if (n_pts == 0) return ATX_OK;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (dtype == ATX_F32)
-        return pointwise_typed<float>(x, y, n_pts, (int)n_lev, x_pitch, y_pitch, layout, prog, vec_prog, host_prog, n_stage, point_mask, s);
-    return pointwise_typed<double>(x, y, n_pts, (int)n_lev, x_pitch, y_pitch, layout, prog, vec_prog, host_prog, n_stage, point_mask, s);
+    const int rc = dtype == ATX_F32
+        ? pointwise_typed<float>(x, y, n_pts, (int)n_lev, x_pitch, y_pitch, layout, prog, vec_prog, host_prog, n_stage, point_mask, s)
+        : pointwise_typed<double>(x, y, n_pts, (int)n_lev, x_pitch, y_pitch, layout, prog, vec_prog, host_prog, n_stage, point_mask, s);
+    if (rc != ATX_SPLIT_PROGRAM) return rc;
+    // The program's per-level tables exceed the LDS budget (n_stage > 1 here): stages compose, y = s_{n-1}( ... s_0(x)), so the first
+    // half goes x -> y and the second half y -> y in place — same statements in the same order, same bits.  vec_prog is laid out for the
+    // whole program and does not travel with a part of it.
+    const int32_t first = n_stage / 2;
+    const int rc_first = atx_pointwise_stack(x, y, n_pts, n_lev, x_pitch, y_pitch, dtype, layout, prog, nullptr, host_prog, first, point_mask, stream);
+    if (rc_first != ATX_OK) return rc_first;
+    return atx_pointwise_stack(y, y, n_pts, n_lev, y_pitch, y_pitch, dtype, layout, prog + (int64_t)first * n_lev, nullptr,
+                               host_prog ? host_prog + (int64_t)first * n_lev : nullptr, n_stage - first, point_mask, stream);
 }
 
 extern "C" int atx_mask_build(const void* m, int64_t m_stride, uint8_t* mask, int64_t n, int cmp, double threshold,
@@ -1286,8 +1319,8 @@ extern "C" int atx_mask_to_index(const uint8_t* mask, int64_t n, int32_t* index,
 
 static int reduce_rows(const void* x, int64_t n_rows, int64_t row_len, int64_t pitch, int red, double* result, int dtype,
                        void* workspace, size_t workspace_bytes, void* stream, const char* who) {
-    ATX_REQUIRE(x && result, ATX_EINVAL, "%s: null pointer", who);
     ATX_REQUIRE(n_rows >= 0 && row_len >= 0, ATX_EINVAL, "%s: negative size", who);
+    ATX_REQUIRE(result && (x || n_rows == 0 || row_len == 0), ATX_EINVAL, "%s: null pointer", who);  // (an empty array may have no storage)
     ATX_REQUIRE(pitch >= row_len, ATX_ESHAPE, "%s: pitch %lld shorter than a row of %lld", who, (long long)pitch, (long long)row_len);
     ATX_REQUIRE(red >= ATX_RED_MIN && red <= ATX_RED_MINMAX, ATX_EINVAL, "%s: bad reduction %d", who, red);
     ATX_REQUIRE(dtype == ATX_F32 || dtype == ATX_F64, ATX_EINVAL, "%s: bad dtype %d", who, dtype);
@@ -1304,57 +1337,76 @@ static int reduce_rows(const void* x, int64_t n_rows, int64_t row_len, int64_t p
     const int64_t vec_len = row_len - tail;
     const int64_t C = (vec_len + vec - 1) / vec;
     const bool vec_ok = aligned16(x) && (n_rows == 1 || (pitch % vec == 0 && C * vec <= pitch)) && C <= 0x7fffffff;
-    // the two-level finish (no init launch, no atomics, plain store of the result) serves the single-pass case; everything else —
-    // empty input, a tail after the last whole vector, the scalar fallback's two MINMAX passes — combines through atomics on `result`
+    // With a workspace EVERY shape finishes in two levels — partials with plain stores, one combining workgroup, a plain store of the
+    // result, which may therefore be a pinned host cell: the single-pass case, a flat array's tail after its last whole vector (one
+    // more slot), the scalar fallback's two MINMAX passes (MIN into a[], MAX into b[]) and empty input (the identities).  Without
+    // one the workgroups combine through atomics on `result`, which must then be device memory (round 3 dropped the workspace for
+    // every shape but the first and ran up to 8192 CAS loops over PCIe on the caller's pinned cell — the advisor's finding).
     RedWorkspace* ws = static_cast<RedWorkspace*>(workspace);
-    const bool single = n_rows > 0 && row_len > 0 && ((vec_ok && tail == 0 && C > 0) || (!vec_ok && red != ATX_RED_MINMAX));
-    if (!(ws && single)) {
-        ws = nullptr;
+    const int ra = red == ATX_RED_NANCOUNT ? ATX_RED_NANCOUNT : ((red == ATX_RED_MIN || red == ATX_RED_MINMAX) ? ATX_RED_MIN : ATX_RED_MAX);
+    if (!ws) {
         hipLaunchKernelGGL(reduce_init_kernel, dim3(1), dim3(1), 0, s, result, red);
         ATX_LAUNCH_CHECK("reduce_init");
     }
-    if (n_rows == 0 || row_len == 0) return ATX_OK;
+    if (n_rows == 0 || row_len == 0) {
+        if (ws) {  // nothing to combine: the identities (min +inf, max -inf, count 0), as reduce_init writes them
+            hipLaunchKernelGGL(reduce_final_kernel, dim3(1), dim3(kBlock), 0, s, ws, 0, ra, red, result);
+            ATX_LAUNCH_CHECK("reduce_final");
+        }
+        return ATX_OK;
+    }
+    const int64_t grid_cap = kRedGrid - (tail > 0 ? 1 : 0);  // a tail takes one slot of the workspace
     if (vec_ok) {
+        unsigned grid = 0;
         if (C > 0) {
             int64_t blocks = (n_rows * C + (int64_t)kBlock * kRedUnroll - 1) / ((int64_t)kBlock * kRedUnroll);
-            const unsigned grid = (unsigned)(blocks > kRedGrid ? kRedGrid : (blocks < 1 ? 1 : blocks));
+            grid = (unsigned)(blocks > grid_cap ? grid_cap : (blocks < 1 ? 1 : blocks));
             if (dtype == ATX_F32)
                 hipLaunchKernelGGL((reduce_vec_kernel<float, 4>), dim3(grid), dim3(kBlock), 0, s, static_cast<const float*>(x), n_rows, vec_len, (int)C, pitch, red, result, ws);
             else
                 hipLaunchKernelGGL((reduce_vec_kernel<double, 2>), dim3(grid), dim3(kBlock), 0, s, static_cast<const double*>(x), n_rows, vec_len, (int)C, pitch, red, result, ws);
             ATX_LAUNCH_CHECK("reduce_vec");
-            if (ws) {
-                const int ra = red == ATX_RED_NANCOUNT ? ATX_RED_NANCOUNT : ((red == ATX_RED_MIN || red == ATX_RED_MINMAX) ? ATX_RED_MIN : ATX_RED_MAX);
-                hipLaunchKernelGGL(reduce_final_kernel, dim3(1), dim3(kBlock), 0, s, ws, (int)grid, ra, red, result);
-                ATX_LAUNCH_CHECK("reduce_final");
-            }
         }
-        if (tail > 0) {  // combines into the same result cells (atomics): MINMAX as min -> result[0], max -> result[1]
+        if (tail > 0) {
             const size_t esz = dtype == ATX_F32 ? 4 : 8;
             const void* xt = static_cast<const char*>(x) + (size_t)vec_len * esz;
-            for (int pass = 0; pass < (red == ATX_RED_MINMAX ? 2 : 1); ++pass) {
-                const int r = red == ATX_RED_MINMAX ? (pass == 0 ? ATX_RED_MIN : ATX_RED_MAX) : red;
+            if (ws) {
                 if (dtype == ATX_F32)
-                    hipLaunchKernelGGL(reduce_kernel<float>, dim3(1), dim3(kBlock), 0, s, static_cast<const float*>(xt), (int64_t)1, tail, tail, r, result + pass, (RedWorkspace*)nullptr);
+                    hipLaunchKernelGGL(reduce_tail_kernel<float>, dim3(1), dim3(1), 0, s, static_cast<const float*>(xt), (int)tail, red, ws, (int)grid);
                 else
-                    hipLaunchKernelGGL(reduce_kernel<double>, dim3(1), dim3(kBlock), 0, s, static_cast<const double*>(xt), (int64_t)1, tail, tail, r, result + pass, (RedWorkspace*)nullptr);
+                    hipLaunchKernelGGL(reduce_tail_kernel<double>, dim3(1), dim3(1), 0, s, static_cast<const double*>(xt), (int)tail, red, ws, (int)grid);
+                grid += 1;
+            } else {  // combines into the same result cells (atomics): MINMAX as min -> result[0], max -> result[1]
+                for (int pass = 0; pass < (red == ATX_RED_MINMAX ? 2 : 1); ++pass) {
+                    const int r = red == ATX_RED_MINMAX ? (pass == 0 ? ATX_RED_MIN : ATX_RED_MAX) : red;
+                    if (dtype == ATX_F32)
+                        hipLaunchKernelGGL(reduce_kernel<float>, dim3(1), dim3(kBlock), 0, s, static_cast<const float*>(xt), (int64_t)1, tail, tail, r, result + pass, (double*)nullptr);
+                    else
+                        hipLaunchKernelGGL(reduce_kernel<double>, dim3(1), dim3(kBlock), 0, s, static_cast<const double*>(xt), (int64_t)1, tail, tail, r, result + pass, (double*)nullptr);
+                }
             }
             ATX_LAUNCH_CHECK("reduce_tail");
         }
+        if (ws) {
+            hipLaunchKernelGGL(reduce_final_kernel, dim3(1), dim3(kBlock), 0, s, ws, (int)grid, ra, red, result);
+            ATX_LAUNCH_CHECK("reduce_final");
+        }
         return ATX_OK;
     }
+    // scalar form (unaligned base or pitch): one pass, or MIN then MAX for MINMAX
     int64_t blocks = (n_rows * row_len + (int64_t)kBlock * kRedUnroll - 1) / ((int64_t)kBlock * kRedUnroll);
     const unsigned grid = (unsigned)(blocks > kRedGrid ? kRedGrid : (blocks < 1 ? 1 : blocks));
     for (int pass = 0; pass < (red == ATX_RED_MINMAX ? 2 : 1); ++pass) {
         const int r = red == ATX_RED_MINMAX ? (pass == 0 ? ATX_RED_MIN : ATX_RED_MAX) : red;
+        double* partials = ws ? (pass == 0 ? ws->a : ws->b) : nullptr;
         if (dtype == ATX_F32)
-            hipLaunchKernelGGL(reduce_kernel<float>, dim3(grid), dim3(kBlock), 0, s, static_cast<const float*>(x), n_rows, row_len, pitch, r, result + pass, ws);
+            hipLaunchKernelGGL(reduce_kernel<float>, dim3(grid), dim3(kBlock), 0, s, static_cast<const float*>(x), n_rows, row_len, pitch, r, result + pass, partials);
         else
-            hipLaunchKernelGGL(reduce_kernel<double>, dim3(grid), dim3(kBlock), 0, s, static_cast<const double*>(x), n_rows, row_len, pitch, r, result + pass, ws);
+            hipLaunchKernelGGL(reduce_kernel<double>, dim3(grid), dim3(kBlock), 0, s, static_cast<const double*>(x), n_rows, row_len, pitch, r, result + pass, partials);
     }
     ATX_LAUNCH_CHECK("reduce");
-    if (ws) {  // (single pass: MINMAX never comes here with a workspace)
-        hipLaunchKernelGGL(reduce_final_kernel, dim3(1), dim3(kBlock), 0, s, ws, (int)grid, red, red, result);
+    if (ws) {
+        hipLaunchKernelGGL(reduce_final_kernel, dim3(1), dim3(kBlock), 0, s, ws, (int)grid, ra, red, result);
         ATX_LAUNCH_CHECK("reduce_final");
     }
     return ATX_OK;

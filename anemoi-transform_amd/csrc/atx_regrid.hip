@@ -793,6 +793,7 @@ static int launch_cols_ell(const EllBatch& batch, const int32_t* idx, const T* w
     size_t lds = (size_t)tile * k * (sizeof(int32_t) + (WEIGHTED ? sizeof(T) : 0));
     lds = (lds + 15) & ~size_t(15);
     if (prog) lds += level_tables_lds_bytes<T>(n_stage, C, VEC);
+    if (prog && lds > 64 * 1024) return ATX_SPLIT_PROGRAM;  // the caller gathers without the program and applies it afterwards
     ATX_REQUIRE(lds <= 64 * 1024, ATX_ENOTIMPL, "regrid_ell: tile needs %zu B of LDS (k=%d, n_lev=%d, stages=%d)", lds, k, n_lev, n_stage);
     constexpr int KT = K > 4 ? 0 : K;  // the tiled kernel keeps k > 4 on its runtime-k loop (compile-time k would hold 4 x k vectors per lane)
     if (prog) {
@@ -943,6 +944,7 @@ static int launch_cols_csr(const T* src, T* out, const int32_t* indptr, const in
     size_t lds = (size_t)cap * (sizeof(T) + sizeof(int32_t)) + (size_t)(tile + 1) * sizeof(int32_t);
     lds = (lds + 15) & ~size_t(15);
     if (prog) lds += level_tables_lds_bytes<T>(n_stage, C, VEC);
+    if (prog && lds > 64 * 1024) return ATX_SPLIT_PROGRAM;  // the caller gathers without the program and applies it afterwards
     ATX_REQUIRE(lds <= 64 * 1024, ATX_ENOTIMPL, "regrid_csr: tile needs %zu B of LDS", lds);
     // long rows in natural order: stripes of tiles per XCD (atx_common.hpp: xcd_stripe) — their cost may drift along the rows
 #ifndef ATX_CSR_STRIPE
@@ -1076,9 +1078,19 @@ static int regrid_ell_common(const char* fn, const void* const* srcs, void* cons
             batch.src[i] = i < batch.n ? srcs[first + i] : nullptr;
             batch.out[i] = i < batch.n ? outs[first + i] : nullptr;
         }
-        const int rc = dtype == ATX_F32
+        int rc = dtype == ATX_F32
             ? regrid_ell_typed<float>(batch, idx, w, n_tgt, k, (int)n_lev, src_pitch, out_pitch, layout, pad, epi, s)
             : regrid_ell_typed<double>(batch, idx, w, n_tgt, k, (int)n_lev, src_pitch, out_pitch, layout, pad, epi, s);
+        if (rc == ATX_SPLIT_PROGRAM) {  // the fused tables do not fit in LDS: the plain gather, then the program on its output in place
+            Epilogue plain;
+            plain.tgt_rows = tgt_rows;
+            rc = dtype == ATX_F32
+                ? regrid_ell_typed<float>(batch, idx, w, n_tgt, k, (int)n_lev, src_pitch, out_pitch, layout, pad, plain, s)
+                : regrid_ell_typed<double>(batch, idx, w, n_tgt, k, (int)n_lev, src_pitch, out_pitch, layout, pad, plain, s);
+            for (int i = 0; i < batch.n && rc == ATX_OK; ++i)
+                rc = atx_pointwise_stack(batch.out[i], batch.out[i], n_tgt, n_lev, out_pitch, out_pitch, dtype, layout, prog, vec_prog, host_prog,
+                                         n_stage, tgt_mask, stream);
+        }
         if (rc != ATX_OK) return rc;
     }
     return ATX_OK;
@@ -1124,9 +1136,18 @@ static int regrid_csr_common(const char* fn, const void* src, void* out, const i
                 "%s: prog/n_stage mismatch (n_stage=%d)", fn, n_stage);
     if (n_tgt == 0) return ATX_OK;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (dtype == ATX_F32)
-        return regrid_csr_typed<float>(src, out, indptr, indices, data, n_tgt, nnz, (int)n_lev, src_pitch, out_pitch, layout, prog, n_stage, tgt_mask, tgt_rows, s);
-    return regrid_csr_typed<double>(src, out, indptr, indices, data, n_tgt, nnz, (int)n_lev, src_pitch, out_pitch, layout, prog, n_stage, tgt_mask, tgt_rows, s);
+    auto run = [&](const atx_level_op* p, int32_t stages, const uint8_t* m) {
+        if (dtype == ATX_F32)
+            return regrid_csr_typed<float>(src, out, indptr, indices, data, n_tgt, nnz, (int)n_lev, src_pitch, out_pitch, layout, p, stages, m, tgt_rows, s);
+        return regrid_csr_typed<double>(src, out, indptr, indices, data, n_tgt, nnz, (int)n_lev, src_pitch, out_pitch, layout, p, stages, m, tgt_rows, s);
+    };
+    int rc = run(prog, n_stage, tgt_mask);
+    if (rc == ATX_SPLIT_PROGRAM) {  // the fused tables do not fit in LDS: the plain product, then the program on its output in place
+        rc = run(nullptr, 0, nullptr);
+        if (rc == ATX_OK)
+            rc = atx_pointwise_stack(out, out, n_tgt, n_lev, out_pitch, out_pitch, dtype, layout, prog, nullptr, nullptr, n_stage, tgt_mask, stream);
+    }
+    return rc;
 }
 
 extern "C" int atx_regrid_csr(const void* src, void* out, const int32_t* indptr, const int32_t* indices,

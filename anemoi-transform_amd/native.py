@@ -12,6 +12,7 @@ from __future__ import annotations
 
 import ctypes
 import os
+import threading
 from ctypes import POINTER, c_char_p, c_double, c_int, c_int32, c_int64, c_size_t, c_void_p
 from typing import Any
 
@@ -100,7 +101,7 @@ SIGNATURES: dict[str, tuple[Any, list[Any]]] = {
     "atx_knn_query": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int32, c_void_p, c_void_p, c_void_p]),
     "atx_cutout_inside": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int32, c_void_p, c_void_p]),
     "atx_stream_copy": (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),
-    "atx_vector_program": (c_int64, [c_void_p, c_int32, c_int64, c_int, c_void_p]),
+    "atx_vector_program": (c_int64, [c_void_p, c_int32, c_int64, c_int, c_void_p, c_int64]),
     "atx_reduce_workspace": (c_size_t, []),
     "atx_reduce": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_int, c_void_p, c_size_t, c_void_p]),
     "atx_relayout": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int64, c_int, c_int, c_int, c_void_p]),
@@ -360,9 +361,9 @@ def _build_level_program(stages, device) -> torch.Tensor:
     if raw.is_cuda:
         lib = load()
         for tdtype, code in ((torch.float32, F32), (torch.float64, F64)):
-            n_entries = lib.atx_vector_program(host.ctypes.data, n_stage, n_lev, code, None)
+            n_entries = lib.atx_vector_program(host.ctypes.data, n_stage, n_lev, code, None, 0)
             table = np.zeros(n_entries, dtype=LEVEL_OP_DTYPE)
-            got = lib.atx_vector_program(host.ctypes.data, n_stage, n_lev, code, table.ctypes.data)
+            got = lib.atx_vector_program(host.ctypes.data, n_stage, n_lev, code, table.ctypes.data, n_entries)
             if got != n_entries:
                 raise AtxError(f"atx_vector_program: {lib.atx_last_error().decode()}")
             raw.vec_prog[tdtype] = torch.from_numpy(table.view(np.uint8).copy()).to(device)
@@ -452,7 +453,7 @@ class _Scratch:
     cells the kernels write their result into directly (pinned memory is device-visible at the same address), the zeroed
     workspace of the ticketed reduction, the event the host waits on and a growing scratch buffer.  Such a call is then its
     launch(es) and ONE event wait — no allocation, no fill, no initialisation launch, no copy back, no blocking ``.item()``
-    (``reduce`` of one 26 MB field: 45 us -> see tools/small_case_bench.py).  One host thread per stream."""
+    (``reduce`` of one 26 MB field: 45 us -> see tools/small_case_bench.py).  Slots are per (device, stream, host thread)."""
 
     _slots: dict = {}
 
@@ -466,7 +467,8 @@ class _Scratch:
 
     @classmethod
     def of(cls, device) -> "_Scratch":
-        key = (device.index if device.index is not None else torch.cuda.current_device(), _stream())
+        # per host thread as well: a producer thread (prefetch) and the consumer may enqueue on the same stream
+        key = (device.index if device.index is not None else torch.cuda.current_device(), _stream(), threading.get_ident())
         slot = cls._slots.get(key)
         if slot is None:
             if len(cls._slots) >= 64:  # streams come and go

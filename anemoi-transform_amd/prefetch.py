@@ -41,6 +41,29 @@ def to_device(fields: Iterable[Any]) -> FieldList:
 _DONE = object()
 
 
+class _Uploaded:
+    """A FieldList whose stacks were filled on the producer's stream, and the event that says when."""
+
+    def __init__(self, fields: FieldList, done) -> None:
+        self.fields, self.done = fields, done
+
+    def hand_over(self) -> FieldList:
+        """Called on the consumer's thread: its current stream waits (on the device) for the upload, and the caching allocator learns
+        that the stacks — allocated on the producer's stream — are now used on this one."""
+        if self.done is not None:
+            import torch
+
+            current = torch.cuda.current_stream()
+            current.wait_event(self.done)
+            seen = set()
+            for field in self.fields:
+                ref = field.stack_ref() if hasattr(field, "stack_ref") else None
+                if ref is not None and id(ref[0]) not in seen and ref[0].data.is_cuda:
+                    seen.add(id(ref[0]))
+                    ref[0].data.record_stream(current)
+        return self.fields
+
+
 def prefetch_to_device(fieldlists: Iterable[Iterable[Any]], depth: int = 1) -> Iterator[FieldList]:
     """Yield ``to_device(fl)`` for every ``fl`` of ``fieldlists``, in order, with up to ``depth`` uploads running ahead of the
     consumer on a background thread.  An exception raised while reading or uploading an item is re-raised at the point where that
@@ -51,19 +74,31 @@ def prefetch_to_device(fieldlists: Iterable[Iterable[Any]], depth: int = 1) -> I
     stop = threading.Event()
 
     def producer() -> None:
+        import contextlib
+
         import torch
 
+        side = None
         if torch.cuda.is_available():
             from . import stack as _stack
 
             dev = _stack.device()
             if dev.type == "cuda":
                 torch.cuda.set_device(dev)
+                # the producer's OWN stream: its uploads (and the layout kernel behind them) neither queue behind the consumer's
+                # launches on the default stream nor put wait markers into it — the consumer gets an event to wait on instead
+                side = torch.cuda.Stream(dev)
         try:
             for fl in fieldlists:
                 if stop.is_set():
                     return
-                item = to_device(fl)
+                with (torch.cuda.stream(side) if side is not None else contextlib.nullcontext()):
+                    item = to_device(fl)
+                    done = None
+                    if side is not None:
+                        done = torch.cuda.Event()
+                        done.record(side)
+                item = _Uploaded(item, done)
                 while not stop.is_set():
                     try:
                         ready.put(item, timeout=0.1)
@@ -84,7 +119,7 @@ def prefetch_to_device(fieldlists: Iterable[Iterable[Any]], depth: int = 1) -> I
                 return
             if isinstance(item, BaseException):
                 raise item
-            yield item
+            yield item.hand_over()
     finally:
         stop.set()
         while True:  # unblock a producer waiting on a full queue

@@ -18,6 +18,7 @@ demand by the ``atx_relayout`` kernel.
 from __future__ import annotations
 
 import os
+import threading
 
 import numpy as np
 import torch
@@ -52,7 +53,7 @@ _PINNED_MIN_BYTES = 8 << 20    # below this a plain copy is as fast
 _STAGE_BYTES = 256 << 20       # size of one pinned staging chunk (two are in flight)
 _COPY_THREADS = max(1, min(8, (os.cpu_count() or 2) // 2))
 _copy_pool = None
-_copy_streams: dict[int, torch.cuda.Stream] = {}
+_copy_streams: dict[tuple, torch.cuda.Stream] = {}  # per (device, host thread): a prefetch thread and the consumer do not share one
 
 
 def copy_pool():
@@ -77,9 +78,12 @@ def _upload_rows(rows: list[np.ndarray], dst: torch.Tensor) -> None:
         dst.copy_(torch.from_numpy(host))
         return
     pool = copy_pool()
-    stream = _copy_streams.get(dst.device.index)
+    key = (dst.device.index, threading.get_ident())
+    stream = _copy_streams.get(key)
     if stream is None:
-        stream = _copy_streams[dst.device.index] = torch.cuda.Stream(dst.device)
+        if len(_copy_streams) >= 16:  # threads come and go
+            _copy_streams.clear()
+        stream = _copy_streams[key] = torch.cuda.Stream(dst.device)
     per_chunk = max(1, min(n_lev, _STAGE_BYTES // row_bytes))
     stages = [torch.empty((per_chunk, n_pts), dtype=dst.dtype, pin_memory=True) for _ in range(2 if n_lev > per_chunk else 1)]
     in_flight: list[torch.cuda.Event | None] = [None] * len(stages)

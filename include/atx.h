@@ -44,9 +44,11 @@
 extern "C" {
 #endif
 
-#define ATX_VERSION 300 /* 0.3.0 — round 3: atx_reduce* take a workspace, atx_regrid_*_ordered, two more multi-input operators, and the
-                           * table written by atx_vector_program grew a typed per-level part (size it with the out == NULL query; a table
-                           * built by a 0.2 library is too short for 0.3 kernels) */
+#define ATX_VERSION 400 /* 0.4.0 — round 4: atx_vector_program takes the CAPACITY of `out` (ATX_EWORKSPACE when too small — 0.3 wrote its
+                           * grown table without asking), atx_reduce* keep the no-atomics route for every shape when given a workspace.
+                           * 0.3.0 — round 3: atx_reduce* take a workspace, atx_regrid_*_ordered, two more multi-input operators, and the
+                           * table written by atx_vector_program grew a typed per-level part (a table built by a 0.2 library is too short for
+                           * 0.3+ kernels: check atx_version() >= 300 before passing one as vec_prog) */
 
 /* ---- status codes --------------------------------------------------------- */
 enum {
@@ -235,12 +237,13 @@ int atx_pointwise_stack(const void* x, void* y, int64_t n_pts, int64_t n_lev,
  *     op | use_mask << 7; the padding of the last vector repeats the last level) — so that a lane reads the parameters of its
  *     vector's levels with two 16-byte loads: programs with a different scale per level (packed surface stacks, normalisation
  *     per level) then cost the fused regrid epilogue nothing extra (O1280 -> 0.25 deg, 137 levels: 0.44 ms with or without).
- * Returns the size of the whole table in atx_level_op entries (out == NULL: only that — always size `out` by this query),
- * negative on error.  Uploaded to a 16-byte aligned device buffer and passed as `vec_prog` (of the stack's dtype) it lets
+ * Returns the size of the whole table in atx_level_op entries (out == NULL: only that — always size `out` by this query);
+ * out_entries is the capacity of `out` in entries: ATX_EWORKSPACE, and nothing written, when it is smaller than the table.
+ * Negative on error.  Uploaded to a 16-byte aligned device buffer and passed as `vec_prog` (of the stack's dtype) it lets
  * atx_regrid_ell fuse multiply-add programs on its fastest kernel and atx_pointwise_stack run without any per-workgroup set-up;
  * vec_prog == NULL is always valid (the kernels then derive what they need themselves). */
 #define ATX_OP_MIXED (-1)
-int64_t atx_vector_program(const atx_level_op* prog, int32_t n_stage, int64_t n_lev, int dtype, atx_level_op* out);
+int64_t atx_vector_program(const atx_level_op* prog, int32_t n_stage, int64_t n_lev, int dtype, atx_level_op* out, int64_t out_entries);
 
 /* ---- multi-input per-point transforms ------------------------------------------ */
 /* Operators of the reference's MatchingFieldsFilter family (R: filters/fields/matching.py:90-311):
@@ -304,7 +307,9 @@ typedef enum { ATX_RED_MIN = 0, ATX_RED_MAX = 1, ATX_RED_NANCOUNT = 2, ATX_RED_M
  * workspace (optional, NULL = none): device scratch of atx_reduce_workspace() bytes, 8-byte aligned, usable by one call at a time
  * per stream (no initialisation needed).  With it the workgroups store partials and a second one-workgroup launch combines them: no
  * per-workgroup atomics on `result`, no initialisation launch, and `result` may be a pinned HOST cell the caller reads after
- * synchronising the stream (no copy back).  Without it the workgroups combine through atomics on `result` (device memory). */
+ * synchronising the stream (no copy back) — for EVERY shape: lengths that are not a multiple of the 16-byte vector, unaligned
+ * bases (two scalar passes for MINMAX) and empty input (the identities: +inf, -inf, 0).  Without a workspace the workgroups
+ * combine through atomics on `result`, which must then be DEVICE memory. */
 size_t atx_reduce_workspace(void);
 int atx_reduce(const void* x, int64_t n, int red, double* result, int dtype, void* workspace, size_t workspace_bytes, void* stream);
 /* the same over the n_pts x n_lev elements of a (pitched) stack, padding excluded */

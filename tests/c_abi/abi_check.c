@@ -21,9 +21,10 @@ int main(void) {
         atx_level_op prog[2] = {{ATX_OP_AFFINE, 0, 2.0, 1.0}, {ATX_OP_COPY, 0, 0.0, 0.0}};
         atx_level_op out[8];
         /* 1 per-vector entry (24 B) padded to 32 B, then 4 levels x (2 floats + 1 code byte) = 36 B: 68 B = 3 entries */
-        const long long n = atx_vector_program(prog, 1, 2, ATX_F32, NULL);
+        const long long n = atx_vector_program(prog, 1, 2, ATX_F32, NULL, 0);
         if (n != 3) ++failures;
-        if (atx_vector_program(prog, 1, 2, ATX_F32, out) != n || out[0].op != ATX_OP_MIXED) ++failures;
+        if (atx_vector_program(prog, 1, 2, ATX_F32, out, n - 1) != ATX_EWORKSPACE) ++failures; /* capacity is checked */
+        if (atx_vector_program(prog, 1, 2, ATX_F32, out, n) != n || out[0].op != ATX_OP_MIXED) ++failures;
         if (((const float*)((const char*)out + 32))[0] != 2.0f || ((const unsigned char*)out + 64)[0] != ATX_OP_AFFINE) ++failures;
     }
     if (atx_mask_to_index_workspace(1000) == 0) ++failures;

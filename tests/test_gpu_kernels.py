@@ -392,15 +392,27 @@ def test_reduce_routes_with_and_without_a_workspace(dev, monkeypatch, workspace)
     monkeypatch.setattr(native, "_REDUCE_TICKET", workspace)
     rng = np.random.default_rng(18)
     for np_dtype in (np.float64, np.float32):
-        for n in (4, 4096, 1_000_000, 5_000_001):  # the last one has a tail: falls back to the atomics route inside the library
+        # empty input: the identities, through the workspace's finish as through reduce_init (np.min of nothing raises; the library
+        # answers +inf / -inf / 0 so that callers can combine ranges)
+        empty = torch.empty(0, dtype=torch.float64 if np_dtype == np.float64 else torch.float32, device=dev)
+        assert native.reduce(empty, native.RED_MINMAX) == (float("inf"), float("-inf"))
+        assert native.reduce(empty, native.RED_MIN) == float("inf") and native.reduce(empty, native.RED_MAX) == float("-inf")
+        assert native.reduce(empty, native.RED_NANCOUNT) == 0.0
+        # 3: nothing but a tail; 5_000_001: whole vectors and a tail (round 3 sent tails through atomics on the caller's pinned cell;
+        # with a workspace they are one more partial now); an unaligned base takes the scalar kernels, MINMAX in two passes
+        for n in (3, 4, 4096, 1_000_000, 5_000_001):
             x = make_fields(rng, 1, n, np_dtype)[0]
             xd = to_dev(x, dev)
             for _ in range(3):  # the workspace is reused call after call
                 assert native.reduce(xd, native.RED_MINMAX) == (float(x.min()), float(x.max()))
             assert native.reduce(xd, native.RED_MIN) == float(x.min()) and native.reduce(xd, native.RED_NANCOUNT) == 0.0
+            shifted = to_dev(np.concatenate([[np_dtype(1e9)], x]), dev)[1:]  # base off the 16-byte boundary; the 1e9 in front must not be seen
+            assert native.reduce(shifted, native.RED_MINMAX) == (float(x.min()), float(x.max()))
             x[n // 2] = np.nan
             xd = to_dev(x, dev)
             assert all(np.isnan(v) for v in native.reduce(xd, native.RED_MINMAX)) and native.reduce(xd, native.RED_NANCOUNT) == 1.0
+            x[n // 2], x[-1] = 0.0, np.nan  # the NaN in the tail
+            assert native.reduce(to_dev(x, dev), native.RED_NANCOUNT) == 1.0 and np.isnan(native.reduce(to_dev(x, dev), native.RED_MAX))
         z = make_fields(rng, 37, 20011, np_dtype)
         st = Stack.from_fields(z, dev=dev)
         kw = dict(n_pts=st.n_pts, n_lev=st.n_lev, pitch=st.pitch, layout=COLUMNS)
@@ -857,3 +869,66 @@ def test_gather_into_a_kept_stack_and_bound_launch(dev, tdtype, np_dtype, layout
         launch2()
     side.synchronize()
     assert torch.equal(kept2.data, kept.data)
+
+
+@pytest.mark.parametrize("tdtype,np_dtype", DTYPES)
+def test_tall_stacks_with_long_programs_are_served(dev, tdtype, np_dtype):
+    """1000 levels x 8 stages of per-level operators: the per-level tables (72 KB in float32, 136 KB in float64) exceed what a
+    workgroup may stage in LDS.  Round 3 answered ATX_ENOTIMPL; the entry points now run the stages in halves (per-point programs)
+    or gather first and apply the program to the output in place (fused regrid epilogue) — the same statements in the same order,
+    so the oracle's bits."""
+    import native_double
+
+    rng = np.random.default_rng(33)
+    n_lev, n_stage, n_src, n_tgt, k = 1000, 8, 900, 400, 4
+    x = make_fields(rng, n_lev, n_src, np_dtype)
+    ops = (native.OP_AFFINE, native.OP_MUL, native.OP_CLIP, native.OP_COPY, native.OP_AFFINE_INV)
+    stages = []
+    for s in range(n_stage):
+        stage = []
+        for l in range(n_lev):
+            op = ops[int(rng.integers(len(ops)))]
+            p0, p1 = (float(rng.uniform(200, 280)), float(rng.uniform(281, 360))) if op == native.OP_CLIP else (float(rng.uniform(0.9, 1.1)), float(rng.uniform(-3, 3)))
+            stage.append((op, int(rng.random() < 0.2), p0, p1))
+        stages.append(stage)
+    table = native.LEVEL_OP_DTYPE
+
+    def oracle_program(fields, mask):
+        want = np.array(fields, copy=True)
+        for stage in stages:
+            for l, (op, use_mask, p0, p1) in enumerate(stage):
+                entry = np.zeros((), dtype=table)
+                entry["op"], entry["use_mask"], entry["p0"], entry["p1"] = op, use_mask, p0, p1
+                want[l] = native_double._apply_op(entry, want[l], mask if use_mask else None)
+        return want
+
+    prog = native.level_program(stages, dev)
+    # per-point program, out of place and in place, column and field-major stacks
+    pmask = rng.random(n_src) < 0.3
+    pmask_d = to_dev(np.concatenate([pmask, np.zeros(8, bool)]).astype(np.uint8), dev)
+    want = oracle_program(x, pmask)
+    for layout in LAYOUTS:
+        src = Stack.from_fields(x, dev=dev, layout=layout)
+        for in_place in (False, True):
+            out = src if in_place else src.new_like()
+            native.pointwise_stack(src.data, out.data, n_pts=n_src, n_lev=n_lev, x_pitch=src.pitch, y_pitch=out.pitch, layout=layout, prog=prog,
+                                   n_stage=n_stage, point_mask=pmask_d)
+            assert np.array_equal(out.numpy(), want, equal_nan=True), (layout, in_place)
+    # fused regrid epilogue: fixed-k and general CSR
+    idx, w = random_ell(rng, n_src, n_tgt, k, np_dtype)
+    tmask = rng.random(n_tgt) < 0.3
+    tmask_d = to_dev(np.concatenate([tmask, np.zeros(8, bool)]).astype(np.uint8), dev)
+    indptr = np.arange(n_tgt + 1) * k
+    gathered = np.stack([oracle.csr_apply(w.reshape(-1), idx.reshape(-1), indptr, (n_tgt, n_src), f) for f in x])
+    want = oracle_program(gathered, tmask)
+    for layout in LAYOUTS:
+        src = Stack.from_fields(x, dev=dev, layout=layout)
+        out = src.new_like(n_pts=n_tgt)
+        native.regrid_ell(src.data, out.data, to_dev(idx, dev), to_dev(w, dev), n_src=n_src, n_tgt=n_tgt, k=k, n_lev=n_lev, src_pitch=src.pitch,
+                          out_pitch=out.pitch, layout=layout, prog=prog, n_stage=n_stage, tgt_mask=tmask_d)
+        assert np.array_equal(out.numpy(), want, equal_nan=True), ("ell", layout)
+        out.data.fill_(0.0)
+        native.regrid_csr(src.data, out.data, to_dev(indptr.astype(np.int32), dev), to_dev(idx.reshape(-1), dev), to_dev(w.reshape(-1), dev),
+                          n_src=n_src, n_tgt=n_tgt, nnz=n_tgt * k, n_lev=n_lev, src_pitch=src.pitch, out_pitch=out.pitch, layout=layout,
+                          prog=prog, n_stage=n_stage, tgt_mask=tmask_d)
+        assert np.array_equal(out.numpy(), want, equal_nan=True), ("csr", layout)

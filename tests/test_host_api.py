@@ -443,7 +443,7 @@ def test_header_is_plain_c_and_links(tmp_path):
 def test_abi_argument_validation_without_a_gpu():
     """Bad arguments are rejected before anything touches HIP, with the reference's exception types."""
     lib = native.load()
-    assert lib.atx_version() == 300
+    assert lib.atx_version() == 400
     assert lib.atx_strerror(native.ESHAPE) == b"shape mismatch"
     assert lib.atx_regrid_ell(None, None, None, None, 1, 1, 1, 1, 1, 1, 0, 0, 0, None, None, None, 0, None, None) == native.EINVAL
     assert b"null" in lib.atx_last_error()
@@ -570,14 +570,14 @@ def test_vector_program_host_helper():
         host[i] = o
     for code, vec, want in ((native.F32, 4, [native.OP_AFFINE, -1, native.OP_AFFINE]),
                             (native.F64, 2, [native.OP_AFFINE, -1, -1, native.OP_MUL, native.OP_AFFINE])):
-        n = lib.atx_vector_program(host.ctypes.data, 1, len(ops), code, None)
+        n = lib.atx_vector_program(host.ctypes.data, 1, len(ops), code, None, 0)
         C = (len(ops) + vec - 1) // vec
         assert C == len(want)
         # second part, from the next 16-byte boundary: p0[Lp], p1[Lp] in the stack's type and one code byte per level
         np_t, Lp, start = (np.float32, np.float64)[code == native.F64], C * vec, (C * 24 + 15) // 16 * 16
         assert n == -(-(start + Lp * (2 * np.dtype(np_t).itemsize + 1)) // 24)
         out = np.zeros(n, dtype=native.LEVEL_OP_DTYPE)
-        assert lib.atx_vector_program(host.ctypes.data, 1, len(ops), code, out.ctypes.data) == n
+        assert lib.atx_vector_program(host.ctypes.data, 1, len(ops), code, out.ctypes.data, n) == n
         assert out["op"][:C].tolist() == want
         assert out["use_mask"][C - 1] == 1  # the last (partial) vector holds only level 8
         raw = out.view(np.uint8)
@@ -587,8 +587,13 @@ def test_vector_program_host_helper():
         codes = raw[start + 2 * Lp * np.dtype(np_t).itemsize:][:Lp]
         assert p0.tolist() == [np_t(o[2]) for o in padded] and p1.tolist() == [np_t(o[3]) for o in padded]
         assert codes.tolist() == [o[0] | (o[1] << 7) for o in padded]
-    assert lib.atx_vector_program(None, 1, 4, native.F32, None) == native.EINVAL
-    assert lib.atx_vector_program(host.ctypes.data, 9, 1, native.F32, None) == native.EINVAL
+        # the capacity of `out` is checked: one entry short is refused and NOTHING is written (0.3 had no such argument)
+        guard = np.full(n, 7, dtype=np.uint8).repeat(24).view(native.LEVEL_OP_DTYPE)
+        before = guard.tobytes()
+        assert lib.atx_vector_program(host.ctypes.data, 1, len(ops), code, guard.ctypes.data, n - 1) == native.EWORKSPACE
+        assert guard.tobytes() == before and b"needs" in lib.atx_last_error()
+    assert lib.atx_vector_program(None, 1, 4, native.F32, None, 0) == native.EINVAL
+    assert lib.atx_vector_program(host.ctypes.data, 9, 1, native.F32, None, 0) == native.EINVAL
 
 
 def test_shard_bounds_invariants_on_random_plans(monkeypatch):

@@ -74,3 +74,28 @@ def test_prefetch_passes_errors_on_and_stops_when_closed(monkeypatch):
     assert len(seen) <= 3
     with pytest.raises(ValueError):
         next(prefetch_to_device(iter(lists), depth=0))
+
+
+@pytest.mark.gpu
+def test_prefetch_on_the_device_uploads_on_its_own_stream(dev):
+    """On the MI355X the producer thread uploads under its OWN stream and hands the consumer an event: the default stream carries no
+    wait marker of the producer's, the stacks are usable as soon as the consumer's stream has waited, results equal the host-fed path."""
+    import torch
+
+    g = lookup("o96")
+    rng = np.random.default_rng(5)
+    lists = []
+    for d in range(4):  # 60 float32 fields of O96 per list: 9.7 MB, above the pinned-staging threshold
+        lists.append(fieldlist_from_dicts([{"param": "t", "levelist": l, "values": (250.0 + rng.standard_normal(len(g["latitudes"])) + d).astype(np.float32),
+                                            "latitudes": g["latitudes"], "longitudes": g["longitudes"], "valid_datetime": f"2020-01-0{d + 1}T00:00:00Z"}
+                                           for l in range(60)]))
+    regrid = create_filter_by_name("regrid", in_grid="o96", out_grid=[1.0, 1.0], method="nearest")
+    want = [[f.to_numpy(flatten=True) for f in regrid.forward(fl)] for fl in lists]
+    got, streams = [], set()
+    for dev_fl in prefetch_to_device(iter(lists), depth=2):
+        stack = dev_fl[0].stack_ref()[0]
+        assert stack.data.is_cuda and stack.dtype == torch.float32
+        streams.add(torch.cuda.current_stream().cuda_stream)
+        got.append([f.to_numpy(flatten=True) for f in regrid.forward(dev_fl)])
+    assert len(streams) == 1  # the consumer stayed on its own stream throughout
+    assert len(got) == 4 and all(np.array_equal(a, b) for x, y in zip(got, want) for a, b in zip(x, y))
