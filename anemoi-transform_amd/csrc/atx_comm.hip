@@ -14,6 +14,7 @@
 // process that already holds an RCCL (PyTorch ships one) the same copy is reused by SONAME instead of a second one
 // being mapped.
 #include "atx_common.hpp"
+#include "atx_nccl_abi.h"  // the NCCL / RCCL public C types and signatures bound below (shared with the test stand-in)
 
 #include <dlfcn.h>
 
@@ -23,25 +24,21 @@
 
 namespace atx {
 
-// The slice of the RCCL API this file uses, declared here so that no RCCL header is needed to build (the ABI of these
-// functions is NCCL's public, stable C interface).
-typedef struct ncclComm* ncclComm_t;
-typedef struct { char internal[ATX_COMM_ID_BYTES]; } ncclUniqueId;
-typedef int ncclResult_t;      // ncclSuccess == 0
-constexpr int kNcclChar = 0;   // ncclInt8 / ncclChar
+constexpr int kNcclChar = 0;  // ncclInt8 / ncclChar
+static_assert(ATX_NCCL_UNIQUE_ID_BYTES == ATX_COMM_ID_BYTES, "include/atx.h and the NCCL ABI disagree on the unique id size");
 
 struct Rccl {
     void* handle = nullptr;
-    ncclResult_t (*GetVersion)(int*) = nullptr;
-    ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
-    ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
-    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
-    const char* (*GetErrorString)(ncclResult_t) = nullptr;
-    ncclResult_t (*Broadcast)(const void*, void*, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
-    ncclResult_t (*Send)(const void*, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
-    ncclResult_t (*Recv)(void*, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
-    ncclResult_t (*GroupStart)() = nullptr;
-    ncclResult_t (*GroupEnd)() = nullptr;
+    atx_ncclGetVersion_t GetVersion = nullptr;
+    atx_ncclGetUniqueId_t GetUniqueId = nullptr;
+    atx_ncclCommInitRank_t CommInitRank = nullptr;
+    atx_ncclCommDestroy_t CommDestroy = nullptr;
+    atx_ncclGetErrorString_t GetErrorString = nullptr;
+    atx_ncclBroadcast_t Broadcast = nullptr;
+    atx_ncclSend_t Send = nullptr;
+    atx_ncclRecv_t Recv = nullptr;
+    atx_ncclGroup_t GroupStart = nullptr;
+    atx_ncclGroup_t GroupEnd = nullptr;
     char error[256] = {0};
 };
 
@@ -102,7 +99,7 @@ static int comm_status(ncclResult_t e, const char* what) {
 }  // namespace atx
 
 struct atx_comm {
-    atx::ncclComm_t comm;
+    ncclComm_t comm;
     int32_t world;
     int32_t rank;
     int device;

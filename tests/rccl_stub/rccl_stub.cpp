@@ -8,6 +8,8 @@
 // thread drains every connection into a per-source FIFO, so a send never waits for the matching receive (no deadlock whatever the
 // order inside a group).  Inside ncclGroupStart/End operations are deferred and run sends first, then receives.
 #include <hip/hip_runtime.h>
+
+#include "../../anemoi-transform_amd/csrc/atx_nccl_abi.h"  // NCCL's public C types: the stand-in is defined with the very signatures libatx calls through
 #include <sys/socket.h>
 #include <sys/stat.h>
 #include <sys/un.h>
@@ -174,23 +176,19 @@ int submit(std::vector<Op> ops) {
 
 extern "C" {
 
-int ncclGetVersion(int* v) {
+ncclResult_t ncclGetVersion(int* v) {
     *v = 29999;  // "2.99.99": recognisably not a real release
     return 0;
 }
 
-int ncclGetUniqueId(void* id) {
-    std::memset(id, 0, 128);
+ncclResult_t ncclGetUniqueId(ncclUniqueId* id) {
+    std::memset(id->internal, 0, sizeof(id->internal));
     std::random_device rd;
-    std::snprintf(static_cast<char*>(id), 128, "%08x%08x", rd(), rd());
+    std::snprintf(id->internal, sizeof(id->internal), "%08x%08x", rd(), rd());
     return 0;
 }
 
-struct UniqueId {
-    char internal[128];
-};
-
-int ncclCommInitRank(void** comm, int world, UniqueId id, int rank) {
+ncclResult_t ncclCommInitRank(ncclComm_t* comm, int world, ncclUniqueId id, int rank) {
     Comm* c = new Comm;
     c->world = world;
     c->rank = rank;
@@ -206,12 +204,12 @@ int ncclCommInitRank(void** comm, int world, UniqueId id, int rank) {
         return 2;
     }
     c->acceptor = std::thread(acceptor_loop, c);
-    *comm = c;
+    *comm = reinterpret_cast<ncclComm_t>(c);
     return 0;
 }
 
-int ncclCommDestroy(void* comm) {
-    Comm* c = static_cast<Comm*>(comm);
+ncclResult_t ncclCommDestroy(ncclComm_t comm) {
+    Comm* c = reinterpret_cast<Comm*>(comm);
     {
         std::lock_guard<std::mutex> lock(c->mu);
         c->closing = true;
@@ -227,7 +225,7 @@ int ncclCommDestroy(void* comm) {
     return 0;
 }
 
-const char* ncclGetErrorString(int e) {
+const char* ncclGetErrorString(ncclResult_t e) {
     switch (e) {
         case 0: return "success";
         case 1: return "HIP error in the stub";
@@ -238,16 +236,16 @@ const char* ncclGetErrorString(int e) {
     }
 }
 
-int ncclSend(const void* buf, size_t count, int /*dtype: bytes*/, int peer, void* comm, hipStream_t stream) {
-    return submit({Op{0, static_cast<Comm*>(comm), buf, nullptr, count, peer, stream}});
+ncclResult_t ncclSend(const void* buf, size_t count, ncclDataType_t /*bytes*/, int peer, ncclComm_t comm, hipStream_t stream) {
+    return submit({Op{0, reinterpret_cast<Comm*>(comm), buf, nullptr, count, peer, stream}});
 }
 
-int ncclRecv(void* buf, size_t count, int, int peer, void* comm, hipStream_t stream) {
-    return submit({Op{1, static_cast<Comm*>(comm), nullptr, buf, count, peer, stream}});
+ncclResult_t ncclRecv(void* buf, size_t count, ncclDataType_t, int peer, ncclComm_t comm, hipStream_t stream) {
+    return submit({Op{1, reinterpret_cast<Comm*>(comm), nullptr, buf, count, peer, stream}});
 }
 
-int ncclBroadcast(const void* send, void* recv, size_t count, int, int root, void* comm, hipStream_t stream) {
-    Comm* c = static_cast<Comm*>(comm);
+ncclResult_t ncclBroadcast(const void* send, void* recv, size_t count, ncclDataType_t, int root, ncclComm_t comm, hipStream_t stream) {
+    Comm* c = reinterpret_cast<Comm*>(comm);
     std::vector<Op> ops;
     if (c->rank == root) {
         for (int p = 0; p < c->world; ++p)
@@ -261,12 +259,12 @@ int ncclBroadcast(const void* send, void* recv, size_t count, int, int root, voi
     return submit(std::move(ops));
 }
 
-int ncclGroupStart() {
+ncclResult_t ncclGroupStart(void) {
     ++g_group_depth;
     return 0;
 }
 
-int ncclGroupEnd() {
+ncclResult_t ncclGroupEnd(void) {
     if (--g_group_depth > 0) return 0;
     std::vector<Op> ops;
     ops.swap(g_deferred);
