@@ -37,6 +37,8 @@ def sanitized():
     runtime = asan_runtime_dir()
     if not (os.path.exists(CLANG) and os.path.exists(HIPCC) and runtime):
         pytest.skip("clang / hipcc / the AddressSanitizer runtime are not installed")
+    if not os.path.exists(os.path.join(ROOT, "tools", "build_sanitized.sh")):
+        pytest.skip("the sanitizer recipe does not travel to the GPU box (.gpurunignore): this pass runs on the CPU box only")
     sources = (glob.glob(os.path.join(ROOT, "anemoi-transform_amd", "csrc", "*")) + glob.glob(os.path.join(ROOT, "include", "*.h")) +
                [os.path.join(ROOT, "tests", "rccl_stub", "rccl_stub.cpp"), os.path.join(ROOT, "tools", "build_sanitized.sh")])
     newest = max(os.path.getmtime(p) for p in sources)
