@@ -80,7 +80,7 @@ def bench_line(path: str) -> str:
 
         rows = list(csv.DictReader(open(shape_csv)))
         if rows:
-            h = rows[0]  # the shape with the most dispatches: the headline launch
+            h = max(rows, key=lambda r: float(r["calls"]) * float(r["average_ns"]))  # the shape the run spends most of its kernel time in: the headline launch
             lines.append(f"* rocprofv3 `--kernel-trace` of the same command, headline launch shape (`{h['kernel'].replace('atx::', '')}`, {h['grid_x_lanes']} lanes): "
                          f"{h['calls']} dispatches, average **{float(h['average_ns']) / 1e3:.1f} µs**, min {float(h['min_ns']) / 1e3:.1f} µs "
                          f"(`{shape_rel}`; HIP events of the run under rocprof: `{rocprof_rel}`)")

@@ -5,8 +5,8 @@ cd $R
 python3 bench.py > gpurun_out/r04_bench_default.json 2> gpurun_out/r04_bench_default.err
 echo "default bench done"
 (cd /tmp && export TMPDIR=/tmp && rm -rf $R/gpurun_out/prof_r04 && rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_r04 -- python3 $R/bench.py --steps 200 --warmup 20 --no-cpu-baseline > $R/gpurun_out/r04_bench_under_rocprof.json 2> $R/gpurun_out/r04_bench_under_rocprof.err)
-python3 tools/kernel_trace_by_shape.py $(ls gpurun_out/prof_r04/*/*_kernel_trace.csv | head -1) regrid_cols_ell_direct_kernel > gpurun_out/r04_bench_kernel_by_launch_shape.csv
-cp $(ls gpurun_out/prof_r04/*/*_kernel_stats.csv | head -1) gpurun_out/r04_bench_kernel_stats.csv
+python3 tools/kernel_trace_by_shape.py $(ls -t gpurun_out/prof_r04/*/*_kernel_trace.csv | head -1) regrid_cols_ell_direct_kernel > gpurun_out/r04_bench_kernel_by_launch_shape.csv
+cp $(ls -t gpurun_out/prof_r04/*/*_kernel_stats.csv | head -1) gpurun_out/r04_bench_kernel_stats.csv
 echo "rocprof done"
 # the N > 1 sections at world size 1 on the real collective library (the record a first real N = 8 line is read against)
 python3 bench.py --rehearse-multi > gpurun_out/r04_bench_rehearse_multi_world1.json 2> gpurun_out/r04_bench_rehearse_multi_world1.err
