@@ -48,40 +48,58 @@ __device__ __forceinline__ void tp_store_vec(T* p, const Pack<T, N>& v) {
     }
 }
 
-template <typename T, bool TO_COLUMNS>
+// (p, l) of item i = p * nl + l advanced by kBlock items without a division per element (nl is a run-time 137: the quotient and
+// remainder of every element cost more issue slots than the 4-byte load they address — round 4: columns -> fields f32 1.60 -> see
+// profiles/r04_relayout_index_math.log).  TPC is the tile's point count when it is a compile-time power of two (0: run-time TP).
+template <typename T, bool TO_COLUMNS, int TPC>
 __global__ void __launch_bounds__(kBlock)
 transpose_kernel(const T* __restrict__ src, T* __restrict__ dst, int64_t n_pts, int n_lev,
-                 int64_t src_pitch, int64_t dst_pitch, int TP, int LC, int LCpad) {
+                 int64_t src_pitch, int64_t dst_pitch, int TP_, int LC, int LCpad) {
     extern __shared__ __align__(16) unsigned char smem[];
     T* tile = reinterpret_cast<T*>(smem);
+    const int TP = TPC > 0 ? TPC : TP_;
     const int64_t p0 = (int64_t)blockIdx.x * TP;
     const int l0 = blockIdx.y * LC;
     const int np = (int)min((int64_t)TP, n_pts - p0);
     const int nl = min(LC, n_lev - l0);
     const int tid = threadIdx.x;
+    // steps of kBlock items in the (point, level) order of the columns side
+    const int dq = kBlock / nl, dr = kBlock - dq * nl;
 
     // fields side: element (p, l) at base[l*pitch + p]; columns side: base[p*pitch + l]
     if (TO_COLUMNS) {
 #pragma unroll 4
         for (int i = tid; i < nl * TP; i += kBlock) {
-            const int l = i / TP, p = i - l * TP;
+            const int l = i / TP, p = i - l * TP;  // (TPC > 0: a shift and a mask)
             if (p < np) tile[p * LCpad + l] = tp_load<TO_COLUMNS && ATX_TP_NT>(src + (int64_t)(l0 + l) * src_pitch + p0 + p);
         }
         __syncthreads();
+        int p = tid / nl, l = tid - p * nl;
         for (int i = tid; i < np * nl; i += kBlock) {
-            const int p = i / nl, l = i - p * nl;
             tp_store<TO_COLUMNS && ATX_TP_NT>(dst + (p0 + p) * dst_pitch + l0 + l, tile[p * LCpad + l]);
+            p += dq;
+            l += dr;
+            if (l >= nl) {
+                l -= nl;
+                ++p;
+            }
         }
     } else {
+        int p = tid / nl, l = tid - p * nl;
 #pragma unroll 4
         for (int i = tid; i < np * nl; i += kBlock) {
-            const int p = i / nl, l = i - p * nl;
             tile[p * LCpad + l] = tp_load<TO_COLUMNS && ATX_TP_NT>(src + (p0 + p) * src_pitch + l0 + l);
+            p += dq;
+            l += dr;
+            if (l >= nl) {
+                l -= nl;
+                ++p;
+            }
         }
         __syncthreads();
         for (int i = tid; i < nl * TP; i += kBlock) {
-            const int l = i / TP, p = i - l * TP;
-            if (p < np) tp_store<TO_COLUMNS && ATX_TP_NT>(dst + (int64_t)(l0 + l) * dst_pitch + p0 + p, tile[p * LCpad + l]);
+            const int lv = i / TP, pp = i - lv * TP;
+            if (pp < np) tp_store<TO_COLUMNS && ATX_TP_NT>(dst + (int64_t)(l0 + lv) * dst_pitch + p0 + pp, tile[pp * LCpad + lv]);
         }
     }
 }
@@ -211,10 +229,12 @@ static int relayout_typed(const void* src_, void* dst_, int64_t n_pts, int n_lev
             return ATX_OK;
         }
     }
+    constexpr int kTileBytes = ATX_TP_BYTES;
+    constexpr int TPC = (kTileBytes / (int)sizeof(T)) > 0 && ((kTileBytes / (int)sizeof(T)) & ((kTileBytes / (int)sizeof(T)) - 1)) == 0 ? kTileBytes / (int)sizeof(T) : 0;
     if (dst_layout == ATX_COLUMNS)
-        hipLaunchKernelGGL((transpose_kernel<T, true>), dim3(gx, gy), dim3(kBlock), lds, st, src, dst, n_pts, n_lev, sp, dp, TP, LC, LCpad);
+        hipLaunchKernelGGL((transpose_kernel<T, true, TPC>), dim3(gx, gy), dim3(kBlock), lds, st, src, dst, n_pts, n_lev, sp, dp, TP, LC, LCpad);
     else
-        hipLaunchKernelGGL((transpose_kernel<T, false>), dim3(gx, gy), dim3(kBlock), lds, st, src, dst, n_pts, n_lev, sp, dp, TP, LC, LCpad);
+        hipLaunchKernelGGL((transpose_kernel<T, false, TPC>), dim3(gx, gy), dim3(kBlock), lds, st, src, dst, n_pts, n_lev, sp, dp, TP, LC, LCpad);
     ATX_LAUNCH_CHECK("transpose");
     return ATX_OK;
 }
@@ -236,10 +256,86 @@ select_cols_kernel(const T* __restrict__ src, T* __restrict__ dst, LevelMap map,
     __syncthreads();
     const int64_t p0 = (int64_t)blockIdx.x * tp;
     const int np = (int)min((int64_t)tp, n_pts - p0);
+    // (point, level) advanced by kBlock items without a division per element (nj is a run-time count)
+    const int dq = kBlock / nj, dr = kBlock - dq * nj;
+    int p = threadIdx.x / nj, j = threadIdx.x - p * nj;
+#pragma unroll 4
     for (int i = threadIdx.x; i < np * nj; i += kBlock) {
-        const int p = i / nj, j = i - p * nj;
         const int32_t l = lm[j];
         if (l >= 0) dst[(p0 + p) * dst_pitch + j0 + j] = src[(p0 + p) * src_pitch + l];
+        p += dq;
+        j += dr;
+        if (j >= nj) {
+            j -= nj;
+            ++p;
+        }
+    }
+}
+
+// columns, 16-byte accesses on both sides (round 4): the levels [lo, lo + W) of the tile's columns — the range the map reads — go
+// through LDS as they lie (16-byte loads of a strided slab), every destination vector is assembled from LDS through the map and
+// stored with ONE 16-byte store.  The element-by-element kernel above issues a 4-byte load and a 4-byte store per element with a
+// map look-up in between: a full permutation of 137 levels ran at 0.47 (f32) / 0.53 (f64) of the HBM peak where a copy runs at 0.8
+// (profiles/r04_select_levels.log).  Vectors with an untouched (negative) or missing entry fall back to element stores.
+template <typename T>
+__global__ void __launch_bounds__(kBlock)
+select_cols_slab_kernel(const T* __restrict__ src, T* __restrict__ dst, LevelMap map, int j0, int nj, int64_t n_pts,
+                        int64_t src_pitch, int64_t dst_pitch, int tp, int lo, int W, int wpad) {
+    constexpr int VEC = Vec16<T>::N;
+    using V = Pack<T, VEC>;
+    extern __shared__ __align__(16) unsigned char smem[];
+    T* tile = reinterpret_cast<T*>(smem);                                  // [tp][wpad]
+    int32_t* lm = reinterpret_cast<int32_t*>(tile + (size_t)tp * wpad);    // [nj], relative to lo
+    for (int i = threadIdx.x; i < nj; i += kBlock) lm[i] = map.src_level[i] >= 0 ? map.src_level[i] - lo : -1;
+    const int64_t p0 = (int64_t)blockIdx.x * tp;
+    const int np = (int)min((int64_t)tp, n_pts - p0);
+    {   // phase 1: the slab, WV vectors per column
+        const int WV = W / VEC;
+        const int dq = kBlock / WV, dr = kBlock - dq * WV;
+        int p = threadIdx.x / WV, c = threadIdx.x - p * WV;
+#pragma unroll 4
+        for (int i = threadIdx.x; i < np * WV; i += kBlock) {
+            *reinterpret_cast<V*>(tile + (size_t)p * wpad + c * VEC) = *reinterpret_cast<const V*>(src + (p0 + p) * src_pitch + lo + c * VEC);
+            p += dq;
+            c += dr;
+            if (c >= WV) {
+                c -= WV;
+                ++p;
+            }
+        }
+    }
+    __syncthreads();
+    {   // phase 2: destination vectors
+        const int CV = (nj + VEC - 1) / VEC;
+        const int dq = kBlock / CV, dr = kBlock - dq * CV;
+        int p = threadIdx.x / CV, c = threadIdx.x - p * CV;
+        for (int i = threadIdx.x; i < np * CV; i += kBlock) {
+            V v;
+            bool whole = true;
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) {
+                const int j = c * VEC + e;
+                const int32_t l = j < nj ? lm[j] : -1;
+                whole = whole && l >= 0;
+                v.v[e] = l >= 0 ? tile[(size_t)p * wpad + l] : T(0);
+            }
+            T* d = dst + (p0 + p) * dst_pitch + j0 + c * VEC;
+            if (whole) {
+                *reinterpret_cast<V*>(d) = v;
+            } else {
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) {
+                    const int j = c * VEC + e;
+                    if (j < nj && lm[j] >= 0) d[e] = v.v[e];
+                }
+            }
+            p += dq;
+            c += dr;
+            if (c >= CV) {
+                c -= CV;
+                ++p;
+            }
+        }
     }
 }
 
@@ -252,6 +348,17 @@ select_fields_kernel(const T* __restrict__ src, T* __restrict__ dst, LevelMap ma
     if (l < 0) return;
     const T* s = src + (int64_t)l * src_pitch;
     T* d = dst + (int64_t)(j0 + blockIdx.y) * dst_pitch;
+    // a row copy: 16 bytes per lane when both rows start on a 16-byte boundary (4-byte accesses ran a float32 row at 0.62 of the HBM
+    // peak against 0.74 for float64; round 4), the <= VEC - 1 trailing points element by element
+    constexpr int VEC = Vec16<T>::N;
+    using V = Pack<T, VEC>;
+    if (((reinterpret_cast<uintptr_t>(s) | reinterpret_cast<uintptr_t>(d)) & 15u) == 0) {
+        const int64_t nv = n_pts / VEC;
+        for (int64_t v = (int64_t)blockIdx.x * kBlock + threadIdx.x; v < nv; v += (int64_t)gridDim.x * kBlock)
+            tp_store_vec<true, T, VEC>(d + v * VEC, tp_load_vec<true, T, VEC>(s + v * VEC));  // read once, written once: non-temporal
+        for (int64_t p = nv * VEC + (int64_t)blockIdx.x * kBlock + threadIdx.x; p < n_pts; p += (int64_t)gridDim.x * kBlock) d[p] = s[p];
+        return;
+    }
     for (int64_t p = (int64_t)blockIdx.x * kBlock + threadIdx.x; p < n_pts; p += (int64_t)gridDim.x * kBlock) d[p] = s[p];
 }
 
@@ -270,12 +377,49 @@ static int select_typed(const void* src_, void* dst_, const int32_t* level_map, 
         }
         if (!any) continue;
         if (layout == ATX_COLUMNS) {
+            // the slab kernel when both stacks take 16-byte accesses and the range of source levels the map reads is not much wider
+            // than the 128-byte lines the selected levels occupy anyway (a column is fetched in whole lines whatever is used of them)
+            constexpr int VEC = Vec16<T>::N;
+            int lmin = INT32_MAX, lmax = -1;
+            bool line_used[512] = {false};
+            int lines = 0;
+            for (int j = 0; j < nj; ++j) {
+                const int l = map.src_level[j];
+                if (l < 0) continue;
+                lmin = l < lmin ? l : lmin;
+                lmax = l > lmax ? l : lmax;
+                const int slot = (int)(((int64_t)l * (int64_t)sizeof(T)) / 128);
+                if (slot < 512 && !line_used[slot]) {
+                    line_used[slot] = true;
+                    ++lines;
+                }
+            }
+            const int lo = lmin / VEC * VEC;
+            const int W = (lmax + VEC) / VEC * VEC - lo;
+            const bool aligned = aligned16(src) && aligned16(dst) && sp % VEC == 0 && dp % VEC == 0 && (int64_t)lo + W <= sp && j0 % VEC == 0 &&
+                                 (int64_t)j0 + ((nj + VEC - 1) / VEC) * VEC <= dp;
+#ifndef ATX_SELECT_SLAB
+#define ATX_SELECT_SLAB 1
+#endif
+            if (ATX_SELECT_SLAB && aligned && lines > 0 && (int64_t)W * (int64_t)sizeof(T) * 10 <= (int64_t)lines * 128 * 13) {
+                const int wpad = (W % 32 == 0) ? W + VEC : W;  // rows a multiple of 128 bytes apart would put a column of the tile into one LDS bank
+                int tps = (int)((32 * 1024 - (size_t)nj * sizeof(int32_t)) / ((size_t)wpad * sizeof(T)));
+                tps = tps > 64 ? 64 : (tps < 1 ? 1 : tps);
+                const size_t lds = (size_t)tps * wpad * sizeof(T) + (size_t)nj * sizeof(int32_t);
+                if (lds <= 48 * 1024) {
+                    const unsigned gxs = (unsigned)((n_pts + tps - 1) / tps);
+                    hipLaunchKernelGGL(select_cols_slab_kernel<T>, dim3(gxs), dim3(kBlock), lds, st, src, dst, map, j0, nj, n_pts, sp, dp, tps, lo, W, wpad);
+                    ATX_LAUNCH_CHECK("select_levels_slab");
+                    continue;
+                }
+            }
             int tp = 4096 / nj;  // ~16 items per lane
             tp = tp < 1 ? 1 : tp;
             const unsigned gx = (unsigned)((n_pts + tp - 1) / tp);
             hipLaunchKernelGGL(select_cols_kernel<T>, dim3(gx), dim3(kBlock), 0, st, src, dst, map, j0, nj, n_pts, sp, dp, tp);
         } else {
-            int64_t gx = (n_pts + (int64_t)kBlock * 8 - 1) / ((int64_t)kBlock * 8);
+            const int64_t per_block = (int64_t)kBlock * 2 * Vec16<T>::N;  // two 16-byte vectors per lane: many short workgroups
+            int64_t gx = (n_pts + per_block - 1) / per_block;
             gx = gx < 1 ? 1 : (gx > kStreamGrid ? kStreamGrid : gx);
             hipLaunchKernelGGL(select_fields_kernel<T>, dim3((unsigned)gx, (unsigned)nj), dim3(kBlock), 0, st, src, dst, map, j0, n_pts, sp, dp);
         }
