@@ -300,7 +300,16 @@ def test_random_combine_cases(dev, seed):
 
     assert np.array_equal(run(native.COMB_SNOW_DEPTH_M, [sd, rsn], 1)[0], oracle.snow_depth_m(sd, rsn))
     assert np.array_equal(run(native.COMB_SUB, [t, w], 1)[0], t - w)
-    np.testing.assert_allclose(run(native.COMB_SNOW_COVER, [sd, rsn], 1)[0], oracle.snow_cover(sd, rsn), rtol=rtol, atol=1e-7)
+    # snow_cover has a JUMP in its statement — `snow_cover[snow_cover > 0.99] = 1.0` (R: snow_cover.py:38) — so wherever tanh lands within
+    # a few ulp of 0.99 the last bit of tanh decides between 0.99 and 1.0: numpy's and the device library's float32 tanh may disagree
+    # there (seed 156 of a 300-seed soak: 1 element of 520 286).  Everywhere else the tolerance is the usual one; at such a point both
+    # sides of the jump are the statement's own values.
+    got, want = run(native.COMB_SNOW_COVER, [sd, rsn], 1)[0], oracle.snow_cover(sd, rsn)
+    with np.errstate(all="ignore"):
+        before_jump = np.clip(np.tanh((4000 * ((1000 * sd) / rsn)) / np.clip(rsn, 100, 400)), 0, 1)
+    at_jump = np.abs(before_jump - np_dtype(0.99)) <= 8 * np.finfo(np_dtype).eps
+    np.testing.assert_allclose(got[~at_jump], want[~at_jump], rtol=rtol, atol=1e-7)
+    assert np.all((got[at_jump] == 1.0) | (np.abs(got[at_jump] - before_jump[at_jump]) <= 8 * np.finfo(np_dtype).eps)) and at_jump.sum() <= max(3, 1e-4 * at_jump.size)
     deg = bool(rng.random() < 0.5)
     x = np.rad2deg(ang).astype(np_dtype) if deg else ang
     co, si = run(native.COMB_COS_SIN, [x], 2, flags=native.COMB_DEGREES if deg else 0)
