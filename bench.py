@@ -573,7 +573,11 @@ def multi_gpu_lines(args, result, dist, rank, world, dev, plan, stacks, outs, la
         from anemoi_transform_amd.interp import knn_inverse_distance
 
         g_src, g_tgt = lookup("o1280"), lookup("n320-sized")
-        n4_src, n4_tgt, n_stack = len(g_src["latitudes"]), len(g_tgt["latitudes"]), 24
+        # one stack per timestep, the 6 variables of a grid point sharing a column (6 x 137 = 822 levels, 3.3 KB): the layout a job
+        # that controls its stacks would choose — a gathered column wastes less of its first and last 128-byte line
+        # (extras.config4 of the N = 1 line times both this and 24 stacks of 137 levels)
+        n4_src, n4_tgt, n_var, n_stack = len(g_src["latitudes"]), len(g_tgt["latitudes"]), 6, 4
+        lev4 = n_var * args.levels
         idx4, w4 = knn_inverse_distance(g_src, g_tgt, k=4)
         b4 = GatherPlan(n4_src, n4_tgt, index=idx4, weights=w4).bounds(world)
         lo4, hi4 = b4[rank], b4[rank + 1]
@@ -582,15 +586,15 @@ def multi_gpu_lines(args, result, dist, rank, world, dev, plan, stacks, outs, la
         t4, np4 = torch.float32, np.float32  # SURVEY.md §8d sizes config 4 in float32 (86.8 GB of sources per GPU; float64 would not leave room beside the N headline stacks)
         for i in range(n_stack):
             gen.manual_seed(SEED + 7 * i)
-            st = Stack.empty(n4_src, args.levels, t4, dev, COLUMNS, zero=True)
-            st.data[:, : args.levels].normal_(250.0 + 5.0 * (i // 4), 20.0, generator=gen)
+            st = Stack.empty(n4_src, lev4, t4, dev, COLUMNS, zero=True)
+            st.data[:, :lev4].normal_(250.0 + 5.0 * i, 20.0, generator=gen)
             srcs.append(st)
-        dsts = [Stack.empty(hi4 - lo4, args.levels, t4, dev, COLUMNS) for _ in range(n_stack)]
+        dsts = [Stack.empty(hi4 - lo4, lev4, t4, dev, COLUMNS) for _ in range(n_stack)]
         idx_d4, w_d4, rows_d4 = ordered_tables(idx4, w4, g_tgt, lo4, hi4, np4, dev, natural=args.natural_order)
 
         def go():
             native.regrid_ell_batch([s.data for s in srcs], [d.data for d in dsts], idx_d4, w_d4, n_src=n4_src, n_tgt=hi4 - lo4, k=4,
-                                    n_lev=args.levels, src_pitch=srcs[0].pitch, out_pitch=dsts[0].pitch, layout=COLUMNS, tgt_rows=rows_d4)
+                                    n_lev=lev4, src_pitch=srcs[0].pitch, out_pitch=dsts[0].pitch, layout=COLUMNS, tgt_rows=rows_d4)
 
         reps = max(3, min(args.steps, 20))
         for _ in range(3):
@@ -602,10 +606,11 @@ def multi_gpu_lines(args, result, dist, rank, world, dev, plan, stacks, outs, la
             go()
         torch.cuda.synchronize()
         t = max_over_ranks(time.perf_counter() - t0)
-        return {"value": n4_tgt * args.levels * n_stack * reps / t, "unit": "grid-points/s", "ms_per_step": t / reps * 1e3, "fields": n_stack * args.levels,
+        return {"value": n4_tgt * lev4 * n_stack * reps / t, "unit": "grid-points/s", "ms_per_step": t / reps * 1e3, "fields": n_stack * lev4,
                 "targets_of_this_rank": hi4 - lo4,
                 "dtype": "f32",
-                "workload": f"O1280 -> N320-sized ({n4_tgt} pts), k=4, float32, 24 stacks x {args.levels} levels resident on every rank, target points over {world} ranks"}
+                "workload": f"O1280 -> N320-sized ({n4_tgt} pts), k=4, float32, {n_var} variables x {args.levels} levels x {n_stack} timesteps resident on every rank "
+                            f"as {n_stack} stacks of {lev4} levels, target points over {world} ranks"}
 
     def config5():
         plain, fused, _, all_units, _, keep = config5_case(args, dev, tdtype, np_dtype, rank, world)
@@ -984,7 +989,10 @@ def config5_case(args, dev, tdtype, np_dtype, rank=0, world=1):
 
 def config4_lines(args, dev, tdtype, np_dtype, itemsize):
     """The whole 3 288-field batch of BASELINE configs[3] resident on ONE MI355X (88.7 GB f32): all target points (what one
-    GPU does alone), and each of the 8 traffic-balanced target shards (what each of 8 GPUs would do; the slowest bounds the job)."""
+    GPU does alone), and each of the 8 traffic-balanced target shards (what each of 8 GPUs would do; the slowest bounds the job) —
+    in two layouts of the same fields: 24 stacks of 137 levels (one per variable and timestep) through the batched launch, and
+    4 stacks of 822 levels (one per timestep: the 6 variables of a grid point share a column of 3.3 KB), where a gathered column
+    wastes less of its first and last 128-byte line (tools/experiments/tall_stacks.py: 0.69 -> 0.73 of the HBM peak)."""
     from anemoi_transform_amd import native
     from anemoi_transform_amd.gather import GatherPlan
     from anemoi_transform_amd.grids import lookup
@@ -992,40 +1000,54 @@ def config4_lines(args, dev, tdtype, np_dtype, itemsize):
     from anemoi_transform_amd.stack import COLUMNS, Stack
 
     src_grid, tgt = lookup("o1280"), lookup("n320-sized")  # BASELINE configs[3], whatever grid pair the headline runs on
-    n_src, n_tgt, n_lev, n_stack, k = len(src_grid["latitudes"]), len(tgt["latitudes"]), args.levels, 24, 4
+    n_src, n_tgt, n_var, n_time, k = len(src_grid["latitudes"]), len(tgt["latitudes"]), 6, 4, 4
     idx, w = knn_inverse_distance(src_grid, tgt, k=k)
     plan = GatherPlan(n_src, n_tgt, index=idx, weights=w)
-    gen = torch.Generator(device=dev)
-    stacks = []
-    for i in range(n_stack):
-        gen.manual_seed(SEED + 7 * i)
-        st = Stack.empty(n_src, n_lev, tdtype, dev, COLUMNS, zero=True)
-        st.data[:, :n_lev].normal_(250.0 + 5.0 * (i // 4), 20.0, generator=gen)
-        stacks.append(st)
-    outs = [Stack.empty(n_tgt, n_lev, tdtype, dev, COLUMNS) for _ in range(n_stack)]
-
-    def run(lo, hi):
-        idx_d, w_d, rows_d = ordered_tables(idx, w, tgt, lo, hi, np_dtype, dev, natural=args.natural_order)
-        views = [o.data[lo:hi] for o in outs]
-
-        def go():  # atx_regrid_ell_batch / _ordered: one launch per 16 stacks -> 2 launches for the 24
-            native.regrid_ell_batch([s.data for s in stacks], views, idx_d, w_d, n_src=n_src, n_tgt=hi - lo, k=k, n_lev=n_lev,
-                                    src_pitch=stacks[0].pitch, out_pitch=outs[0].pitch, layout=COLUMNS, tgt_rows=rows_d)
-
-        ms, _ = time_launches(go, 10, 2)
-        u = int(np.unique(idx[lo:hi]).size)
-        return dict(line((hi - lo) * n_lev * n_stack, ms, n_stack * algorithmic_bytes(n_lev, itemsize, u, hi - lo, k)), targets=hi - lo)
-
-    out = {"dtype": "f32" if itemsize == 4 else "f64",
-           "workload": f"O1280 -> N320-sized reduced Gaussian ({n_tgt} pts, grids.sized_row_lengths), k=4, {n_stack} stacks x {n_lev} levels "
-                       f"= {n_stack * n_lev} fields resident ({sum(s.data.numel() for s in stacks) * itemsize / 1e9:.1f} GB)",
-           "all_targets_one_gpu": run(0, n_tgt)}
     bounds = plan.bounds(8)
-    shards = [run(bounds[r], bounds[r + 1]) for r in range(8)]
-    slowest = max(shards, key=lambda s: s["avg_launch_ms"])
-    out["shards_of_8"] = {"ms": [s["avg_launch_ms"] for s in shards], "targets": [s["targets"] for s in shards], "slowest": slowest,
-                          "job_value_bound_by_slowest_shard": n_tgt * n_lev * n_stack / (slowest["avg_launch_ms"] * 1e-3),
-                          "note": "each shard timed alone on this GPU with all 24 source stacks resident: the per-GPU step of the 8-GPU job"}
+    n_fields = n_var * n_time * args.levels
+
+    def layout(n_stack, n_lev):
+        gen = torch.Generator(device=dev)
+        stacks = []
+        for i in range(n_stack):
+            gen.manual_seed(SEED + 7 * i)
+            st = Stack.empty(n_src, n_lev, tdtype, dev, COLUMNS, zero=True)
+            st.data[:, :n_lev].normal_(250.0 + 5.0 * (i // 4), 20.0, generator=gen)
+            stacks.append(st)
+        outs = [Stack.empty(n_tgt, n_lev, tdtype, dev, COLUMNS) for _ in range(n_stack)]
+
+        def run(lo, hi):
+            idx_d, w_d, rows_d = ordered_tables(idx, w, tgt, lo, hi, np_dtype, dev, natural=args.natural_order)
+            views = [o.data[lo:hi] for o in outs]
+
+            def go():  # atx_regrid_ell_batch / _ordered: one launch per 16 stacks
+                native.regrid_ell_batch([s.data for s in stacks], views, idx_d, w_d, n_src=n_src, n_tgt=hi - lo, k=k, n_lev=n_lev,
+                                        src_pitch=stacks[0].pitch, out_pitch=outs[0].pitch, layout=COLUMNS, tgt_rows=rows_d)
+
+            ms, _ = time_launches(go, 10, 2)
+            u = int(np.unique(idx[lo:hi]).size)
+            return dict(line((hi - lo) * n_lev * n_stack, ms, n_stack * algorithmic_bytes(n_lev, itemsize, u, hi - lo, k)), targets=hi - lo)
+
+        rec = {"stacks": n_stack, "levels_per_stack": n_lev, "resident_GB": sum(s.data.numel() for s in stacks) * itemsize / 1e9,
+               "all_targets_one_gpu": run(0, n_tgt)}
+        shards = [run(bounds[r], bounds[r + 1]) for r in range(8)]
+        slowest = max(shards, key=lambda s: s["avg_launch_ms"])
+        rec["shards_of_8"] = {"ms": [s["avg_launch_ms"] for s in shards], "targets": [s["targets"] for s in shards], "slowest": slowest,
+                              "job_value_bound_by_slowest_shard": n_tgt * n_fields / (slowest["avg_launch_ms"] * 1e-3),
+                              "note": "each shard timed alone on this GPU with all source stacks resident: the per-GPU step of the 8-GPU job"}
+        del stacks, outs
+        torch.cuda.empty_cache()
+        return rec
+
+    per_variable = layout(n_var * n_time, args.levels)
+    per_timestep = layout(n_time, n_var * args.levels)
+    out = {"dtype": "f32" if itemsize == 4 else "f64",
+           "workload": f"O1280 -> N320-sized reduced Gaussian ({n_tgt} pts, grids.sized_row_lengths), k=4, {n_var} variables x {args.levels} levels x "
+                       f"{n_time} timesteps = {n_fields} fields resident ({per_variable['resident_GB']:.1f} GB)",
+           # round 1-3's keys keep their meaning: the 24 x 137 layout
+           "all_targets_one_gpu": per_variable["all_targets_one_gpu"], "shards_of_8": per_variable["shards_of_8"],
+           "stacks_per_variable_and_timestep": per_variable,
+           "stacks_per_timestep_variables_share_a_column": per_timestep}
     return out
 
 

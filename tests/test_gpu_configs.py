@@ -93,6 +93,20 @@ def test_config4_batched_stacks_target_sharded_8_ways(dev):
         want = oracle.csr_apply(w32, idx.reshape(-1), indptr, (n_tgt, n_src), stacks[stack_id].level_numpy(level))
         assert np.array_equal(full[stack_id].level_numpy(level), want), (stack_id, level)
 
+    # the same fields with the 6 variables of one timestep sharing a column (ONE stack of 6 x 137 = 822 levels, what bench.py's
+    # config-4 line times as its second layout): level for level the same bits — and an 822-level launch of the direct kernel
+    timestep = 2
+    members = [4 * v + timestep for v in range(6)]  # stack_id = 4 * variable + timestep
+    tall = Stack.empty(n_src, 6 * n_lev, torch.float32, dev, COLUMNS, zero=True)
+    for j, sid in enumerate(members):
+        tall.data[:, j * n_lev:(j + 1) * n_lev] = stacks[sid].data[:, :n_lev]
+    out_tall = plan.apply(tall)
+    assert out_tall.n_lev == 822
+    for j, sid in enumerate(members):
+        assert torch.equal(out_tall.data[:, j * n_lev:(j + 1) * n_lev].contiguous().view(torch.int32),
+                           full[sid].data[:, :n_lev].contiguous().view(torch.int32)), sid
+    del tall, out_tall
+
     pieces = [s.apply_many(stacks) for s in shards]  # what ranks 0..7 would each compute
     for stack_id in range(n_stack):
         parts = torch.cat([pieces[r][stack_id].data for r in range(8)])
