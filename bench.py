@@ -937,6 +937,16 @@ def single_gpu_lines(args, result, dev, stacks, outs, launch, idx_d, w_d, rows_d
         extras["config5"] = {"workload": "O2560 (26306560 pts) -> 0.25 deg, k=4, 137 levels: regrid | orog_to_z (1 level) | convert K->degC (136 levels)",
                              "regrid_only": line(units, ms_plain, alg5), "fused_chain_one_launch": line(units, ms_fused, alg5)}
         del plain, fused, keep
+        torch.cuda.empty_cache()
+        # the same chain with the three variables of SURVEY.md §8d's description sharing a column: one stack of 3 x 137 levels
+        plain, fused, units, _, alg5, keep = config5_case(args, dev, tdtype, np_dtype, variables=3)
+        ms_plain, _ = time_launches(plain, 10, 2)
+        ms_fused, _ = time_launches(fused, 10, 2)
+        extras["config5"]["three_variables_share_a_column"] = {
+            "workload": f"O2560 -> 0.25 deg, k=4, ONE stack of 3 x {args.levels} levels (t -> degC, orography-like x g, one variable left alone), "
+                        f"{keep[0].data.numel() * keep[0].data.element_size() / 1e9:.1f} GB resident",
+            "regrid_only": line(units, ms_plain, alg5), "fused_chain_one_launch": line(units, ms_fused, alg5)}
+        del plain, fused, keep
     except Exception as e:
         extras["config5"] = {"error": f"{type(e).__name__}: {e}"}
     torch.cuda.empty_cache()
@@ -957,10 +967,13 @@ def single_gpu_lines(args, result, dev, stacks, outs, launch, idx_d, w_d, rows_d
     result["extras"] = extras
 
 
-def config5_case(args, dev, tdtype, np_dtype, rank=0, world=1):
+def config5_case(args, dev, tdtype, np_dtype, rank=0, world=1, variables=1):
     """BASELINE configs[4]: regrid + orography-adjust + unit-convert chained on ERA5-shape O2560 fields, as ONE fused launch per
-    137-level stack (136 levels of t -> degC, one level of orog -> z).  Returns (launch closures, units, algorithmic bytes) for
-    this rank's traffic-balanced slice of the 0.25 degree target grid.  The index table comes from the device k-NN search with
+    stack.  `variables=1` (rounds 1-3): one 137-level stack, 136 levels of t -> degC and one level of orog -> z.  `variables=3`
+    (SURVEY.md §8d "137 levels x {t, orog-like, one convertible var}"): the three variables of a grid point share a column — 137
+    levels of t (K -> degC), 137 of an orography-like field (x g), 137 left alone — one stack of 411 levels (43 / 87 GB), the layout
+    a job that controls its stacks would choose (DESIGN.md §2 "Tall stacks").  Returns (launch closures, units, algorithmic bytes)
+    for this rank's traffic-balanced slice of the 0.25 degree target grid.  The index table comes from the device k-NN search with
     the kernel's own order among equidistant points (cKDTree needs about a minute for 26.3 M points; the timing does not depend
     on that order)."""
     from anemoi_transform_amd import native
@@ -970,15 +983,26 @@ def config5_case(args, dev, tdtype, np_dtype, rank=0, world=1):
     from anemoi_transform_amd.stack import COLUMNS, Stack
 
     g_src, g_tgt = lookup("o2560"), lookup("0.25")
-    n5_src, n5_tgt, L = len(g_src["latitudes"]), len(g_tgt["latitudes"]), args.levels
+    n5_src, n5_tgt, L1 = len(g_src["latitudes"]), len(g_tgt["latitudes"]), args.levels
+    L = L1 * variables
     idx5, w5 = knn_inverse_distance(g_src, g_tgt, k=4, device=True, ties="index")
     b5 = GatherPlan(n5_src, n5_tgt, index=idx5, weights=w5).bounds(world)
     lo, hi = b5[rank], b5[rank + 1]
-    x = synth_stack(g_src, L, tdtype, dev, 0, COLUMNS)
+    if variables == 1:
+        x = synth_stack(g_src, L, tdtype, dev, 0, COLUMNS)
+    else:
+        x = Stack.empty(n5_src, L, tdtype, dev, COLUMNS, zero=True)
+        gen = torch.Generator(device=dev)
+        gen.manual_seed(SEED + 5)
+        x.data[:, :L].normal_(270.0, 15.0, generator=gen)
     out = Stack.empty(hi - lo, L, tdtype, dev, COLUMNS)
     idx_d, w_d, rows_d = ordered_tables(idx5, w5, g_tgt, lo, hi, np_dtype, dev, natural=args.natural_order)
-    cp = (native.OP_COPY, 0, 0.0, 0.0)
-    prog = native.level_program([[cp] * (L - 1) + [(native.OP_MUL, 0, 9.80665, 0.0)], [(native.OP_AFFINE, 0, 1.0, -273.15)] * (L - 1) + [cp]], dev)
+    cp, to_z, to_degc = (native.OP_COPY, 0, 0.0, 0.0), (native.OP_MUL, 0, 9.80665, 0.0), (native.OP_AFFINE, 0, 1.0, -273.15)
+    if variables == 1:
+        stages = [[cp] * (L - 1) + [to_z], [to_degc] * (L - 1) + [cp]]
+    else:  # levels [0, L1): t; [L1, 2 L1): orography-like; the rest: left alone
+        stages = [[cp] * L1 + [to_z] * L1 + [cp] * (L - 2 * L1), [to_degc] * L1 + [cp] * (L - L1)]
+    prog = native.level_program(stages, dev)
     kw = dict(n_src=n5_src, n_tgt=hi - lo, k=4, n_lev=L, src_pitch=x.pitch, out_pitch=out.pitch, layout=COLUMNS, tgt_rows=rows_d)
     plain = lambda: native.regrid_ell(x.data, out.data, idx_d, w_d, **kw)  # noqa: E731
     fused = lambda: native.regrid_ell(x.data, out.data, idx_d, w_d, prog=prog, n_stage=2, **kw)  # noqa: E731

@@ -157,6 +157,35 @@ def test_config5_chained_filters_on_o2560(dev, tdtype, np_dtype):
     torch.cuda.empty_cache()
 
 
+def test_config5_three_variables_sharing_a_column(dev):
+    """BASELINE configs[4] as SURVEY.md §8d words it — 137 levels x {t, orography-like, one more variable} — with the three variables of
+    a grid point in ONE column (a 411-level O2560 stack, 43 GB float32): the fused launch (program with three runs of levels: the
+    direct kernel's typed per-level table) against regrid-then-program and, on sample levels, against the oracle."""
+    src, tgt = lookup("o2560"), lookup("0.25")
+    n_src, n_tgt, n1 = len(src["latitudes"]), len(tgt["latitudes"]), 137
+    n_lev = 3 * n1
+    idx, w = interp.knn_inverse_distance(src, tgt, k=4, device=True)
+    plan = GatherPlan(n_src, n_tgt, index=idx, weights=w)
+    x = Stack.empty(n_src, n_lev, torch.float32, dev, COLUMNS, zero=True)
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(55)
+    x.data[:, :n_lev].normal_(270.0, 15.0, generator=gen)
+    cp, to_z, to_degc = (native.OP_COPY, 0, 0.0, 0.0), (native.OP_MUL, 0, oracle.G, 0.0), (native.OP_AFFINE, 0, 1.0, -273.15)
+    prog = native.level_program([[cp] * n1 + [to_z] * n1 + [cp] * n1, [to_degc] * n1 + [cp] * (2 * n1)], dev)
+    fused = plan.apply(x, prog=prog, n_stage=2)
+    chained = plan.apply(x)
+    native.pointwise_stack(chained.data, chained.data, n_pts=n_tgt, n_lev=n_lev, x_pitch=chained.pitch, y_pitch=chained.pitch, layout=COLUMNS,
+                           prog=prog, n_stage=2)
+    assert torch.equal(fused.data[:, :n_lev].contiguous().view(torch.int32), chained.data[:, :n_lev].contiguous().view(torch.int32))
+    indptr = np.arange(n_tgt + 1) * 4
+    w32 = w.astype(np.float32).reshape(-1)
+    for l, fn in ((5, lambda v: oracle.rescale_forward(v, np.float32(1.0), np.float32(-273.15))), (n1 + 70, lambda v: v * np.float32(oracle.G)), (n_lev - 1, lambda v: v)):
+        base = oracle.csr_apply(w32, idx.reshape(-1), indptr, (n_tgt, n_src), x.level_numpy(l))
+        assert np.array_equal(fused.level_numpy(l), fn(base)), l
+    del x, fused, chained
+    torch.cuda.empty_cache()
+
+
 def test_kernels_on_a_stack_beyond_2_to_31_elements(dev):
     """O2560 x 137 levels = 3.6e9 elements (14.4 GB f32): every streaming kernel must do its index arithmetic in 64 bits.
     Checked on samples against torch indexing (bit copies) and against an independent reduction."""
