@@ -539,6 +539,85 @@ static inline bool uniform_level_program(const atx_level_op* host_prog, int n_st
     return true;
 }
 
+// Round 4: the general piecewise-uniform form — per stage up to kMaxRuns RUNS of consecutive levels, each with its own operator, the
+// boundaries ANYWHERE (not on the vector grid).  This is the program of a stack in which several variables share a column
+// (DESIGN.md §2 "Tall stacks": 137 levels of t -> degC, 137 of orography x g, 137 left alone): boundaries at 137 and 274 fall
+// inside 16-byte vectors, so uniform_level_program refuses it and it used to read the per-level table (+11 % on a 411-level
+// float64 regrid) or go through the per-level LDS kernel (0.70-0.75 of the peak against 0.81).  By value in the kernel arguments:
+// a lane evaluates every run's operator on its vector and keeps, element by element, the one whose levels it holds.
+constexpr int kMaxRuns = 4;
+template <typename T>
+struct RunOps {
+    int n_stage;
+    int n_run[kMaxUniform];               // runs of stage s (1 .. kMaxRuns)
+    int start[kMaxUniform][kMaxRuns];     // first LEVEL of run r (start[s][0] = 0)
+    LevelOp<T> op[kMaxUniform][kMaxRuns];
+};
+
+template <typename T>
+static inline bool runs_level_program(const atx_level_op* host_prog, int n_stage, bool have_mask, int n_lev, RunOps<T>& out) {
+    if (!host_prog || n_stage < 1 || n_stage > kMaxUniform) return false;
+    auto typed = [](const atx_level_op& o) {
+        LevelOp<T> r;
+        r.op = o.op;
+        r.use_mask = o.use_mask ? 1 : 0;
+        r.p0 = static_cast<T>(o.p0);
+        r.p1 = static_cast<T>(o.p1);
+        return r;
+    };
+    auto same = [](const LevelOp<T>& a, const LevelOp<T>& b) {
+        return a.op == b.op && a.use_mask == b.use_mask && std::memcmp(&a.p0, &b.p0, sizeof(T)) == 0 && std::memcmp(&a.p1, &b.p1, sizeof(T)) == 0;
+    };
+    out.n_stage = n_stage;
+    for (int s = 0; s < kMaxUniform; ++s) {
+        out.n_run[s] = 1;
+        for (int r = 0; r < kMaxRuns; ++r) {
+            out.start[s][r] = r == 0 ? 0 : INT32_MAX;
+            out.op[s][r] = LevelOp<T>{ATX_OP_COPY, 0, T(0), T(0)};
+        }
+    }
+    for (int s = 0; s < n_stage; ++s) {
+        const atx_level_op* row = host_prog + (int64_t)s * n_lev;
+        int n = 0;
+        for (int l = 0; l < n_lev; ++l) {
+            const LevelOp<T> o = typed(row[l]);
+            if (n > 0 && same(o, out.op[s][n - 1])) continue;
+            if (n == kMaxRuns) return false;  // a fifth run
+            out.start[s][n] = l;
+            out.op[s][n] = o;
+            ++n;
+        }
+        out.n_run[s] = n;
+        for (int r = 0; r < n; ++r)
+            if (out.op[s][r].use_mask && !have_mask) return false;  // (rejected by validation anyway)
+    }
+    return true;
+}
+
+// All stages of a RunOps program applied to the vector of levels c*VEC .. c*VEC+VEC-1 (scalar loop bounds and branches: the runs
+// are uniform over the launch; the per-element choice is a select).
+template <typename T, int VEC, bool TRANS = true>
+__device__ __forceinline__ void apply_run_ops(const RunOps<T>& runs, int c, Pack<T, VEC>& v, bool masked) {
+    using V = Pack<T, VEC>;
+#pragma unroll
+    for (int s = 0; s < kMaxUniform; ++s) {
+        if (s >= runs.n_stage) break;
+        V res = v;
+        apply_level_op_vec<T, VEC, TRANS>(runs.op[s][0], res, masked);
+#pragma unroll
+        for (int r = 1; r < kMaxRuns; ++r) {
+            if (r >= runs.n_run[s]) break;
+            V other = v;
+            apply_level_op_vec<T, VEC, TRANS>(runs.op[s][r], other, masked);
+            const int first = runs.start[s][r];
+#pragma unroll
+            for (int e = 0; e < VEC; ++e)
+                if (c * VEC + e >= first) res.v[e] = other.v[e];
+        }
+        v = res;
+    }
+}
+
 // Does some 16-byte vector of levels hold two different operators at some stage (once the parameters are rounded to T)?  Such
 // "mixed" vectors are evaluated level by level from the per-level program — fine for the odd boundary vector of a two-variable
 // stack, slow when every vector is one (a different scale per level, float32: 2.20 ms on the per-vector-table kernel, 1.82 ms on

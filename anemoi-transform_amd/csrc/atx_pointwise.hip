@@ -374,6 +374,35 @@ pointwise_cols_uniform_kernel(const T* __restrict__ x, T* __restrict__ y, int64_
     }
 }
 
+// Programs made of RUNS of levels (RunOps: up to 4 per stage, boundaries anywhere — several variables sharing a column): the launch shape
+// of the by-value kernel above — one 16-byte vector per lane, no loop, no shared memory, non-temporal accesses when no point mask is
+// read — with every run's operator evaluated on the vector and the element's own kept.  Before round 4 such programs went through the
+// per-level LDS kernel (0.70 / 0.75 of the peak).
+template <typename T, int VEC, bool TRANS, bool NT>
+__global__ void __launch_bounds__(kBlock)
+pointwise_cols_runs_kernel(const T* __restrict__ x, T* __restrict__ y, int64_t n_vec, int C, int Cp, RunOps<T> runs,
+                           const uint8_t* __restrict__ point_mask) {
+    using V = Pack<T, VEC>;
+    const int64_t vi = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (vi >= n_vec) return;
+    int64_t row;
+    int c;
+    if (n_vec <= 0xffffffffll) {
+        const unsigned r = (unsigned)vi / (unsigned)Cp;
+        row = r;
+        c = (int)((unsigned)vi - r * (unsigned)Cp);
+    } else {
+        row = vi / Cp;
+        c = (int)(vi - row * Cp);
+    }
+    if (c >= C) return;  // padding slot of a loose pitch
+    const bool masked = point_mask ? point_mask[row] != 0 : false;
+    V v = NT ? pw_load_nt<T, VEC>(x + vi * VEC) : pw_load<T, VEC>(x + vi * VEC);
+    apply_run_ops<T, VEC, TRANS>(runs, c, v, masked);
+    if (NT) pw_store_nt<T, VEC>(y + vi * VEC, v);
+    else pw_store<T, VEC>(y + vi * VEC, v);
+}
+
 // ONE stage whose 16-byte vectors each hold one operator KIND (the parameters may differ from level to level: a scale per level): one
 // vector per lane, no loop, the parameters from the typed per-level part of the host-built table (level_tables_layout; two 16-byte
 // loads and one code word per lane, L1 / L2 resident) — the launch shape of the by-value kernel.  Measured against the per-level LDS
@@ -1072,6 +1101,31 @@ static int pointwise_typed(const void* x_, void* y_, int64_t n_pts, int n_lev, i
                 }
 #undef ATX_PW_UNIFORM_LAUNCH
                 ATX_LAUNCH_CHECK("pointwise_stack_uniform");
+                return ATX_OK;
+            }
+            // (1b) runs of levels with boundaries anywhere (several variables in one column), out of place or in place: by value as well
+#ifndef ATX_PW_RUNS
+#define ATX_PW_RUNS 1
+#endif
+            // Measured against the routes below (tools/experiments/runs_probe.py, profiles/r04_runs_probe.log): evaluating every run's operator and
+            // selecting costs a streaming kernel more than it saves — one stage of 3 runs 0.72 / 0.67 (f32 / f64) here against 0.76 / 0.72 on the
+            // table and per-level kernels — except for float32 programs of two or more stages, which those kernels run at 0.52-0.58 and this one
+            // at 0.65-0.66.  So only they take it.
+            RunOps<T> runs{};
+            if (ATX_PW_RUNS && sizeof(T) == 4 && n_stage >= 2 && (n_vec + kBlock - 1) / kBlock <= 0x7fffffffll &&
+                runs_level_program<T>(host_prog, n_stage, mask != nullptr, n_lev, runs)) {
+                bool uses_mask = false;
+                for (int s = 0; s < n_stage; ++s)
+                    for (int r = 0; r < runs.n_run[s]; ++r) uses_mask = uses_mask || runs.op[s][r].use_mask != 0;
+                const bool trans = program_has_transcendental(host_prog, n_stage, n_lev);
+                const bool nt = !(uses_mask && mask);
+                const dim3 grid((unsigned)((n_vec + kBlock - 1) / kBlock));
+#define ATX_PW_RUNS_LAUNCH(TR_, NT_) \
+    hipLaunchKernelGGL((pointwise_cols_runs_kernel<T, VEC, TR_, NT_>), grid, dim3(kBlock), 0, st, x, y, n_vec, C, Cp, runs, uses_mask ? mask : nullptr)
+                if (trans) { if (nt) ATX_PW_RUNS_LAUNCH(true, true); else ATX_PW_RUNS_LAUNCH(true, false); }
+                else { if (nt) ATX_PW_RUNS_LAUNCH(false, true); else ATX_PW_RUNS_LAUNCH(false, false); }
+#undef ATX_PW_RUNS_LAUNCH
+                ATX_LAUNCH_CHECK("pointwise_stack_runs");
                 return ATX_OK;
             }
             // (2) operators differing from level to level.  Measured (137 levels of O1280, profiles/r03_pointwise_ab.log): the table

@@ -282,7 +282,7 @@ regrid_cols_ell_kernel(EllBatch batch,
 #ifndef ATX_PAD_SELF
 #define ATX_PAD_SELF 1
 #endif
-constexpr int kEpiNone = 0, kEpiUniform = 1, kEpiTable = 2;
+constexpr int kEpiNone = 0, kEpiUniform = 1, kEpiTable = 2, kEpiRuns = 3;  // kEpiRuns (round 4): up to 4 runs of levels per stage, boundaries anywhere (RunOps)
 constexpr int kMaxTable = 4;
 
 // COPY / AFFINE / MUL (+ mask) on one element, branch-free; bit-identical to apply_level_op for these operators.
@@ -300,7 +300,7 @@ regrid_cols_ell_direct_kernel(EllBatch batch, const int32_t* __restrict__ idx, c
                               int C, int64_t src_pitch, int64_t out_pitch, unsigned n_blocks, int items_per_lane,
                               UniformOps<T> uniform, const unsigned char* __restrict__ level_tables, int n_stage, int n_lev,
                               const uint8_t* __restrict__ tgt_mask,
-                              const int32_t* __restrict__ tgt_rows) {
+                              const int32_t* __restrict__ tgt_rows, RunOps<T> runs) {
     using V = Pack<T, VEC>;
     const T* __restrict__ src = static_cast<const T*>(batch.src[blockIdx.y]);
     T* __restrict__ out = static_cast<T*>(batch.out[blockIdx.y]);
@@ -329,7 +329,7 @@ regrid_cols_ell_direct_kernel(EllBatch batch, const int32_t* __restrict__ idx, c
         V ta[kMaxTable], tb[kMaxTable];
         unsigned tcode[kMaxTable];
         bool masked = false;
-        if (EPI == kEpiUniform) masked = tgt_mask ? (tgt_mask[row] != 0) : false;
+        if (EPI == kEpiUniform || EPI == kEpiRuns) masked = tgt_mask ? (tgt_mask[row] != 0) : false;
         if (EPI == kEpiTable) {  // the operators of this vector's levels, in the stack's type (level_tables_layout)
             using OpWord = typename std::conditional<VEC == 4, uint32_t, uint16_t>::type;
             const int Lp = C * VEC;
@@ -379,6 +379,8 @@ regrid_cols_ell_direct_kernel(EllBatch batch, const int32_t* __restrict__ idx, c
                     if (c >= uniform.split[s]) acc = other;
                 }
             }
+        } else if (EPI == kEpiRuns) {
+            apply_run_ops<T, VEC>(runs, c, acc, masked);
         } else if (EPI == kEpiTable) {
 #pragma unroll
             for (int s = 0; s < kMaxTable; ++s) {
@@ -765,15 +767,27 @@ static int launch_cols_ell(const EllBatch& batch, const int32_t* idx, const T* w
             UniformOps<T> uniform{};
             if (!prog) {
                 hipLaunchKernelGGL((regrid_cols_ell_direct_kernel<T, VEC, K, WEIGHTED, PAD, kEpiNone>), dim3(n_blocks, batch.n), dim3(kEllBlock), 0,
-                                   stream, batch, idx, w, n_items, C, src_pitch, out_pitch, n_blocks, 1, uniform, nullptr, 0, n_lev, nullptr, epi.tgt_rows);
+                                   stream, batch, idx, w, n_items, C, src_pitch, out_pitch, n_blocks, 1, uniform, nullptr, 0, n_lev, nullptr, epi.tgt_rows, RunOps<T>{});
                 ATX_LAUNCH_CHECK("regrid_cols_ell_direct");
                 return ATX_OK;
             }
             if (ATX_EPI_DIRECT && uniform_program<T>(epi, n_lev, VEC, uniform)) {
                 hipLaunchKernelGGL((regrid_cols_ell_direct_kernel<T, VEC, K, WEIGHTED, PAD, kEpiUniform>), dim3(n_blocks, batch.n), dim3(kEllBlock),
                                    0, stream, batch, idx, w, n_items, C, src_pitch, out_pitch, n_blocks, 1, uniform, nullptr, n_stage, n_lev,
-                                   tgt_mask, epi.tgt_rows);
+                                   tgt_mask, epi.tgt_rows, RunOps<T>{});
                 ATX_LAUNCH_CHECK("regrid_cols_ell_direct_uniform");
+                return ATX_OK;
+            }
+#ifndef ATX_EPI_RUNS
+#define ATX_EPI_RUNS 1
+#endif
+            RunOps<T> runs{};
+            if (ATX_EPI_DIRECT && ATX_EPI_RUNS && runs_level_program<T>(epi.host_prog, n_stage, tgt_mask != nullptr, n_lev, runs)) {
+                // several variables in one column (runs of levels with boundaries anywhere): by value, no table read beside the gather
+                hipLaunchKernelGGL((regrid_cols_ell_direct_kernel<T, VEC, K, WEIGHTED, PAD, kEpiRuns>), dim3(n_blocks, batch.n), dim3(kEllBlock),
+                                   0, stream, batch, idx, w, n_items, C, src_pitch, out_pitch, n_blocks, 1, uniform, nullptr, n_stage, n_lev,
+                                   tgt_mask, epi.tgt_rows, runs);
+                ATX_LAUNCH_CHECK("regrid_cols_ell_direct_runs");
                 return ATX_OK;
             }
             if (ATX_EPI_DIRECT && VEC == Vec16<T>::N && madd_family_program(epi, n_lev)) {  // the table is built for 16-byte vectors
@@ -781,7 +795,7 @@ static int launch_cols_ell(const EllBatch& batch, const int32_t* idx, const T* w
                                                     level_tables_layout(n_stage, n_lev, sizeof(T) == 4 ? ATX_F32 : ATX_F64).levels_offset;
                 hipLaunchKernelGGL((regrid_cols_ell_direct_kernel<T, VEC, K, WEIGHTED, PAD, kEpiTable>), dim3(n_blocks, batch.n), dim3(kEllBlock), 0,
                                    stream, batch, idx, w, n_items, C, src_pitch, out_pitch, n_blocks, 1, uniform, level_tables, n_stage, n_lev,
-                                   tgt_mask, epi.tgt_rows);
+                                   tgt_mask, epi.tgt_rows, RunOps<T>{});
                 ATX_LAUNCH_CHECK("regrid_cols_ell_direct_table");
                 return ATX_OK;
             }
