@@ -21,9 +21,9 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CLANG = "/opt/rocm/lib/llvm/bin/clang"
 HIPCC = "/opt/rocm/bin/hipcc"
-VARIANTS = os.path.join(ROOT, "anemoi-transform_amd", "lib", "variants")
+VARIANTS = os.path.join(ROOT, "gpurun_out", "hostsan")  # scratch: git-ignored, outside the snapshot gpurun sends to the GPU box
 LIB = os.path.join(VARIANTS, "libatx_hostsan.so")
-STUB = os.path.join(ROOT, "tests", "rccl_stub", "librccl_stub_hostsan.so")
+STUB = os.path.join(VARIANTS, "librccl_stub_hostsan.so")
 SAN = ["-fsanitize=address,undefined", "-fno-sanitize-recover=all", "-shared-libasan", "-g"]
 
 
