@@ -65,10 +65,11 @@ ENTRIES = [lambda m: (native.OP_COPY, m, 0.0, 0.0), lambda m: (native.OP_AFFINE,
 
 def random_program(rng, n_stage, n_lev):
     """Stages in the shapes the kernels tell apart: one operator for all levels; two runs of levels (split anywhere: on and off
-    16-byte boundaries); the multiply-add family level by level; a few active levels among COPY; anything goes."""
+    16-byte boundaries); three or four runs with boundaries anywhere (several variables sharing a column: the by-value runs routes of
+    round 4); the multiply-add family level by level; a few active levels among COPY; anything goes."""
     ops = []
     for _ in range(n_stage):
-        style = rng.choice(["uniform", "two_pieces", "madd", "sparse", "random"])
+        style = rng.choice(["uniform", "two_pieces", "runs", "madd", "sparse", "random"])
         pick = lambda family=7: ENTRIES[int(rng.integers(0, family))](int(rng.random() < 0.3))  # noqa: E731
         if style == "uniform":
             stage = [pick()] * n_lev
@@ -78,6 +79,10 @@ def random_program(rng, n_stage, n_lev):
                 split = split // 4 * 4
             first, second = pick(), pick()
             stage = [first if l < split else second for l in range(n_lev)]
+        elif style == "runs":
+            cuts = sorted(int(v) for v in rng.integers(0, n_lev + 1, int(rng.integers(2, 4))))  # 2 or 3 cuts: up to 3 or 4 runs (empty ones allowed)
+            run_ops = [pick() for _ in range(len(cuts) + 1)]
+            stage = [run_ops[sum(l >= c for c in cuts)] for l in range(n_lev)]
         elif style == "madd":
             stage = [pick(3) for _ in range(n_lev)]
         elif style == "sparse":
