@@ -36,6 +36,7 @@ def test_single_gpu_line():
     assert d["unit"] == "grid-points/s" and d["value"] > 0 and d["dtype"] == "f64" and "workload" in d["config"]  # the reference's own arithmetic (R: fields.py:178-202)
     r = d["roofline"]
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
+    assert r["min_launch_ms"] <= r["median_launch_ms"] and r["min_launch_ms"] <= r["avg_launch_ms"]  # HIP events around single launches
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] == 1 and c["value"] > 0 and "sample" in c
     # both reference statements (csr_array @ x, x[..., idx]) in both widths
