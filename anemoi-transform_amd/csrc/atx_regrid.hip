@@ -22,6 +22,7 @@
 #include "atx_common.hpp"
 #include "atx_regrid_decl.hpp"
 
+#include <cstdlib>
 #include <cstring>
 
 namespace atx {
@@ -39,6 +40,55 @@ check_indices_kernel(const int32_t* __restrict__ idx, int64_t n, int64_t n_src, 
 #pragma unroll
     for (int off = kWave / 2; off > 0; off >>= 1) bad += __shfl_down(bad, off, kWave);
     if ((threadIdx.x & (kWave - 1)) == 0 && bad) atomicAdd(n_bad, bad);
+}
+
+// The same count with a lower bound of -1 allowed (ATX_ELL_PADDED marks absent entries with -1) and, for ordered traversals,
+// over a row table that must stay inside [0, n_tgt).
+__global__ void __launch_bounds__(kBlock)
+check_range_kernel(const int32_t* __restrict__ idx, int64_t n, int64_t lo, int64_t hi, unsigned long long* n_bad) {
+    unsigned long long bad = 0;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
+        const int64_t v = idx[i];
+        bad += (v < lo || v >= hi) ? 1u : 0u;
+    }
+#pragma unroll
+    for (int off = kWave / 2; off > 0; off >>= 1) bad += __shfl_down(bad, off, kWave);
+    if ((threadIdx.x & (kWave - 1)) == 0 && bad) atomicAdd(n_bad, bad);
+}
+
+// ATX_VALIDATE=1 (read once per process): every gather entry point first range-checks the tables it was handed ON THE DEVICE and
+// refuses the launch (ATX_EINVAL, nothing written) if an index points outside the source stack — the kernels trust their tables,
+// and an out-of-range read is a GPU fault that can take the whole node with it.  A debugging aid for binders that build their own
+// tables: it synchronises the stream and costs a pass over the tables, so it is off by default (the Python mirror validates on the
+// host when a plan is built, GatherPlan._check).
+static bool validation_on() {
+    static const bool on = [] {
+        const char* v = std::getenv("ATX_VALIDATE");
+        return v && *v && std::strcmp(v, "0") != 0;
+    }();
+    return on;
+}
+
+static int validate_table(const char* fn, const char* what, const int32_t* idx, int64_t n, int64_t lo, int64_t hi, hipStream_t s) {
+    if (n <= 0 || !idx) return ATX_OK;
+    unsigned long long* n_bad = nullptr;
+    int st = hip_status(hipMalloc(reinterpret_cast<void**>(&n_bad), sizeof(unsigned long long)), "ATX_VALIDATE: hipMalloc");
+    if (st != ATX_OK) return st;
+    unsigned long long host = 0;
+    st = hip_status(hipMemsetAsync(n_bad, 0, sizeof(unsigned long long), s), "ATX_VALIDATE: memset");
+    if (st == ATX_OK) {
+        int64_t blocks = (n + kBlock - 1) / kBlock;
+        if (blocks > kStreamGrid) blocks = kStreamGrid;
+        hipLaunchKernelGGL(check_range_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, s, idx, n, lo, hi, n_bad);
+        st = hip_status(hipGetLastError(), "ATX_VALIDATE: launch");
+    }
+    if (st == ATX_OK) st = hip_status(hipMemcpyAsync(&host, n_bad, sizeof host, hipMemcpyDeviceToHost, s), "ATX_VALIDATE: copy");
+    if (st == ATX_OK) st = hip_status(hipStreamSynchronize(s), "ATX_VALIDATE: synchronise");
+    (void)hipFree(n_bad);
+    if (st != ATX_OK) return st;
+    ATX_REQUIRE(host == 0, ATX_EINVAL, "%s: ATX_VALIDATE found %llu entries of %s outside [%lld, %lld) — launch refused", fn, host, what,
+                (long long)lo, (long long)hi);
+    return ATX_OK;
 }
 
 static int check_stack_args(const char* fn, const void* src, const void* out, int64_t n_src, int64_t n_tgt,
@@ -92,6 +142,11 @@ static int regrid_ell_common(const char* fn, const void* const* srcs, void* cons
     ATX_REQUIRE(prog || (!vec_prog && !host_prog), ATX_EINVAL, "%s: vec_prog / host_prog accompany prog, which is NULL", fn);
     if (n_tgt == 0) return ATX_OK;
     hipStream_t s = static_cast<hipStream_t>(stream);
+    if (validation_on()) {
+        int st = validate_table(fn, "idx", idx, n_tgt * k, pad ? -1 : 0, n_src, s);
+        if (st == ATX_OK && tgt_rows) st = validate_table(fn, "tgt_rows", tgt_rows, n_tgt, 0, n_tgt, s);
+        if (st != ATX_OK) return st;
+    }
     Epilogue epi;
     epi.prog = prog;
     epi.vec_prog = vec_prog;
@@ -164,6 +219,12 @@ static int regrid_csr_common(const char* fn, const void* src, void* out, const i
                 "%s: prog/n_stage mismatch (n_stage=%d)", fn, n_stage);
     if (n_tgt == 0) return ATX_OK;
     hipStream_t s = static_cast<hipStream_t>(stream);
+    if (validation_on()) {
+        int st = validate_table(fn, "indices", indices, nnz, 0, n_src, s);
+        if (st == ATX_OK) st = validate_table(fn, "indptr", indptr, n_tgt + 1, 0, nnz + 1, s);
+        if (st == ATX_OK && tgt_rows) st = validate_table(fn, "tgt_rows", tgt_rows, n_tgt, 0, n_tgt, s);
+        if (st != ATX_OK) return st;
+    }
     auto run = [&](const atx_level_op* p, int32_t stages, const uint8_t* m) {
         if (dtype == ATX_F32)
             return regrid_csr_typed<float>(src, out, indptr, indices, data, n_tgt, nnz, (int)n_lev, src_pitch, out_pitch, layout, p, stages, m, tgt_rows, s);

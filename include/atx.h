@@ -204,6 +204,11 @@ int atx_regrid_csr_ordered(const void* src, void* out, const int32_t* indptr, co
                            int64_t out_pitch, int dtype, int layout, const atx_level_op* prog, int32_t n_stage,
                            const uint8_t* tgt_mask, void* stream);
 
+/* Debugging aid for binders that build their own tables: with ATX_VALIDATE=1 in the environment (read once per process) every
+ * atx_regrid_* call first range-checks idx / indices / indptr / tgt_rows on the device and refuses the launch with ATX_EINVAL if an
+ * entry points outside the stack (the kernels trust their tables: an out-of-range read is a GPU fault).  It synchronises the stream
+ * and costs a pass over the tables; off by default. */
+
 /* Counts entries of idx[0..n) outside [0, n_src) into *n_bad (device int64,
  * zeroed by the call).  cKDTree returns n_src for "no neighbour within
  * distance_upper_bound" (R: spatial.py:630-632) — reject before gathering. */

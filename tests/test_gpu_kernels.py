@@ -8,6 +8,8 @@ interpolation within 1e-6 relative of the oracle fed the same f32 inputs
 
 from __future__ import annotations
 
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -18,6 +20,7 @@ from anemoi_transform_amd.stack import COLUMNS, FIELDS, Stack
 from oracle import oracle
 
 pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 DTYPES = [(torch.float64, np.float64), (torch.float32, np.float32)]
 LAYOUTS = [COLUMNS, FIELDS]
@@ -932,3 +935,61 @@ def test_tall_stacks_with_long_programs_are_served(dev, tdtype, np_dtype):
                           n_src=n_src, n_tgt=n_tgt, nnz=n_tgt * k, n_lev=n_lev, src_pitch=src.pitch, out_pitch=out.pitch, layout=layout,
                           prog=prog, n_stage=n_stage, tgt_mask=tmask_d)
         assert np.array_equal(out.numpy(), want, equal_nan=True), ("csr", layout)
+
+
+def test_validation_mode_refuses_a_table_that_points_outside_the_stack(dev):
+    """ATX_VALIDATE=1 (a fresh process: the variable is read once): the library range-checks the tables on the device and refuses the
+    launch instead of reading out of bounds — for fixed-k, padded, ordered and CSR tables; valid tables run as usual."""
+    import subprocess
+    import sys
+    import textwrap
+
+    code = textwrap.dedent("""
+        import sys, numpy as np, torch
+        sys.path.insert(0, %r)
+        import __graft_entry__ as g
+        g.load_package()
+        from anemoi_transform_amd import native
+        from anemoi_transform_amd.stack import COLUMNS, Stack
+        dev = torch.device("cuda", 0)
+        rng = np.random.default_rng(0)
+        n_src, n_tgt, n_lev, k = 500, 300, 5, 4
+        src = Stack.from_fields(rng.standard_normal((n_lev, n_src)), dev=dev)
+        out = src.new_like(n_pts=n_tgt)
+        out.data.fill_(7.0)
+        idx = rng.integers(0, n_src, (n_tgt, k)).astype(np.int32)
+        w = torch.from_numpy(rng.random((n_tgt, k))).to(dev)
+        kw = dict(n_src=n_src, n_tgt=n_tgt, k=k, n_lev=n_lev, src_pitch=src.pitch, out_pitch=out.pitch, layout=COLUMNS)
+        native.regrid_ell(src.data, out.data, torch.from_numpy(idx).to(dev), w, **kw)          # a valid table runs
+        assert not bool((out.data[:, :n_lev] == 7.0).any())
+        out.data.fill_(7.0)
+        refused = 0
+        for bad_value, padded in ((n_src, False), (-1, False), (-2, True), (n_src + 10**6, True)):
+            bad = idx.copy(); bad[123, 2] = bad_value
+            try:
+                native.regrid_ell(src.data, out.data, torch.from_numpy(bad).to(dev), w, padded=padded, **kw)
+            except ValueError as e:
+                assert "ATX_VALIDATE" in str(e) and "idx" in str(e), e
+                refused += 1
+        padded_ok = idx.copy(); padded_ok[5, 3] = -1
+        native.regrid_ell(src.data, out.data, torch.from_numpy(padded_ok).to(dev), w, padded=True, **kw)   # -1 is the padding marker
+        out.data.fill_(7.0)
+        rows = torch.arange(n_tgt, dtype=torch.int32, device=dev); rows[7] = n_tgt
+        try:
+            native.regrid_ell(src.data, out.data, torch.from_numpy(idx).to(dev), w, tgt_rows=rows, **kw)
+        except ValueError as e:
+            assert "tgt_rows" in str(e); refused += 1
+        indptr = (np.arange(n_tgt + 1) * k).astype(np.int32)
+        bad = idx.reshape(-1).copy(); bad[77] = n_src
+        try:
+            native.regrid_csr(src.data, out.data, torch.from_numpy(indptr).to(dev), torch.from_numpy(bad).to(dev), w.reshape(-1), n_src=n_src, n_tgt=n_tgt,
+                              nnz=n_tgt * k, n_lev=n_lev, src_pitch=src.pitch, out_pitch=out.pitch, layout=COLUMNS)
+        except ValueError as e:
+            assert "indices" in str(e); refused += 1
+        torch.cuda.synchronize()
+        assert bool((out.data[:, :n_lev] == 7.0).all())   # refused launches wrote nothing
+        print("refused", refused)
+    """ % ROOT)
+    env = dict(os.environ, ATX_VALIDATE="1")
+    run = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=env)
+    assert run.returncode == 0 and "refused 6" in run.stdout, run.stdout + run.stderr[-3000:]
