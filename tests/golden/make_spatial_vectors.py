@@ -15,7 +15,8 @@ How to run (build container only; neither the reference nor the shim travels to 
 
     a throw-away package providing ``earthkit.meteo.constants.constants`` with the four constants SURVEY.md §8c lists
     (R, R_earth, g, radian) must be on PYTHONPATH, in a directory OUTSIDE this repository (e.g. under /tmp);
-    PYTHONPATH=<that directory> python3 tests/golden/make_spatial_vectors.py
+    PYTHONPATH=<that directory> python3 tests/golden/make_spatial_vectors.py            # writes spatial_vectors.npz
+    PYTHONPATH=<that directory> python3 tests/golden/make_spatial_vectors.py --check    # re-runs the reference and compares with the committed file
 
 Inputs are either formula grids of this repository (``grids.lookup`` — stored by NAME, with a content hash, the tests
 regenerate them) or small seeded arrays stored in the file.  Outputs are stored exactly (int32 indices, float64 distances,
@@ -219,6 +220,19 @@ def main() -> int:
                                               "inside": int(mask.sum())})
 
     arrays["manifest"] = np.array(json.dumps(manifest, indent=1))
+    if "--check" in sys.argv:  # nothing is written: what the reference returns NOW against the committed vectors
+        with np.load(OUT) as committed:
+            missing = sorted(set(arrays) - set(committed.files)), sorted(set(committed.files) - set(arrays))
+            differ = [k for k in arrays if k in committed.files and k != "manifest" and not np.array_equal(arrays[k], committed[k])]
+            old = json.loads(str(committed["manifest"]))
+        for key in ("numpy", "scipy"):
+            if old.get(key) != manifest[key]:
+                print(f"note: the committed vectors were produced with {key} {old.get(key)}, this run uses {manifest[key]}")
+        if any(missing) or differ:
+            print(f"MISMATCH: only here {missing[0]}, only in the file {missing[1]}, different {differ}")
+            return 1
+        print(f"{OUT}: all {len(arrays) - 1} arrays equal what the reference returns in this container")
+        return 0
     np.savez_compressed(OUT, **arrays)
     print(f"wrote {OUT}: {len(arrays)} arrays, {os.path.getsize(OUT) / 1e6:.2f} MB")
     for section in ("nearest_grid_points", "cutout_mask", "thinning_mask", "global_on_lam_mask", "cropping_mask", "cutout_mask_errors"):
