@@ -16,7 +16,7 @@ are sharded N ways — every rank interpolates its traffic-balanced 1/N slice of
 batched launch per step; no collective in the data path.  `value` = point-fields all ranks produced / max-over-ranks
 wall time of the K steps, with the N source stacks already resident on every rank (that is what "inputs resident in
 HBM" means for a target-sharded job).  What it costs to GET them there is measured in the same run and reported next
-to `value`, never inside it: `source_exchange_ms.broadcast` (N RCCL broadcasts of 3.7 GB), `source_exchange_ms.bands`
+to `value`, never inside it: `source_exchange_ms.broadcast` (N RCCL broadcasts of 3.7 GB), `.all_gather` (the same as one all-gather), `.bands`
 (band-limited RCCL send/recv), each verified bit-equal against the stacks the rank synthesised itself, and
 `end_to_end` — one step INCLUDING the exchange, broadcast r+1 overlapped with launch r — and `end_to_end_bands`, the same step
 with the band-limited all-to-all in front of one batched launch.  `config4` is BASELINE configs[3] on the N GPUs of the run
@@ -214,7 +214,7 @@ def mirror_multi_gpu_into_config(result: dict) -> None:
         "strong": pick("strong", "value", "ms_per_step"),
         "end_to_end": pick("end_to_end", "value", "ms_per_step", "verified_bit_equal"),
         "end_to_end_bands": pick("end_to_end_bands", "value", "ms_per_step", "verified_bit_equal"),
-        "source_exchange_ms": {"broadcast": exchange.get("broadcast"), "bands": exchange.get("bands")},
+        "source_exchange_ms": {"broadcast": exchange.get("broadcast"), "all_gather": exchange.get("all_gather"), "bands": exchange.get("bands")},
         "field_axis_sharding": pick("field_axis_sharding", "value", "ms_per_step"),
         "config4": pick("config4", "value", "ms_per_step"),
         "config5": pick("config5", "value", "ms_per_step"),
@@ -672,7 +672,16 @@ def multi_gpu_lines(args, result, dist, rank, world, dev, plan, stacks, outs, la
         return {"ms": ms, "bytes_received_per_gpu": sum(b.data.numel() * b.data.element_size() for i, b in enumerate(got) if i != rank),
                 "verified_bit_equal": verified["bands"]}
 
+    def all_gather():
+        got, ms = timed(lambda: atxd.exchange_stacks(mine, collective="all_gather"))
+        exchange_ms["all_gather"] = ms
+        return {"ms": ms, "bytes_received_per_gpu": (world - 1) * mine.data.numel() * mine.data.element_size(),
+                "verified_bit_equal": all(torch.equal(g.data, s.data) for g, s in zip(got, stacks)),
+                "note": "the whole-stack exchange as ONE all-gather instead of N broadcasts"}
+
     detail["broadcast"] = section("exchange broadcast", broadcast)
+    detail["all_gather"] = section("exchange all_gather", all_gather)
+    torch.cuda.empty_cache()
     detail["bands"] = section("exchange bands", bands)
 
     def repetitions(exchange):  # as many repetitions as fit ~3 s of exchange; none if one exchange alone takes more than 30 s (gloo rehearsals)

@@ -80,6 +80,12 @@ def _worker(rank: int, world: int, port: int, kind: str, tmpdir: str) -> None:
         want = np.stack([oracle.csr_apply(data, indices, indptr, (n_tgt, n_src), f) for f in expect])
         assert np.array_equal(full.numpy(), want), f"rank {rank} stack {r}"
 
+    # 1b. the same exchange as ONE all-gather: the same stacks, as views of one buffer
+    gathered = atxd.exchange_stacks(mine, collective="all_gather")
+    assert len(gathered) == world and all(np.array_equal(g.numpy(), s.numpy()) for g, s in zip(gathered, stacks))
+    assert gathered[0].data.untyped_storage().data_ptr() == gathered[-1].data.untyped_storage().data_ptr()
+    assert np.array_equal(atxd.sharded_regrid(plan, gathered[(rank + 1) % world]).numpy(), atxd.sharded_regrid(plan, stacks[(rank + 1) % world]).numpy())
+
     # 2. feeding a rank only the band of source columns its slice references gives the same rows
     shard = plan.shard(rank, world)
     lo, hi = atxd.source_band(shard)

@@ -76,7 +76,7 @@ def test_two_ranks_without_a_launcher():
     assert KEYS <= set(d) and d["n_gpus"] == 2 and d["value"] > 0 and d["config"]["stacks_per_step"] == 2
     # --no-extras: the mirror is there (the driver's record keeps `config` whole) and says that nothing was measured
     m = d["config"]["multi_gpu"]
-    assert m["strong"] is None and m["end_to_end"] is None and m["source_exchange_ms"] == {"broadcast": None, "bands": None}
+    assert m["strong"] is None and m["end_to_end"] is None and m["source_exchange_ms"] == {"broadcast": None, "all_gather": None, "bands": None}
 
 
 def assert_mirrored(d: dict) -> None:
@@ -85,7 +85,7 @@ def assert_mirrored(d: dict) -> None:
     m = d["config"]["multi_gpu"]
     for section in ("strong", "end_to_end", "end_to_end_bands", "field_axis_sharding"):
         assert m[section]["value"] == d[section]["value"] > 0 and m[section]["ms_per_step"] == d[section]["ms_per_step"], section
-    assert m["source_exchange_ms"] == {k: d["source_exchange_ms"][k] for k in ("broadcast", "bands")}
+    assert m["source_exchange_ms"] == {k: d["source_exchange_ms"][k] for k in ("broadcast", "all_gather", "bands")}
     assert m["end_to_end"]["verified_bit_equal"] is True and m["end_to_end_bands"]["verified_bit_equal"] is True
     assert m["secondary_timed_out_in"] is None
     text = d["config"]["sharding"]
@@ -106,8 +106,8 @@ def test_two_ranks_rehearsal_over_gloo():
     assert KEYS <= set(d) and d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 0
     assert d["config"]["stacks_per_step"] == 2 and d["config"]["launches_per_step_per_gpu"] == 1
     assert "EXCLUDES the source exchange" in d["config"]["sharding"] and "gloo" in d["config"]["collectives"]
-    assert set(d["source_exchange_ms"]) == {"broadcast", "bands"} and all(v > 0 for v in d["source_exchange_ms"].values())
-    for kind in ("broadcast", "bands"):
+    assert set(d["source_exchange_ms"]) == {"broadcast", "all_gather", "bands"} and all(v > 0 for v in d["source_exchange_ms"].values())
+    for kind in ("broadcast", "all_gather", "bands"):
         assert d["source_exchange"][kind]["verified_bit_equal"] is True
     assert d["source_exchange"]["bands"]["bytes_received_per_gpu"] < d["source_exchange"]["broadcast"]["bytes_received_per_gpu"]
     assert d["end_to_end"]["verified_bit_equal"] is True and d["end_to_end_bands"]["verified_bit_equal"] is True  # (small grids: no section skipped)
