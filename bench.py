@@ -214,6 +214,7 @@ def mirror_multi_gpu_into_config(result: dict) -> None:
         "strong": pick("strong", "value", "ms_per_step"),
         "end_to_end": pick("end_to_end", "value", "ms_per_step", "verified_bit_equal"),
         "end_to_end_bands": pick("end_to_end_bands", "value", "ms_per_step", "verified_bit_equal"),
+        "end_to_end_all_gather": pick("end_to_end_all_gather", "value", "ms_per_step", "verified_bit_equal"),
         "source_exchange_ms": {"broadcast": exchange.get("broadcast"), "all_gather": exchange.get("all_gather"), "bands": exchange.get("bands")},
         "field_axis_sharding": pick("field_axis_sharding", "value", "ms_per_step"),
         "config4": pick("config4", "value", "ms_per_step"),
@@ -426,8 +427,8 @@ def main():
                          "source stacks before the timed region (inputs resident in HBM), so `value` is WEAK scaling and EXCLUDES the source "
                          "exchange: value(N) / value(1) is the driver's scaling figure and approaches N by construction.  north_star's "
                          "'>= 6x at 8 GPUs with the source broadcast once via RCCL' is answered by config.multi_gpu: `end_to_end` "
-                         "(one step INCLUDING the RCCL broadcast of the N stacks, overlapped with the launches) and `end_to_end_bands` "
-                         "(the band-limited all-to-all instead) are the rates of a job that must move its sources every step; `strong` "
+                         "(one step INCLUDING the RCCL broadcast of the N stacks, overlapped with the launches), `end_to_end_all_gather` (one "
+                         "all-gather instead) and `end_to_end_bands` (the band-limited all-to-all) are the rates of a job that must move its sources every step; `strong` "
                          "is the fixed-total-work line — the N = 1 job (ONE stack, BASELINE configs[2]) split over the N ranks — to be "
                          "divided by the N = 1 `value`; `source_exchange_ms` is the once-only cost a resident job pays up front")
                         if multi else "single GPU",
@@ -718,6 +719,25 @@ def multi_gpu_lines(args, result, dist, rank, world, dev, plan, stacks, outs, la
                 "note": "one step INCLUDING the exchange, band-limited: all-to-all of the source slabs each target slice needs, then one batched launch"}
 
     result["end_to_end_bands"] = section("end_to_end_bands", end_to_end_bands)
+
+    def end_to_end_all_gather():
+        # the whole-stack exchange as ONE all-gather, then one batched launch over this rank's target slice of the N stacks
+        reps = repetitions("all_gather")
+        if reps == 0:
+            return {"skipped": "the all-gather exchange failed or took more than 30 s"}
+        local = plan.shard(rank, world)
+
+        def once():
+            return local.apply_many(atxd.exchange_stacks(mine, collective="all_gather"))
+
+        (got, ms) = timed(lambda: [once() for _ in range(reps)][-1])
+        same = all(torch.equal(g.data, o.data) for g, o in zip(got, outs))
+        return {"ms_per_step": ms / reps, "value": units_per_step / (ms / reps * 1e-3), "unit": "grid-points/s", "verified_bit_equal": same,
+                "note": "one step INCLUDING the exchange: one all-gather of the N source stacks, then one batched launch"}
+
+    torch.cuda.empty_cache()
+    result["end_to_end_all_gather"] = section("end_to_end_all_gather", end_to_end_all_gather)
+    torch.cuda.empty_cache()
 
     # ---- the same exchanges through the library's own C-ABI communicator (atx_comm_*: RCCL bound directly)
     if args.backend == "nccl":

@@ -83,10 +83,11 @@ def assert_mirrored(d: dict) -> None:
     """`config.multi_gpu` repeats the numbers of the top-level sections (which the driver's record reduces to their names) and
     `config.sharding` says which of them answers north_star's ">= 6x at 8 GPUs"."""
     m = d["config"]["multi_gpu"]
-    for section in ("strong", "end_to_end", "end_to_end_bands", "field_axis_sharding"):
+    for section in ("strong", "end_to_end", "end_to_end_bands", "end_to_end_all_gather", "field_axis_sharding"):
         assert m[section]["value"] == d[section]["value"] > 0 and m[section]["ms_per_step"] == d[section]["ms_per_step"], section
     assert m["source_exchange_ms"] == {k: d["source_exchange_ms"][k] for k in ("broadcast", "all_gather", "bands")}
     assert m["end_to_end"]["verified_bit_equal"] is True and m["end_to_end_bands"]["verified_bit_equal"] is True
+    assert m["end_to_end_all_gather"]["verified_bit_equal"] is True
     assert m["secondary_timed_out_in"] is None
     text = d["config"]["sharding"]
     assert "end_to_end" in text and "strong" in text and "north_star" in text and "WEAK" in text
