@@ -352,7 +352,28 @@ pointwise_cols_uniform_kernel(const T* __restrict__ x, T* __restrict__ y, int64_
                 for (int s = 0; s < kMaxUniform; ++s) act |= (c[k] >= u.split[s]) ? (act_bits >> (4 + s)) : (act_bits >> s);
                 go[k] = go[k] && (act & 1u) != 0;
             }
-            if (go[k] && point_mask) masked[k] = point_mask[row] != 0;
+#ifndef ATX_PW_MASK_WAVE
+#define ATX_PW_MASK_WAVE 0
+#endif
+            if (point_mask) {
+                // The mask byte of a point is shared by the Cp lanes of its row: a per-lane byte load is one more vector-memory instruction
+                // per wave on a kernel that has two (ATX_PW_MASK_WAVE=1: the wave fetches the 8 bytes from its first row on with ONE scalar
+                // load and every lane picks its own — possible when a wave spans at most 8 rows and the 8 bytes lie inside the mask).
+                bool wave_path = false;
+                if (ATX_PW_MASK_WAVE && Cp >= 10 && n_vec <= 0xffffffffll) {
+                    const unsigned first_vi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(vi - (threadIdx.x & (kWave - 1))));
+                    const unsigned row0 = (first_vi / (unsigned)Cp) & ~7u;  // 8-byte aligned start
+                    const int64_t n_rows = n_vec / Cp;
+                    if ((int64_t)row0 + 8 <= n_rows && (reinterpret_cast<uintptr_t>(point_mask) & 7u) == 0) {
+                        wave_path = true;
+                        const unsigned long long bits = *reinterpret_cast<const unsigned long long*>(point_mask + row0);
+                        const unsigned off = (unsigned)row - row0;  // < 8 + 64 / Cp
+                        if (off < 8u) masked[k] = go[k] && ((bits >> (8u * off)) & 0xffull) != 0;
+                        else masked[k] = go[k] && point_mask[row] != 0;
+                    }
+                }
+                if (!wave_path && go[k]) masked[k] = point_mask[row] != 0;
+            }
         }
         if (go[k]) v[k] = NT ? pw_load_nt<T, VEC>(x + vi * VEC) : pw_load<T, VEC>(x + vi * VEC);
     }
@@ -1087,7 +1108,10 @@ static int pointwise_typed(const void* x_, void* y_, int64_t n_pts, int n_lev, i
 #define ATX_PW_UNIFORM_LAUNCH(TR_, U_, NT_)                                                                                                \
     hipLaunchKernelGGL((pointwise_cols_uniform_kernel<T, VEC, TR_, U_, NT_>), dim3((unsigned)((n_vec + kBlock * U_ - 1) / (kBlock * U_))), \
                        dim3(kBlock), 0, st, x, y, n_vec, C, Cp, uni, uses_mask ? mask : nullptr, need_rc, in_place, act_bits)
-                const bool nt = ATX_PW_UNIFORM_NT && !(uses_mask && mask);
+#ifndef ATX_PW_MASK_NT
+#define ATX_PW_MASK_NT 0
+#endif
+                const bool nt = ATX_PW_UNIFORM_NT && (ATX_PW_MASK_NT || !(uses_mask && mask));
                 if (in_place) {
                     if (trans && nt && ATX_PW_TRANS_NT) ATX_PW_UNIFORM_LAUNCH(true, ATX_PW_UNIFORM_U_IN, true);
                     else if (trans) ATX_PW_UNIFORM_LAUNCH(true, ATX_PW_UNIFORM_U_IN, false);
