@@ -646,6 +646,7 @@ def group_into_stacks(fields: Iterable[Any], positions: list[int] | None = None,
             else:
                 groups.append(StackGroup(select_levels(stack, levels), members, group_fields))
         else:
+            members, group_fields = _variables_together(members, group_fields)
             arrays = [host_values(f) for f in group_fields]
             dtype = _host_dtype(arrays)
             # long lists (config 4: thousands of fields on one grid) become several stacks of at most MAX_STACK_LEVELS:
@@ -655,6 +656,28 @@ def group_into_stacks(fields: Iterable[Any], positions: list[int] | None = None,
                 part = slice(first, first + MAX_STACK_LEVELS)
                 groups.append(StackGroup(Stack.from_fields(arrays[part], dtype=dtype, dev=_stack.device()), members[part], group_fields[part]))
     return groups
+
+
+def _variables_together(members: list[int], group_fields: list[Any]) -> tuple[list[int], list[Any]]:
+    """The fields of one host group with those of one ``param`` next to each other, otherwise in the order they came.
+
+    Which level of the stack a field becomes is internal (results go back to their positions in the list), so a list that comes
+    level by level — t, q, t, q, ... — is uploaded as "all levels of t, then all of q": a filter that treats the variables
+    differently (``convert`` on t, ``clip`` on q) then has a program of RUNS of levels, which the kernels take by value, instead of
+    one that changes at every level (per-level tables)."""
+    def name(f):
+        try:
+            return str(f.metadata("param"))
+        except Exception:  # noqa: BLE001 - fields without a param stay where they are
+            return ""
+
+    names = [name(f) for f in group_fields]
+    changes = sum(a != b for a, b in zip(names, names[1:]))
+    if changes < len(set(names)):  # already one run per variable
+        return members, group_fields
+    first_seen = {n: i for i, n in reversed(list(enumerate(names)))}
+    order = sorted(range(len(names)), key=lambda j: (first_seen[names[j]], j))
+    return [members[j] for j in order], [group_fields[j] for j in order]
 
 
 def fields_to_stack(fields: list[Any]) -> Stack:

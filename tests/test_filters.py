@@ -721,7 +721,13 @@ def test_long_field_lists_are_split_into_bounded_stacks(engine, monkeypatch):
     for i, s_ in enumerate(specs):
         s_["param"] = "t" if i % 3 else "q"
     groups = fields_module.group_into_stacks(list(test_source(specs)))
-    assert [g.stack.n_lev for g in groups] == [7, 7, 3] and [p for g in groups for p in g.positions] == list(range(17))
+    positions = [p for g in groups for p in g.positions]
+    assert [g.stack.n_lev for g in groups] == [7, 7, 3] and sorted(positions) == list(range(17))
+    # inside the stacks the fields of one variable sit next to each other (a list that alternates between variables would give a
+    # per-variable filter a program that changes at every level; this way it has one run per variable) — which level a field becomes
+    # is internal: the results below come back in the order of the list
+    assert [specs[p]["param"] for p in positions] == ["q"] * 6 + ["t"] * 11
+    assert positions == [p for p in range(17) if p % 3 == 0] + [p for p in range(17) if p % 3]
     regrid = create_filter_by_name("regrid", in_grid="o16", out_grid=[10.0, 10.0], method="nearest")
     rescale = create_filter_by_name("rescale", scale=2.0, offset=1.0, param="t")
     out = list(test_source(specs) | regrid | rescale)

@@ -237,7 +237,7 @@ def test_sparse_selection_on_a_device_stack_keeps_levels_in_place(engine):
     assert new_stack is not stack and new_stack.n_lev == stack.n_lev
     for i, f in enumerate(out):
         if specs[i]["param"] == "t":
-            assert f.stack_ref() == (new_stack, i)  # same level index in the new stack: no compaction copy
+            assert f.stack_ref() == (new_stack, on_device[i].stack_ref()[1])  # same level of the new stack as of the old one: no compaction copy
             assert np.array_equal(f.to_numpy(), oracle.rescale_forward(on_device[i].to_numpy(), 2.0, -1.0), equal_nan=True)
         else:
             assert f is on_device[i]
@@ -279,3 +279,31 @@ def test_fused_mask_only_meets_the_fields_it_masks_two_grids(engine, tmp_path, m
         assert np.array_equal(a.to_numpy(), b.to_numpy(), equal_nan=True)
     assert np.array_equal(fused[0].to_numpy(), oracle.rescale_forward(specs[0]["values"], 2.0, 1.0))
     assert np.array_equal(np.isnan(fused[2].to_numpy()), mask_b.astype(bool))
+
+
+def test_a_list_that_alternates_between_variables_becomes_runs_of_levels(engine):
+    """A FieldList that comes level by level (t, q, t, q, ...) is uploaded with the fields of one variable next to each other, so a
+    filter chain that treats the variables differently compiles to a program of RUNS of levels (the by-value routes of the kernels)
+    instead of one that changes at every level — and the results still come back in the order of the list."""
+    from anemoi_transform_amd.filters import fusion
+
+    src, tgt = lookup("o16"), lookup([20.0, 20.0])
+    specs = synthetic_fields(src, 12)
+    for i, s_ in enumerate(specs):
+        s_["param"] = ("t", "q", "orog")[i % 3]
+        s_["levelist"] = i // 3
+    regrid = create_filter_by_name("regrid", in_grid="o16", out_grid=tgt, method="nearest")
+    convert = create_filter_by_name("convert", unit_in="K", unit_out="degC", param="t")
+    orog = create_filter_by_name("orog_to_z_fields")
+    on_device = regrid.forward(test_source(specs).ds)
+    levels = [f.stack_ref()[1] for f in on_device]
+    by_param = {p: sorted(l for l, s_ in zip(levels, specs) if s_["param"] == p) for p in ("t", "q", "orog")}
+    assert all(v == list(range(v[0], v[0] + 4)) for v in by_param.values())  # four consecutive levels per variable
+    out = list(test_source(specs) | regrid | convert | orog)
+    want = oracle.filter_regrid_nearest([dict(s_) for s_ in specs], in_grid=src, out_grid=tgt)
+    for f, w, s_ in zip(out, want, specs):
+        v = np.asarray(w["values"]).ravel()
+        v = oracle.rescale_forward(v, 1.0, -273.15) if s_["param"] == "t" else (oracle.orog_to_z(v) if s_["param"] == "orog" else v)
+        assert f.metadata("levelist") == s_["levelist"] and f.metadata("param") == ("z" if s_["param"] == "orog" else s_["param"])
+        assert np.array_equal(f.to_numpy(flatten=True), v, equal_nan=True)
+    assert fusion is not None
