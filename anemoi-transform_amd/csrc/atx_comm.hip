@@ -3,6 +3,8 @@
 // The regrid path shards on TARGET POINTS with no collective in the data path; the only exchange is
 // the SOURCE stack reaching every rank once.  Three shapes of that exchange are exported:
 //   atx_bcast          — the whole pitched stack from the rank that holds it (one ncclBroadcast)
+//   atx_all_gather     — every rank's stack onto every rank in ONE collective (ncclAllGather): the N-broadcast exchange of a job in
+//                        which every rank contributes a stack, with every xGMI link busy at once
 //   atx_exchange       — band-limited: every rank sends each peer only the slab of source columns that peer's target
 //                        slice references and receives its own slabs (grouped ncclSend / ncclRecv)
 //   atx_gather_shards  — the per-rank target slices assembled on every rank for callers that want the full field
@@ -35,6 +37,7 @@ struct Rccl {
     atx_ncclCommDestroy_t CommDestroy = nullptr;
     atx_ncclGetErrorString_t GetErrorString = nullptr;
     atx_ncclBroadcast_t Broadcast = nullptr;
+    atx_ncclAllGather_t AllGather = nullptr;
     atx_ncclSend_t Send = nullptr;
     atx_ncclRecv_t Recv = nullptr;
     atx_ncclGroup_t GroupStart = nullptr;
@@ -67,6 +70,7 @@ static void load_rccl() {
     const bool ok = bind(r.handle, "ncclGetVersion", r.GetVersion) && bind(r.handle, "ncclGetUniqueId", r.GetUniqueId) &&
                     bind(r.handle, "ncclCommInitRank", r.CommInitRank) && bind(r.handle, "ncclCommDestroy", r.CommDestroy) &&
                     bind(r.handle, "ncclGetErrorString", r.GetErrorString) && bind(r.handle, "ncclBroadcast", r.Broadcast) &&
+                    bind(r.handle, "ncclAllGather", r.AllGather) &&
                     bind(r.handle, "ncclSend", r.Send) && bind(r.handle, "ncclRecv", r.Recv) &&
                     bind(r.handle, "ncclGroupStart", r.GroupStart) && bind(r.handle, "ncclGroupEnd", r.GroupEnd);
     if (!ok) {
@@ -158,6 +162,15 @@ extern "C" int atx_bcast(atx_comm* comm, void* buf, int64_t n_bytes, int32_t roo
     if (n_bytes == 0) return ATX_OK;
     ATX_RCCL_OR_FAIL(r);
     return comm_status(r->Broadcast(buf, buf, (size_t)n_bytes, kNcclChar, root, comm->comm, static_cast<hipStream_t>(stream)), "ncclBroadcast");
+}
+
+extern "C" int atx_all_gather(atx_comm* comm, const void* send, void* recv, int64_t bytes_per_rank, void* stream) {
+    ATX_REQUIRE(comm, ATX_EINVAL, "atx_all_gather: null communicator");
+    ATX_REQUIRE(bytes_per_rank >= 0 && ((send && recv) || bytes_per_rank == 0), ATX_EINVAL, "atx_all_gather: bad buffers (bytes_per_rank=%lld)",
+                (long long)bytes_per_rank);
+    if (bytes_per_rank == 0) return ATX_OK;
+    ATX_RCCL_OR_FAIL(r);
+    return comm_status(r->AllGather(send, recv, (size_t)bytes_per_rank, kNcclChar, comm->comm, static_cast<hipStream_t>(stream)), "ncclAllGather");
 }
 
 extern "C" int atx_exchange(atx_comm* comm, const void* const* send_ptrs, const int64_t* send_bytes, void* const* recv_ptrs,

@@ -23,6 +23,7 @@ typedef ncclResult_t (*atx_ncclCommInitRank_t)(ncclComm_t*, int, ncclUniqueId, i
 typedef ncclResult_t (*atx_ncclCommDestroy_t)(ncclComm_t);
 typedef const char* (*atx_ncclGetErrorString_t)(ncclResult_t);
 typedef ncclResult_t (*atx_ncclBroadcast_t)(const void*, void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t);
+typedef ncclResult_t (*atx_ncclAllGather_t)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t);
 typedef ncclResult_t (*atx_ncclSend_t)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t);
 typedef ncclResult_t (*atx_ncclRecv_t)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t);
 typedef ncclResult_t (*atx_ncclGroup_t)(void);

@@ -125,16 +125,17 @@ def exchange_stacks(mine: Stack, comm=None, collective: str = "broadcast") -> li
     (the "source broadcast once" step of a target-sharded job).
 
     ``collective="broadcast"`` (default): ``world`` broadcasts, one per contributing rank, each usable as soon as it has landed (what the
-    double-buffered step pipelines).  ``collective="all_gather"`` (torch.distributed transport): ONE all-gather into a single buffer of
+    double-buffered step pipelines).  ``collective="all_gather"``: ONE all-gather (``all_gather_into_tensor`` / ``atx_all_gather``) into a single buffer of
     ``world`` stacks — on a fully connected xGMI node every link carries its share at once, where a chain of broadcasts is paced by the
     root's route each time; the stacks returned are views of that buffer."""
     rank, world = _rank_world(comm)
     if collective == "all_gather":
-        if comm is not None:
-            raise NotImplementedError("the C-ABI communicator exchanges whole stacks by broadcast (atx_bcast); all_gather runs on torch.distributed")
         rows = mine.data.shape[0]  # (concatenated along the rows: the output form every backend accepts)
         buf = torch.empty((world * rows, mine.data.shape[1]), dtype=mine.data.dtype, device=mine.data.device)
-        dist.all_gather_into_tensor(buf, mine.data.contiguous(), group=_data_group)
+        if comm is not None:
+            comm.all_gather(mine.data.contiguous(), buf)  # atx_all_gather: ncclAllGather through the C ABI
+        else:
+            dist.all_gather_into_tensor(buf, mine.data.contiguous(), group=_data_group)
         return [Stack(buf[r * rows:(r + 1) * rows], mine.n_pts, mine.n_lev, mine.layout) for r in range(world)]
     if collective != "broadcast":
         raise ValueError(f"collective must be 'broadcast' or 'all_gather', got {collective!r}")

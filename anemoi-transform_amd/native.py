@@ -114,6 +114,7 @@ SIGNATURES: dict[str, tuple[Any, list[Any]]] = {
     "atx_comm_rank": (c_int, [c_void_p]),
     "atx_comm_world": (c_int, [c_void_p]),
     "atx_bcast": (c_int, [c_void_p, c_void_p, c_int64, c_int32, c_void_p]),
+    "atx_all_gather": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
     "atx_exchange": (c_int, [c_void_p, POINTER(c_void_p), POINTER(c_int64), POINTER(c_void_p), POINTER(c_int64), c_void_p]),
     "atx_gather_shards": (c_int, [c_void_p, c_void_p, POINTER(c_int64), c_void_p]),
 }
@@ -569,6 +570,13 @@ class Comm:
         """``t`` (contiguous, in HBM) of rank ``root`` onto every rank, in place."""
         assert t.is_contiguous()
         _call("atx_bcast", self._handle, _ptr(t), t.numel() * t.element_size(), int(root), _stream())
+
+    def all_gather(self, mine: torch.Tensor, everyone: torch.Tensor) -> None:
+        """``mine`` (contiguous) of every rank into ``everyone`` (``world`` times its size): slot ``p`` holds rank ``p``'s."""
+        assert mine.is_contiguous() and everyone.is_contiguous()
+        n_bytes = mine.numel() * mine.element_size()
+        assert everyone.numel() * everyone.element_size() == self.world * n_bytes
+        _call("atx_all_gather", self._handle, _ptr(mine), _ptr(everyone), n_bytes, _stream())
 
     def exchange(self, send: list, recv: list) -> None:
         """``send[p]`` goes to rank ``p``, ``recv[p]`` is filled by rank ``p``; ``None`` / empty tensors skip the pair."""

@@ -754,6 +754,11 @@ def multi_gpu_lines(args, result, dist, rank, world, dev, plan, stacks, outs, la
             got, ms = timed(lambda: atxd.exchange_stacks(mine, comm=comm))
             return {"ms": ms, "verified_bit_equal": all(torch.equal(g.data, s.data) for g, s in zip(got, stacks))}
 
+        def c_abi_all_gather():
+            comm = holder["comm"]
+            got, ms = timed(lambda: atxd.exchange_stacks(mine, comm=comm, collective="all_gather"))
+            return {"ms": ms, "verified_bit_equal": all(torch.equal(g.data, s.data) for g, s in zip(got, stacks))}
+
         def c_abi_bands():
             comm = holder["comm"]
             (got, local_plan), ms = timed(lambda: atxd.exchange_source_bands(mine, plan, comm=comm))
@@ -770,6 +775,9 @@ def multi_gpu_lines(args, result, dist, rank, world, dev, plan, stacks, outs, la
         c_abi["init"] = section("c_abi init", c_abi_init)
         if "error" not in c_abi["init"] and "skipped" not in c_abi["init"]:  # (the same on every rank: `section` agrees on both)
             c_abi["broadcast"] = section("c_abi broadcast", c_abi_broadcast)
+            torch.cuda.empty_cache()
+            c_abi["all_gather"] = section("c_abi all_gather", c_abi_all_gather)
+            torch.cuda.empty_cache()
             c_abi["bands"] = section("c_abi bands", c_abi_bands)
             c_abi["end_to_end"] = section("c_abi end_to_end", c_abi_end_to_end)
             try:

@@ -355,6 +355,7 @@ int atx_cutout_inside(const double* global_xyz, int64_t n, const double* lam_xyz
  * contiguous slice of the target points (R: filters/fields/regrid.py:204-208 is a single-process loop — there is no
  * reference counterpart).  What has to travel is the SOURCE stack, once:
  *   atx_bcast          the whole pitched stack from its owner ("source broadcast once")
+ *   atx_all_gather     every rank's stack onto every rank in one collective
  *   atx_exchange       or only the slab of source columns each peer's target slice references (ATX_COLUMNS: a
  *                      contiguous byte range), grouped send/recv — about 1/world of the bytes for lat-lon targets
  *   atx_gather_shards  optionally the target slices back onto every rank
@@ -374,6 +375,10 @@ int atx_comm_rank(const atx_comm* comm);
 int atx_comm_world(const atx_comm* comm);
 /* buf[0..n_bytes) of rank `root` onto every rank, in place. */
 int atx_bcast(atx_comm* comm, void* buf, int64_t n_bytes, int32_t root, void* stream);
+/* Every rank contributes send[0..bytes_per_rank); afterwards recv[p * bytes_per_rank ...) holds rank p's contribution on every rank
+ * (recv: world * bytes_per_rank bytes; send may be the rank's own slot of recv).  The whole-stack exchange of a job in which every
+ * rank owns one source stack, as ONE collective instead of `world` broadcasts. */
+int atx_all_gather(atx_comm* comm, const void* send, void* recv, int64_t bytes_per_rank, void* stream);
 /* send_ptrs / send_bytes / recv_ptrs / recv_bytes: HOST arrays of `world` entries, one per peer; entry p of the send
  * side goes to rank p, entry p of the receive side is filled by rank p (byte counts must match pairwise across ranks;
  * zero skips the pair; the own entry is a device-to-device copy). */

@@ -134,6 +134,7 @@ static void collectives(void) {
     CHECK(atx_bcast(NULL, one, 16, 0, NULL) == ATX_EINVAL);
     CHECK(strstr(atx_last_error(), "communicator") != NULL);
     CHECK(atx_exchange(NULL, NULL, NULL, NULL, NULL, NULL) == ATX_EINVAL);
+    CHECK(atx_all_gather(NULL, one, one, 16, NULL) == ATX_EINVAL);
     CHECK(atx_gather_shards(NULL, one, NULL, NULL) == ATX_EINVAL);
     CHECK(atx_comm_destroy(NULL) == ATX_OK);
     CHECK(atx_comm_rank(NULL) == ATX_EINVAL && atx_comm_world(NULL) == ATX_EINVAL);

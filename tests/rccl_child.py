@@ -66,6 +66,8 @@ def main() -> None:
     checks["broadcast_stack"] = bool(np.array_equal(got.numpy(), host))
     stacks = atxd.exchange_stacks(mine, comm=comm)
     checks["exchange_stacks"] = len(stacks) == 1 and bool(np.array_equal(stacks[0].numpy(), host))
+    gathered = atxd.exchange_stacks(mine, comm=comm, collective="all_gather")  # all_gather_into_tensor / atx_all_gather on real RCCL
+    checks["all_gather"] = len(gathered) == 1 and bool(np.array_equal(gathered[0].numpy(), host))
     bands, local_plan = atxd.exchange_source_bands(mine, plan, comm=comm)
     checks["exchange_source_bands"] = bool(np.array_equal(local_plan.apply(bands[0]).numpy(), want))
     piped = atxd.pipelined_sharded_regrid(plan, mine, comm=comm)

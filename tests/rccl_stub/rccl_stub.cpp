@@ -259,6 +259,23 @@ ncclResult_t ncclBroadcast(const void* send, void* recv, size_t count, ncclDataT
     return submit(std::move(ops));
 }
 
+ncclResult_t ncclAllGather(const void* send, void* recv, size_t count, ncclDataType_t, ncclComm_t comm, hipStream_t stream) {
+    // every rank sends its block to every peer and receives every peer's block into that peer's slot
+    Comm* c = reinterpret_cast<Comm*>(comm);
+    char* out = static_cast<char*>(recv);
+    std::vector<Op> ops;
+    for (int p = 0; p < c->world; ++p) {
+        if (p == c->rank) continue;
+        ops.push_back(Op{0, c, send, nullptr, count, p, stream});
+        ops.push_back(Op{1, c, nullptr, out + (size_t)p * count, count, p, stream});
+    }
+    char* own = out + (size_t)c->rank * count;
+    if (send != own && count) {
+        if (hipMemcpyAsync(own, send, count, hipMemcpyDeviceToDevice, stream) != hipSuccess) return 1;
+    }
+    return submit(std::move(ops));
+}
+
 ncclResult_t ncclGroupStart(void) {
     ++g_group_depth;
     return 0;

@@ -57,6 +57,10 @@ def main() -> None:
     stacks = atxd.exchange_stacks(mine, comm=comm)
     checks["exchange_stacks"] = len(stacks) == world and all(np.array_equal(st.numpy(), stack_of(r)) for r, st in enumerate(stacks))
 
+    # 1b. the same exchange as ONE all-gather (atx_all_gather)
+    gathered = atxd.exchange_stacks(mine, comm=comm, collective="all_gather")
+    checks["all_gather"] = len(gathered) == world and all(np.array_equal(st.numpy(), stack_of(r)) for r, st in enumerate(gathered))
+
     # 2. band-limited exchange (atx_exchange: grouped send / recv, a different byte count per peer pair)
     bands, local_plan = atxd.exchange_source_bands(mine, plan, comm=comm)
     b_lo, b_hi = atxd.source_band(plan.shard(rank, world))

@@ -158,7 +158,7 @@ def test_multi_gpu_sections_on_real_rccl_at_world_1():
     assert_mirrored(d)
     c = ex["c_abi"]
     assert c["init"]["rccl_version"] >= 20000
-    for name in ("broadcast", "bands", "end_to_end"):
+    for name in ("broadcast", "all_gather", "bands", "end_to_end"):
         assert c[name]["verified_bit_equal"] is True, c
 
 

@@ -16,7 +16,7 @@ import pytest
 pytestmark = pytest.mark.gpu
 HERE = os.path.dirname(os.path.abspath(__file__))
 
-EXPECTED = ["broadcast_stack", "exchange_stacks", "exchange_source_bands", "pipelined_sharded_regrid", "pipelined_repeat_10",
+EXPECTED = ["broadcast_stack", "exchange_stacks", "all_gather", "exchange_source_bands", "pipelined_sharded_regrid", "pipelined_repeat_10",
             "gather_target_shards", "p2p_self"]
 
 

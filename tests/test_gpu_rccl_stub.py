@@ -20,7 +20,7 @@ pytestmark = pytest.mark.gpu
 HERE = os.path.dirname(os.path.abspath(__file__))
 STUB_DIR = os.path.join(HERE, "rccl_stub")
 STUB = os.path.join(STUB_DIR, "librccl_stub.so")
-EXPECTED = ["exchange_stacks", "exchange_source_bands", "pipelined_sharded_regrid", "gather_target_shards", "raw_exchange"]
+EXPECTED = ["exchange_stacks", "all_gather", "exchange_source_bands", "pipelined_sharded_regrid", "gather_target_shards", "raw_exchange"]
 
 
 @pytest.fixture(scope="module")

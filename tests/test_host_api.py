@@ -464,6 +464,7 @@ def test_abi_argument_validation_without_a_gpu():
     handle = ctypes.c_void_p()
     assert lib.atx_comm_init(ctypes.byref(handle), 2, 5, one) == native.EINVAL and b"rank 5" in lib.atx_last_error()
     assert lib.atx_exchange(None, None, None, None, None, None) == native.EINVAL
+    assert lib.atx_all_gather(None, one, one, 16, None) == native.EINVAL
     assert lib.atx_gather_shards(None, one, None, None) == native.EINVAL
     assert lib.atx_comm_destroy(None) == native.OK and lib.atx_comm_rank(None) == native.EINVAL
     assert lib.atx_strerror(native.ECOMM).startswith(b"RCCL")
