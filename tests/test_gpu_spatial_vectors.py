@@ -71,3 +71,43 @@ def test_global_on_lam_mask_device(dev, case):
     indices = spatial.global_on_lam_mask(lats, lons, glob["latitudes"], glob["longitudes"], distance_km=case["distance_km"], device=True)
     want = VECTORS.file[case["key"]]
     assert indices.shape == want.shape and np.array_equal(indices, want)
+
+
+import os  # noqa: E402
+
+_FIRST, _COUNT = (int(v) for v in os.environ.get("ATX_SPATIAL_SEEDS", "0:4").split(":"))
+
+
+@pytest.mark.parametrize("seed", range(_FIRST, _FIRST + _COUNT))
+def test_device_builders_equal_the_host_builders_on_random_patches(dev, seed):
+    """Beyond the fixed vectors: random limited-area patches (regular or jittered, anywhere on the globe, either longitude convention)
+    in O48 / regular global grids — the device builders against the host builders, which the reference-run vectors pin
+    (ATX_SPATIAL_SEEDS=first:count widens the sweep)."""
+    from anemoi_transform_amd.grids import lookup
+
+    rng = np.random.default_rng(9000 + seed)
+    glob = lookup("o48") if rng.random() < 0.6 else lookup([2.5, 2.5])
+    lat0, lon0 = float(rng.uniform(-80, 60)), float(rng.uniform(-180, 340))
+    step = float(rng.choice([0.5, 0.75, 1.25]))
+    lats, lons = np.meshgrid(np.arange(lat0, min(lat0 + rng.uniform(8, 25), 89.0), step), np.arange(lon0, lon0 + rng.uniform(8, 40), step), indexing="ij")
+    lats, lons = lats.reshape(-1).copy(), lons.reshape(-1).copy()
+    if rng.random() < 0.6:
+        lats += rng.normal(0, 0.05, lats.shape)
+        lons += rng.normal(0, 0.05, lons.shape)
+    if rng.random() < 0.3:
+        lons = np.where(lons > 180, lons - 360, lons)
+    glat, glon = glob["latitudes"], glob["longitudes"]
+    for options in ({}, {"min_distance_km": float(rng.uniform(20, 200))}, {"max_distance_km": float(rng.uniform(200, 900))},
+                    {"neighbours": int(rng.integers(3, 10)), "cropping_distance": float(rng.uniform(0.5, 4.0))}):
+        host = spatial.cutout_mask(lats, lons, glat.copy(), glon.copy(), **options)
+        device = spatial.cutout_mask(lats, lons, glat.copy(), glon.copy(), device=True, **options)
+        assert np.array_equal(host, device), (seed, options, np.flatnonzero(host != device)[:5])
+    assert np.array_equal(spatial.thinning_mask(lats, lons, glat, glon), spatial.thinning_mask(lats, lons, glat, glon, device=True))
+    for distance_km in (float(rng.uniform(30, 150)), "lam", None):
+        assert np.array_equal(spatial.global_on_lam_mask(lats, lons, glat, glon, distance_km=distance_km),
+                              spatial.global_on_lam_mask(lats, lons, glat, glon, distance_km=distance_km, device=True)), (seed, distance_km)
+    k = int(rng.integers(1, 9))
+    hi, hd = interp.nearest_grid_points(lats, lons, glat, glon, num_neighbours_to_return=k, return_distances=True)
+    interp.knn_cache_clear(disk=True)
+    di, dd = interp.nearest_grid_points_device(lats, lons, glat, glon, num_neighbours_to_return=k, return_distances=True)
+    assert np.array_equal(hi, di) and np.array_equal(hd, dd), (seed, k)
