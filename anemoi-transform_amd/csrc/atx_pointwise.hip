@@ -811,8 +811,9 @@ __global__ void reduce_init_kernel(double* result, int red) {
 // workgroup, ONE atomic per workgroup (a per-wave atomic on a single address serialised 100 k of them on large inputs).
 constexpr int kRedUnroll = 4;
 #ifndef ATX_RED_GRID
-#define ATX_RED_GRID 8192
-#endif
+#define ATX_RED_GRID 32768  // workgroup cap = partial slots of the two-level finish.  Round 3 compared 8192 with SMALLER caps only; round 4, 137 levels of O1280, two
+#endif                      // interleaved rounds: 32768 f64 min+max 0.707 -> 0.74, NaN count f32 0.70 -> 0.74, f64 0.715 -> 0.76; f32 min+max unchanged (0.68);
+                            // 65536 loses (f32 min+max 0.60).  One field: unchanged (its grid is far below either cap).  profiles/r04_reduce_grid.log
 constexpr int64_t kRedGrid = ATX_RED_GRID;
 
 __device__ __forceinline__ double red_combine(double a, double b, int red) {
