@@ -595,7 +595,9 @@ static inline bool runs_level_program(const atx_level_op* host_prog, int n_stage
 }
 
 // All stages of a RunOps program applied to the vector of levels c*VEC .. c*VEC+VEC-1 (scalar loop bounds and branches: the runs
-// are uniform over the launch; the per-element choice is a select).
+// are uniform over the launch; the per-element choice is a select).  Every run is evaluated, COPY runs included: skipping them behind a
+// scalar branch was tried and LOST — the fused regrid of a 411-level O2560 stack 2.89 -> 3.08 ms (float64), 1.45 -> 1.57 ms (float32), the
+// per-point kernel unchanged: the branches keep the compiler from loading the operators ahead of the gather (profiles/r04_runs_probe.log).
 template <typename T, int VEC, bool TRANS = true>
 __device__ __forceinline__ void apply_run_ops(const RunOps<T>& runs, int c, Pack<T, VEC>& v, bool masked) {
     using V = Pack<T, VEC>;

@@ -1137,7 +1137,10 @@ static int pointwise_typed(const void* x_, void* y_, int64_t n_pts, int n_lev, i
             // table and per-level kernels — except for float32 programs of two or more stages, which those kernels run at 0.52-0.58 and this one
             // at 0.65-0.66.  So only they take it.
             RunOps<T> runs{};
-            if (ATX_PW_RUNS && sizeof(T) == 4 && n_stage >= 2 && (n_vec + kBlock - 1) / kBlock <= 0x7fffffffll &&
+#ifndef ATX_PW_RUNS_ALL
+#define ATX_PW_RUNS_ALL 0  // A/B: every run-structured program on the runs kernel
+#endif
+            if (ATX_PW_RUNS && (ATX_PW_RUNS_ALL || (sizeof(T) == 4 && n_stage >= 2)) && (n_vec + kBlock - 1) / kBlock <= 0x7fffffffll &&
                 runs_level_program<T>(host_prog, n_stage, mask != nullptr, n_lev, runs)) {
                 bool uses_mask = false;
                 for (int s = 0; s < n_stage; ++s)
