@@ -103,7 +103,8 @@ def main():
     n, nt = len(src["latitudes"]), len(tgt["latitudes"])
     idx16, w16 = interp.knn_inverse_distance(src, tgt, k=16, device=True, ties="index")
     idx4, w4 = idx16[:, :4], w16[:, :4] / w16[:, :4].sum(axis=1, keepdims=True)
-    x = bench.synth_stack(src, 137, torch.float32, dev, 0, COLUMNS)
+    dtype = torch.float64 if os.environ.get("ATX_PROBE_DTYPE", "f32") == "f64" else torch.float32  # the same three cases in the headline's own width
+    x = bench.synth_stack(src, 137, dtype, dev, 0, COLUMNS)
     plans = [GatherPlan(n, nt, index=idx4, weights=w4), GatherPlan(n, nt, index=idx16, weights=w16), GatherPlan(n, nt, index=idx16, weights=w16)]
     plans[2].order_targets(target_order_for(tgt["latitudes"], tgt["longitudes"], 16))
     for plan in plans:

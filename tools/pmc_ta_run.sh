@@ -5,7 +5,7 @@
 set -e
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-OUT=$R/gpurun_out/pmc_ta
+OUT=$R/gpurun_out/pmc_ta${ATX_PROBE_DTYPE:+_$ATX_PROBE_DTYPE}
 rm -rf $OUT && mkdir -p $OUT
 timeout -k 10 120 rocprofv3 -L > $R/gpurun_out/r04_rocprofv3_list_avail.txt 2>&1 || echo "rocprofv3 -L failed (list kept)"
 i=0
@@ -18,9 +18,9 @@ for SET in "TA_TA_BUSY GRBM_GUI_ACTIVE" \
            "TA_ADDR_STALLED_BY_TD_CYCLES TA_TOTAL_WAVEFRONTS GRBM_GUI_ACTIVE" \
            "TD_TD_BUSY TD_TC_STALL GRBM_GUI_ACTIVE"; do
   i=$((i+1))
-  timeout -k 10 300 rocprofv3 --pmc $SET --kernel-trace --output-format csv -d $OUT/$i -- python3 $R/tools/pmc_gather_probe.py > $R/gpurun_out/pmc_ta_$i.log 2>&1 || { tail -5 $R/gpurun_out/pmc_ta_$i.log; echo "pass $i FAILED: $SET"; FAILED=1; break; }
+  timeout -k 10 300 rocprofv3 --pmc $SET --kernel-trace --output-format csv -d $OUT/$i -- python3 $R/tools/pmc_gather_probe.py > $R/gpurun_out/pmc_ta${ATX_PROBE_DTYPE:+_$ATX_PROBE_DTYPE}_$i.log 2>&1 || { tail -5 $R/gpurun_out/pmc_ta${ATX_PROBE_DTYPE:+_$ATX_PROBE_DTYPE}_$i.log; echo "pass $i FAILED: $SET"; FAILED=1; break; }
   echo "pass $i done: $SET"
 done
-python3 $R/tools/pmc_gather_probe.py --summarize $OUT > $R/gpurun_out/r04_pmc_ta_counters.txt
-cat $R/gpurun_out/r04_pmc_ta_counters.txt
+python3 $R/tools/pmc_gather_probe.py --summarize $OUT > $R/gpurun_out/r04_pmc_ta_counters${ATX_PROBE_DTYPE:+_$ATX_PROBE_DTYPE}.txt
+cat $R/gpurun_out/r04_pmc_ta_counters${ATX_PROBE_DTYPE:+_$ATX_PROBE_DTYPE}.txt
 exit $FAILED
