@@ -171,6 +171,36 @@ def main() -> int:
                     "rows_with_equal_adjacent_distances": int(np.sum((d[:, :-1] == d[:, 1:]).any(axis=1))) if k > 1 else 0,
                 })
 
+    # ---- the two regrid statements on the reference's own index tables -------------------------------------------------------------
+    # R: filters/fields/regrid.py:380 `data[..., nearest_grid_points]` and :310 `csr_array(...) @ data` cannot be reached through the
+    # reference's filter classes here (they import earthkit / anemoi.utils), but their INPUT — the index table — is the reference's own
+    # (nearest_grid_points above), and the statements themselves are numpy / scipy calls: recorded on a seeded field so that the GPU
+    # path is held to vectors whose indices and distances come from the reference (k = 4: inverse-distance weights w = (1/max(d, 1e-12)) / sum,
+    # SURVEY.md §8d).
+    from scipy.sparse import csr_array
+
+    manifest["regrid"] = []
+    for pair in ("o32_to_5deg", "o96_to_1deg"):
+        src_spec, tgt_spec, _ = KNN_PAIRS[pair]
+        src, tgt = lookup(src_spec), lookup(tgt_spec)
+        n_src, n_tgt = len(src["latitudes"]), len(tgt["latitudes"])
+        seed = 20260630
+        rng = np.random.default_rng(seed)
+        lat, lon = np.deg2rad(src["latitudes"]), np.deg2rad(src["longitudes"])
+        n_levels = 3 if n_tgt < 10000 else 1  # (one level of the larger pair keeps the file small)
+        fields = np.stack([280.0 + 30.0 * np.sin(lat) * np.cos(2.0 * lon + 0.1 * l) + rng.standard_normal(n_src) for l in range(n_levels)])
+        idx1 = arrays[f"ngp/{pair}/k1/unbounded/idx"].astype(np.int64)
+        idx4 = arrays[f"ngp/{pair}/k4/unbounded/idx"].astype(np.int64)
+        dist4 = arrays[f"ngp/{pair}/k4/unbounded/dist"]
+        inv = 1.0 / np.maximum(dist4, 1e-12)
+        weights = inv / inv.sum(axis=1, keepdims=True)
+        matrix = csr_array((weights.reshape(-1), idx4.reshape(-1).astype(np.int32), (np.arange(n_tgt + 1) * 4).astype(np.int32)), shape=(n_tgt, n_src))
+        key = f"regrid/{pair}"
+        arrays[key + "/nearest"] = np.stack([f[..., idx1] for f in fields])
+        arrays[key + "/knn4"] = np.stack([matrix @ f for f in fields])
+        manifest["regrid"].append({"key": key, "pair": pair, "source": src_spec, "target": tgt_spec, "seed": seed, "levels": n_levels,
+                                   "field": "280 + 30 sin(lat) cos(2 lon + 0.1 l) + default_rng(seed).standard_normal(n_src), level by level"})
+
     # ---- the limited-area builders ---------------------------------------------------------------------------------------------
     patches = lam_patches()
     for name, (lats, lons, global_spec) in patches.items():
@@ -235,7 +265,7 @@ def main() -> int:
         return 0
     np.savez_compressed(OUT, **arrays)
     print(f"wrote {OUT}: {len(arrays)} arrays, {os.path.getsize(OUT) / 1e6:.2f} MB")
-    for section in ("nearest_grid_points", "cutout_mask", "thinning_mask", "global_on_lam_mask", "cropping_mask", "cutout_mask_errors"):
+    for section in ("nearest_grid_points", "regrid", "cutout_mask", "thinning_mask", "global_on_lam_mask", "cropping_mask", "cutout_mask_errors"):
         print(f"  {section}: {len(manifest[section])} cases")
     return 0
 

@@ -111,3 +111,34 @@ def test_device_builders_equal_the_host_builders_on_random_patches(dev, seed):
     interp.knn_cache_clear(disk=True)
     di, dd = interp.nearest_grid_points_device(lats, lons, glat, glon, num_neighbours_to_return=k, return_distances=True)
     assert np.array_equal(hi, di) and np.array_equal(hd, dd), (seed, k)
+
+
+@pytest.mark.parametrize("case", MANIFEST["regrid"], ids=ids(MANIFEST["regrid"]))
+def test_regrid_filter_on_reference_tables(dev, case, tmp_path):
+    """The `regrid` filter on the MI355X against outputs recorded from the reference's statements on the reference's own index tables:
+    `method="nearest"` (R: regrid.py:380; the filter builds its table itself — device or host search — and must land on the same
+    indices) and `matrix=` with the k = 4 inverse-distance matrix of the recorded distances (R: regrid.py:310) — float64, bit for bit."""
+    from anemoi_transform_amd.fields import fieldlist_from_dicts
+    from anemoi_transform_amd.filters import create_filter_by_name
+    from test_spatial_vectors import regrid_case_inputs
+
+    fields, idx1, idx4, weights = regrid_case_inputs(case)
+    src = VECTORS.grid(case["source"] if isinstance(case["source"], str) else "x".join(str(v) for v in case["source"]))
+    specs = [{"param": "t", "levelist": l, "values": f, "latitudes": src["latitudes"], "longitudes": src["longitudes"]} for l, f in enumerate(fields)]
+    for engine in ("ckdtree", "device"):
+        interp.set_knn_engine(engine)
+        try:
+            out = create_filter_by_name("regrid", in_grid=case["source"], out_grid=case["target"], method="nearest").forward(fieldlist_from_dicts(specs))
+        finally:
+            interp.set_knn_engine(None)
+        got = np.stack([f.to_numpy(flatten=True) for f in out])
+        assert got.dtype == np.float64 and np.array_equal(got, VECTORS.file[case["key"] + "/nearest"]), engine
+    n_tgt, n_src = idx4.shape[0], fields.shape[1]
+    path = str(tmp_path / "knn4.npz")
+    tgt = VECTORS.grid(case["target"] if isinstance(case["target"], str) else "x".join(str(v) for v in case["target"]))
+    matrix = dict(matrix_data=weights.reshape(-1), matrix_indices=idx4.reshape(-1).astype(np.int32), matrix_indptr=(np.arange(n_tgt + 1) * 4).astype(np.int32),
+                  matrix_shape=np.array([n_tgt, n_src]))
+    interp.save_matrix_npz(path, matrix, src, tgt)  # the reference's file layout (R: regrid.py:281-290)
+    out = create_filter_by_name("regrid", matrix=path).forward(fieldlist_from_dicts(specs))
+    got = np.stack([f.to_numpy(flatten=True) for f in out])
+    assert np.array_equal(got, VECTORS.file[case["key"] + "/knn4"])

@@ -161,3 +161,28 @@ def test_a_regrid_mask_built_from_the_vectors_selects_those_points():
     indices = VECTORS.file[case["key"]].astype(np.int64)
     picked = oracle.masked_subset(glob["latitudes"], indices)
     assert picked.shape == (case["n"],) and picked.min() > 33.0 and picked.max() < 57.0
+
+
+# ---- the two regrid statements on the reference's own index tables (R: regrid.py:380, :310) -------------------------------------
+def regrid_case_inputs(case):
+    """(source fields, k = 1 indices, k = 4 indices, k = 4 inverse-distance weights) of a `regrid` case: the field is regenerated from its seed,
+    the tables are the reference-run `nearest_grid_points` vectors of the same file."""
+    src = VECTORS.grid(case["source"] if isinstance(case["source"], str) else "x".join(str(v) for v in case["source"]))
+    rng = np.random.default_rng(case["seed"])
+    lat, lon = np.deg2rad(src["latitudes"]), np.deg2rad(src["longitudes"])
+    fields = np.stack([280.0 + 30.0 * np.sin(lat) * np.cos(2.0 * lon + 0.1 * l) + rng.standard_normal(len(lat)) for l in range(case["levels"])])
+    idx1 = VECTORS.file[f"ngp/{case['pair']}/k1/unbounded/idx"].astype(np.int64)
+    idx4 = VECTORS.file[f"ngp/{case['pair']}/k4/unbounded/idx"].astype(np.int64)
+    inv = 1.0 / np.maximum(VECTORS.file[f"ngp/{case['pair']}/k4/unbounded/dist"], 1e-12)
+    return fields, idx1, idx4, inv / inv.sum(axis=1, keepdims=True)
+
+
+@pytest.mark.parametrize("case", MANIFEST["regrid"], ids=ids(MANIFEST["regrid"]))
+def test_regrid_statements_on_reference_tables(case):
+    """The oracle's two regrid statements reproduce the recorded outputs (the same numpy / scipy calls on the reference's own tables)."""
+    fields, idx1, idx4, weights = regrid_case_inputs(case)
+    n_tgt, n_src = idx4.shape[0], fields.shape[1]
+    assert np.array_equal(oracle.gather_nn(fields, idx1), VECTORS.file[case["key"] + "/nearest"])
+    indptr = np.arange(n_tgt + 1) * 4
+    got = np.stack([oracle.csr_apply(weights.reshape(-1), idx4.reshape(-1), indptr, (n_tgt, n_src), f) for f in fields])
+    assert np.array_equal(got, VECTORS.file[case["key"] + "/knn4"])
