@@ -188,6 +188,44 @@ __device__ __forceinline__ void combine_one(int flags, const T* x, int n_in, T l
             y1 = x[0] * sin(a);
             break;
         }
+        case ATX_COMB_OPERA_CLIP: {  // level = max_total_precipitation; R: rodeo_opera_preprocessing.py:34-37 (twice), rodeo_opera_clipping.py:98
+            T tp = x[0], qi = x[1];
+            tp = (tp < T(0)) ? T(0) : tp;  // `variable[variable < 0] = 0`: a NaN fails both tests and stays, -0.0 stays -0.0
+            tp = (tp >= level) ? level : tp;
+            qi = (qi < T(0)) ? T(0) : qi;
+            qi = (qi >= T(1)) ? T(1) : qi;
+            y0 = tp / T(1000);
+            y1 = qi;
+            break;
+        }
+        case ATX_COMB_OPERA_PREPROCESS: {  // (tp, qi, dm); R: rodeo_opera_preprocessing.py:83-87 then :34-37 on both
+            T tp = x[0], qi = x[1];
+            const T dm = x[2];
+            if (dm == T(1)) tp = quiet_nan<T>();  // _NODATA
+            if (dm == T(2)) tp = T(0);            // _UNDETECTED
+            if (dm == T(3)) tp = quiet_nan<T>();  // _INF
+            if (dm == T(2)) qi = T(0);
+            tp = (tp < T(0)) ? T(0) : tp;
+            tp = (tp >= level) ? level : tp;
+            qi = (qi < T(0)) ? T(0) : qi;
+            qi = (qi >= T(1)) ? T(1) : qi;
+            y0 = tp;
+            y1 = qi;
+            break;
+        }
+        case ATX_COMB_ORAS6: {  // (x, siconc), level = what this field is (ATX_ORAS6_*); R: oras6_clipping.py:194-215
+            const T puny = T(1e-5), tf = T(273.15), mintf = T(271.15 - 1e-5);
+            const int kind = (int)level;
+            const bool no_ice = x[1] <= puny;  // `mask = siconc_np <= PUNY`: false for a NaN concentration
+            T y = x[0];
+            if (kind == ATX_ORAS6_CELSIUS) y = y + tf;
+            if (no_ice && (kind == ATX_ORAS6_ZERO || kind == ATX_ORAS6_HEAT)) y = T(0);
+            if (no_ice && (kind == ATX_ORAS6_TEMPERATURE || kind == ATX_ORAS6_CELSIUS)) y = tf;
+            if (kind == ATX_ORAS6_HEAT) y = (y >= -puny) ? T(0) : y;
+            if (kind == ATX_ORAS6_SURFACE) y = (y <= mintf) ? mintf : y;
+            y0 = y;
+            break;
+        }
         default: y0 = x[0]; break;
     }
 }
@@ -234,7 +272,15 @@ __device__ __forceinline__ void comb_store(T* p, const Pack<T, 1>& v) {
 #ifndef ATX_COMB_NT_LOAD
 #define ATX_COMB_NT_LOAD 1
 #endif
-constexpr int comb_unroll(int nin, int elem_bytes, int op) { return nin > 3 ? 1 : (elem_bytes == 4 ? ATX_COMB_U_F32 : ATX_COMB_U_F64); }
+#ifndef ATX_COMB_U_OPERA
+#define ATX_COMB_U_OPERA 1  // vectors per lane of the 4- and 5-stream OPERA operators (0: as the other operators).  Measured on 137-level O1280
+                            // stacks, 1 / 2 / 4 per lane: clipping 2->2 f32 0.748 / 0.702 / 0.754 of 8 TB/s, f64 0.814 / 0.752 / 0.810; preprocessing
+                            // 3->2 f32 0.764 / 0.699 / 0.694, f64 0.795 / 0.744 / 0.791 (profiles/r04_opera_unroll.log)
+#endif
+constexpr int comb_unroll(int nin, int elem_bytes, int op) {
+    if (ATX_COMB_U_OPERA > 0 && (op == ATX_COMB_OPERA_CLIP || op == ATX_COMB_OPERA_PREPROCESS)) return ATX_COMB_U_OPERA;
+    return nin > 3 ? 1 : (elem_bytes == 4 ? ATX_COMB_U_F32 : ATX_COMB_U_F64);
+}
 constexpr int64_t comb_grid_cap(int elem_bytes, int op) { return (elem_bytes == 4 || ATX_COMB_CAP_F64 == 0) ? 0x7fffffffll : (int64_t)ATX_COMB_CAP_F64; }
 
 template <typename T, int N>
@@ -259,7 +305,9 @@ combine_kernel(CombArgs a, int flags, int n_in, int n_out, int64_t n_rows, int64
     const int64_t total = n_rows * vec_per_row;
     constexpr int U = comb_unroll(NIN, (int)sizeof(T), OP);
     constexpr int64_t kChunk = (int64_t)kBlock * U;
-    constexpr bool kLevels = OP == ATX_COMB_W_TO_WZ || OP == ATX_COMB_WZ_TO_W;  // the only operators that read level_param
+    constexpr bool kLevels = OP == ATX_COMB_W_TO_WZ || OP == ATX_COMB_WZ_TO_W || OP == ATX_COMB_OPERA_CLIP ||
+                             OP == ATX_COMB_OPERA_PREPROCESS || OP == ATX_COMB_ORAS6;  // the operators that read level_param[level]
+    constexpr bool kShared1 = OP == ATX_COMB_ORAS6;  // operand 1 is ONE field [n_pts] shared by every level, not a stack
     const bool small_rows = vec_per_row < (1 << 20);  // columns layout: (row, col) from 32-bit arithmetic
     // a workgroup takes a contiguous run of chunks, not every gridDim.x-th one: under the 65536-workgroup cap the grid stride is a
     // power of two (1 GiB for f64) and drifting workgroups alias onto the same HBM channels (atx_pointwise.hip, ATX_PW_ASSIGN)
@@ -286,7 +334,7 @@ combine_kernel(CombArgs a, int flags, int n_in, int n_out, int64_t n_rows, int64
             ok[u] = vi[u] < total;
 #pragma unroll
             for (int k = 0; k < NIN; ++k)
-                if (k < n_in && ok[u]) x[u][k] = comb_load<T, VEC>(static_cast<const T*>(a.in[k]) + vi[u] * VEC);
+                if (k < n_in && ok[u] && !(kShared1 && k == 1)) x[u][k] = comb_load<T, VEC>(static_cast<const T*>(a.in[k]) + vi[u] * VEC);
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -308,13 +356,28 @@ combine_kernel(CombArgs a, int flags, int n_in, int n_out, int64_t n_rows, int64
 #pragma unroll
                 for (int k = 0; k < ATX_COMB_MAX_INPUTS; ++k) xe[k] = (k < NIN && k < n_in) ? x[u][k < NIN ? k : 0].v[e] : T(0);
                 const bool live = (col + e) < row_len;
+                if constexpr (kShared1) {
+                    const int64_t point = layout == ATX_COLUMNS ? row : col + e;
+                    xe[1] = live ? static_cast<const T*>(a.in[1])[point] : T(0);
+                }
                 T lv = T(0);
                 if constexpr (kLevels) {
                     const int64_t level = layout == ATX_COLUMNS ? col + e : row;
                     if (level_param && level < n_lev) lv = static_cast<T>(level_param[level]);
                 }
                 T r0, r1;
-                combine_one<T, OP>(flags, xe, n_in, lv, r0, r1);
+                if constexpr (OP == ATX_COMB_LOOKUP) {
+                    // level_param = (n, value of class 0, ..., value of class n-1): `param_dic[x][key]` for a class x that is one of the
+                    // keys 0 .. n-1 (R: land_parameters.py:71); anything else — a fraction, a class beyond the table, NaN — is a KeyError
+                    // there and a NaN here, which the caller counts
+                    const int n_cls = (int)level_param[0];
+                    const T c = xe[0];
+                    const bool known = c >= T(0) && c < T(n_cls) && c == floor(c);
+                    r0 = known ? static_cast<T>(level_param[1 + (int)c]) : quiet_nan<T>();
+                    r1 = T(0);
+                } else {
+                    combine_one<T, OP>(flags, xe, n_in, lv, r0, r1);
+                }
                 y0.v[e] = live ? r0 : T(0);  // padding stays zero
                 y1.v[e] = live ? r1 : T(0);
             }
@@ -355,6 +418,10 @@ static int combine_typed(const CombArgs& a, int op, int flags, int n_in, int n_o
         ATX_COMB_CASE(ATX_COMB_SUB, 2);
         ATX_COMB_CASE(ATX_COMB_XY_TO_POLAR, 2);
         ATX_COMB_CASE(ATX_COMB_POLAR_TO_XY, 2);
+        ATX_COMB_CASE(ATX_COMB_OPERA_CLIP, 2);
+        ATX_COMB_CASE(ATX_COMB_OPERA_PREPROCESS, 3);
+        ATX_COMB_CASE(ATX_COMB_ORAS6, 2);
+        ATX_COMB_CASE(ATX_COMB_LOOKUP, 1);
         default:  // ATX_COMB_SUM
             if (vec_ok) {
                 if (n_in <= 1) ATX_COMB_LAUNCH(VEC, 1, ATX_COMB_SUM);
@@ -382,8 +449,8 @@ using namespace atx;
 extern "C" int atx_combine_stack(int op, const void* const* inputs, int32_t n_in, void* const* outputs, int32_t n_out,
                                  int64_t n_pts, int64_t n_lev, int64_t pitch, int dtype, int layout,
                                  const double* level_param, int32_t flags, void* stream) {
-    static const int kIn[ATX_COMB_COUNT_] = {2, 2, 1, 2, 3, 3, -1, 2, 2, 2};
-    static const int kOut[ATX_COMB_COUNT_] = {1, 1, 2, 1, 1, 1, 1, 1, 2, 2};
+    static const int kIn[ATX_COMB_COUNT_] = {2, 2, 1, 2, 3, 3, -1, 2, 2, 2, 2, 3, 2, 1};
+    static const int kOut[ATX_COMB_COUNT_] = {1, 1, 2, 1, 1, 1, 1, 1, 2, 2, 2, 2, 1, 1};
     ATX_REQUIRE(op >= 0 && op < ATX_COMB_COUNT_, ATX_EINVAL, "atx_combine_stack: bad operator %d", op);
     ATX_REQUIRE(inputs && outputs, ATX_EINVAL, "atx_combine_stack: null pointer table");
     ATX_REQUIRE(n_in >= 1 && n_in <= ATX_COMB_MAX_INPUTS, ATX_EINVAL, "atx_combine_stack: n_in=%d outside [1, %d]", n_in, ATX_COMB_MAX_INPUTS);
@@ -393,7 +460,8 @@ extern "C" int atx_combine_stack(int op, const void* const* inputs, int32_t n_in
     ATX_REQUIRE(layout == ATX_COLUMNS || layout == ATX_FIELDS, ATX_EINVAL, "atx_combine_stack: bad layout %d", layout);
     ATX_REQUIRE(n_pts >= 0 && n_lev > 0 && n_lev <= INT32_MAX, ATX_EINVAL, "atx_combine_stack: bad sizes");
     ATX_REQUIRE(pitch >= (layout == ATX_COLUMNS ? n_lev : n_pts), ATX_ESHAPE, "atx_combine_stack: pitch %lld too small", (long long)pitch);
-    ATX_REQUIRE(level_param || (op != ATX_COMB_W_TO_WZ && op != ATX_COMB_WZ_TO_W), ATX_EINVAL, "atx_combine_stack: operator %d needs level_param", op);
+    const bool reads_param = op == ATX_COMB_W_TO_WZ || op == ATX_COMB_WZ_TO_W || op >= ATX_COMB_OPERA_CLIP;
+    ATX_REQUIRE(level_param || !reads_param, ATX_EINVAL, "atx_combine_stack: operator %d needs level_param", op);
     CombArgs a{};
     for (int k = 0; k < n_in; ++k) {
         ATX_REQUIRE(inputs[k], ATX_EINVAL, "atx_combine_stack: null input %d", k);

@@ -5,7 +5,9 @@ Registered names:
                   orog_to_z_fields, z_to_orog_fields, clip_fields, impute_nans_fields,
                   lnsp_to_sp, sp_to_lnsp, glacier_mask, noop,
                   snow_depth_m, snow_cover, cos_sin_from_rad, cos_sin_mean_wave_direction,
-                  w_to_wz, wz_to_w, sum, accum_to_interval   (multi-input, filters/multi.py)
+                  w_to_wz, wz_to_w, uv_to_ddff, ddff_to_uv, sum, accum_to_interval   (multi-input, filters/multi.py)
+                  rodeo_opera_clipping, rodeo_opera_preprocessing, oras6_clipping, land_parameters
+                                                             (multi-input, filters/domain.py)
                   rename_fields, clear_step, repeat_members, earthkitfieldlambda, empty,
                   icon_refinement_level   (re-labelling / re-listing, filters/metadata.py)
   dispatchers     mask (alias apply_mask), remove_nans (alias drop_nans),
@@ -26,6 +28,7 @@ from ..core import DispatchingFilter, Filter, filter_registry
 
 # importing the modules registers the field filters
 from . import masks as _masks  # noqa: E402
+from . import domain as _domain  # noqa: E402
 from . import metadata as _metadata  # noqa: E402
 from . import multi as _multi  # noqa: E402
 from . import pointwise as _pointwise  # noqa: E402

@@ -209,6 +209,7 @@ def combine_groups(
     flags: int = 0,
     level_values: list[float] | None = None,
     check: Callable[[list[Any]], None] | None = None,
+    after: Callable[[list[Any]], None] | None = None,
 ) -> list[list[tuple[Any, int]]]:
     """Evaluate one operator for all groups: returns, per group, the ``(stack, level)`` of each output.
 
@@ -232,6 +233,8 @@ def combine_groups(
             level_param = torch.tensor([level_values[gi] for gi in members], dtype=torch.float64, device=ins[0].device)
         native.combine_stack(op, [s.data for s in ins], [s.data for s in outs], n_pts=ins[0].n_pts, n_lev=ins[0].n_lev,
                              pitch=ins[0].pitch, layout=ins[0].layout, level_param=level_param, flags=flags)
+        if after is not None:
+            after(outs)
         for level, gi in enumerate(members):
             results[gi] = [(o, level) for o in outs]
     return results
@@ -242,7 +245,8 @@ class StackMatchingFilter(MatchingFieldsFilter):
 
     Subclasses describe each direction with ``<direction>_plan(**fields)`` returning
     ``(op, flags, [(template_field, metadata), ...], level_value)`` for ONE group; the
-    operator and flags must not depend on the group.
+    operator and flags must not depend on the group.  A fifth element, if present, lists input
+    fields handed on unchanged AFTER the results of the group.
     """
 
     _ABSTRACT_MATCHING_BASE = True
@@ -254,6 +258,9 @@ class StackMatchingFilter(MatchingFieldsFilter):
         raise NotImplementedError("Backward transformation not implemented.")
 
     def _check_stacks(self, direction: str, stacks: list[Any]) -> None:
+        pass
+
+    def _check_results(self, direction: str, stacks: list[Any]) -> None:
         pass
 
     def _run(self, data: Any, direction: str) -> FieldList:
@@ -270,12 +277,14 @@ class StackMatchingFilter(MatchingFieldsFilter):
         op, flags = plans[0][0], plans[0][1]
         level_values = [p[3] for p in plans] if plans[0][3] is not None else None
         outs = combine_groups(groups, op, len(plans[0][2]), flags=flags, level_values=level_values,
-                              check=lambda stacks: self._check_stacks(direction, stacks))
+                              check=lambda stacks: self._check_stacks(direction, stacks),
+                              after=lambda stacks: self._check_results(direction, stacks))
         for g, plan, out in zip(groups, plans, outs):
             kwargs = dict(zip(names, g, strict=True))
             result.extend(inputs_generator(self.MATCHING.inputs(direction=direction), **kwargs))
             for (template, metadata), (stack, level) in zip(plan[2], out):
                 result.append(new_field_from_stack(stack, level, template=template, metadata=metadata))
+            result.extend(plan[4] if len(plan) > 4 else ())
         return self.new_fieldlist_from_list(result)
 
     def forward(self, data: Any) -> FieldList:
@@ -287,16 +296,18 @@ class StackMatchingFilter(MatchingFieldsFilter):
     # the per-group entry points of the reference API, for callers that use them directly
     def forward_transform(self, *args: Any, **fields: Any) -> Iterator[Any]:
         fields.update(dict(zip(self.MATCHING.forward, args)))
-        op, flags, outputs, level = self.forward_plan(**fields)
+        op, flags, outputs, level, *rest = self.forward_plan(**fields)
         group = tuple(fields[n] for n in self.MATCHING.forward)
         (out,) = combine_groups([group], op, len(outputs), flags=flags, level_values=None if level is None else [level],
-                                check=lambda stacks: self._check_stacks("forward", stacks))
+                                check=lambda stacks: self._check_stacks("forward", stacks),
+                                after=lambda stacks: self._check_results("forward", stacks))
         for (template, metadata), (stack, lvl) in zip(outputs, out):
             yield new_field_from_stack(stack, lvl, template=template, metadata=metadata)
+        yield from (rest[0] if rest else ())
 
     def backward_transform(self, *args: Any, **fields: Any) -> Iterator[Any]:
         fields.update(dict(zip(self.MATCHING.backward, args)))
-        op, flags, outputs, level = self.backward_plan(**fields)
+        op, flags, outputs, level, *_ = self.backward_plan(**fields)
         group = tuple(fields[n] for n in self.MATCHING.backward)
         (out,) = combine_groups([group], op, len(outputs), flags=flags, level_values=None if level is None else [level])
         for (template, metadata), (stack, lvl) in zip(outputs, out):

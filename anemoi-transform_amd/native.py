@@ -40,7 +40,9 @@ CMP_GT, CMP_LT, CMP_EQ, CMP_NE, CMP_GE, CMP_LE, CMP_NOTNAN, CMP_ISNAN = range(8)
 ) = range(10)
 RED_MIN, RED_MAX, RED_NANCOUNT, RED_MINMAX = range(4)
 (COMB_SNOW_DEPTH_M, COMB_SNOW_COVER, COMB_COS_SIN, COMB_ATAN2, COMB_W_TO_WZ, COMB_WZ_TO_W, COMB_SUM, COMB_SUB, COMB_XY_TO_POLAR,
- COMB_POLAR_TO_XY) = range(10)
+ COMB_POLAR_TO_XY, COMB_OPERA_CLIP, COMB_OPERA_PREPROCESS, COMB_ORAS6, COMB_LOOKUP) = range(14)
+# what a level of a COMB_ORAS6 stack holds (ATX_ORAS6_* of atx.h)
+ORAS6_KEEP, ORAS6_ZERO, ORAS6_TEMPERATURE, ORAS6_CELSIUS, ORAS6_HEAT, ORAS6_SURFACE = range(6)
 COMB_DEGREES = 1
 COMB_MAX_INPUTS = 8
 
@@ -381,13 +383,17 @@ def pointwise_stack(x, y, *, n_pts, n_lev, x_pitch, y_pitch, layout, prog, n_sta
 
 
 def combine_stack(op: int, inputs, outputs, *, n_pts, n_lev, pitch, layout, level_param=None, flags: int = 0) -> None:
-    """Multi-input per-point operator over same-shape stacks (``atx_combine_stack``)."""
+    """Multi-input per-point operator over same-shape stacks (``atx_combine_stack``).  ``level_param``: a float64 value per level, except
+    for ``COMB_LOOKUP`` where it is the table (its length, then its values); the second input of ``COMB_ORAS6`` is one field, not a stack."""
     dtype = inputs[0].dtype
     assert all(t.dtype == dtype for t in list(inputs) + list(outputs))
     ins = (c_void_p * len(inputs))(*[_ptr(t) for t in inputs])
     outs = (c_void_p * len(outputs))(*[_ptr(t) for t in outputs])
+    if op == COMB_ORAS6:
+        assert inputs[1].is_contiguous() and inputs[1].numel() >= n_pts
     if level_param is not None:
-        assert level_param.dtype == torch.float64 and level_param.numel() >= n_lev
+        assert level_param.dtype == torch.float64 and level_param.is_contiguous()
+        assert level_param.numel() >= (2 if op == COMB_LOOKUP else n_lev)
     _call("atx_combine_stack", op, ins, len(inputs), outs, len(outputs), n_pts, n_lev, pitch, dtype_code(dtype), layout,
           _ptr(level_param), flags, _stream())
 

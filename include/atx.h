@@ -44,7 +44,8 @@
 extern "C" {
 #endif
 
-#define ATX_VERSION 400 /* 0.4.0 — round 4: atx_vector_program takes the CAPACITY of `out` (ATX_EWORKSPACE when too small — 0.3 wrote its
+#define ATX_VERSION 410 /* 0.4.1 — four more multi-input operators (ATX_COMB_OPERA_CLIP .. ATX_COMB_LOOKUP); nothing else changed.
+                           * 0.4.0 — round 4: atx_vector_program takes the CAPACITY of `out` (ATX_EWORKSPACE when too small — 0.3 wrote its
                            * grown table without asking), atx_reduce* keep the no-atomics route for every shape when given a workspace.
                            * 0.3.0 — round 3: atx_reduce* take a workspace, atx_regrid_*_ordered, two more multi-input operators, and the
                            * table written by atx_vector_program grew a typed per-level part (a table built by a 0.2 library is too short for
@@ -270,12 +271,29 @@ typedef enum {
     ATX_COMB_XY_TO_POLAR = 8,  /* (u, v) -> (hypot(u, v), mod(270 - atan2(v, u)*180/pi, 360)): speed and the direction the wind blows FROM,
                                   the "meteo" convention of earthkit.meteo.wind.array.xy_to_polar      R: filters/fields/uv_to_ddff.py:93-97   */
     ATX_COMB_POLAR_TO_XY = 9,  /* (speed, dir) -> (speed*cos(a), speed*sin(a)), a = (270 - dir)*pi/180   R: uv_to_ddff.py:121-125         */
-    ATX_COMB_COUNT_ = 10
+    /* 0.4.1: the reference's remaining numpy-only per-point filters */
+    ATX_COMB_OPERA_CLIP = 10,  /* (tp, qi) -> (c(tp, max)/1000, c(qi, 1)), c(v, m): v<0 -> 0, then v>=m -> m (NaN and -0.0 kept);
+                                  max = level_param[l]    R: filters/fields/rodeo_opera_clipping.py:92-98, rodeo_opera_preprocessing.py:34-37 */
+    ATX_COMB_OPERA_PREPROCESS = 11, /* (tp, qi, dm) -> (c(tp', max), c(qi', 1)); tp' = NaN where dm is 1 or 3, 0 where dm is 2; qi' = 0 where
+                                  dm is 2; max = level_param[l]                R: rodeo_opera_preprocessing.py:83-87, :190-200        */
+    ATX_COMB_ORAS6 = 12,       /* (x, siconc) -> x cleaned where siconc <= 1e-5; inputs[1] is ONE contiguous field [n_pts] shared by every
+                                  level; level_param[l] = what level l is, an ATX_ORAS6_* code    R: filters/fields/oras6_clipping.py:189-215 */
+    ATX_COMB_LOOKUP = 13,      /* (class) -> table[class]; level_param = double[1 + n]: n, then the value of class 0 .. n-1; a class that is
+                                  not one of 0 .. n-1 (the reference's KeyError) gives NaN        R: filters/fields/land_parameters.py:71 */
+    ATX_COMB_COUNT_ = 14
 } atx_comb;
 #define ATX_COMB_DEGREES 1
 #define ATX_COMB_MAX_INPUTS 8
+/* what a level of an ATX_COMB_ORAS6 stack holds (R: oras6_clipping.py:196-215) */
+#define ATX_ORAS6_KEEP 0        /* passed on as it is (siconc itself)                                    */
+#define ATX_ORAS6_ZERO 1        /* 0 where there is no ice (velocities, salinity, pressure, volumes, albedo) */
+#define ATX_ORAS6_TEMPERATURE 2 /* 273.15 where there is no ice (sitemptop, sntemp, vasit)                   */
+#define ATX_ORAS6_CELSIUS 3     /* a snow temperature archived in Celsius: + 273.15 first, then as above (:190-191) */
+#define ATX_ORAS6_HEAT 4        /* 0 where there is no ice, then 0 wherever the value is >= -1e-5 (sihc, snhc) */
+#define ATX_ORAS6_SURFACE 5     /* tos: raised to 271.15 - 1e-5 where it is at or below it; the ice mask is not used */
 /* inputs / outputs: HOST arrays of n_in / n_out DEVICE pointers (n_in <= ATX_COMB_MAX_INPUTS, n_out <= 2).
- * level_param: device double[n_lev] or NULL (required by the W/WZ operators).
+ * level_param: device double[n_lev] or NULL (required by the W/WZ operators and by the operators from 10 on, which say above
+ * what they read from it).
  * All stacks share n_pts, n_lev, pitch and layout; the padding of the outputs (elements between a row's length and the pitch) is
  * written with zeros. */
 int atx_combine_stack(int op, const void* const* inputs, int32_t n_in, void* const* outputs, int32_t n_out,

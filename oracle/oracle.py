@@ -585,6 +585,75 @@ def interval_difference(current, previous):
     return current - previous
 
 
+# ---- OPERA radar composites (R: filters/fields/rodeo_opera_preprocessing.py, rodeo_opera_clipping.py) -----------------------
+def opera_clip_variable(variable, max_value):
+    """R: rodeo_opera_preprocessing.py:34-37 — two boolean-mask assignments: a NaN fails both tests and stays, and so does -0.0."""
+    variable = np.array(variable, copy=True)
+    variable[variable < 0] = 0
+    variable[variable >= max_value] = max_value
+    return variable
+
+
+def opera_clipping(tp, quality, max_total_precipitation=10000):
+    """R: rodeo_opera_clipping.py:92-98 — both variables clipped (the quality index to MAX_QI = 1), then tp / FACTOR_TP (1000)."""
+    return opera_clip_variable(tp, max_total_precipitation) / 1000, opera_clip_variable(quality, 1)
+
+
+def opera_preprocessing(tp, quality, mask, max_total_precipitation=10000):
+    """R: rodeo_opera_preprocessing.py:83-87 (mask codes 1 = no data, 2 = undetected, 3 = inf) then :190-195 (the same clipping, no division)."""
+    tp, quality, mask = np.array(tp, copy=True), np.array(quality, copy=True), np.asarray(mask)
+    tp[mask == 1] = np.nan
+    tp[mask == 2] = 0
+    tp[mask == 3] = np.nan
+    quality[mask == 2] = 0
+    return opera_clip_variable(tp, max_total_precipitation), opera_clip_variable(quality, 1)
+
+
+# ---- ORAS6 sea-ice cleaning (R: filters/fields/oras6_clipping.py:19-21, 172-215) ---------------------------------------------
+ORAS6_PUNY = 1e-5
+ORAS6_MINTF = 271.15 - ORAS6_PUNY
+ORAS6_TF = 273.15
+ORAS6_FIELDS = ("siue", "sivn", "siconc", "icesalt", "sihc", "snhc", "sipf", "sitemptop", "sntemp", "snvol", "sivol", "sialb", "vasit", "tos")
+ORAS6_OUTPUT_ORDER = ("siconc", "siue", "sivn", "icesalt", "sihc", "snhc", "sipf", "sitemptop", "sntemp", "snvol", "sivol", "sialb", "vasit", "tos")
+
+
+def oras6_clipping(**arrays):
+    """R: oras6_clipping.py:172-215 on the 14 named arrays; returns them in the order the reference yields them (:217-230)."""
+    a = {name: np.array(arrays[name], copy=True) for name in ORAS6_FIELDS}
+    with np.errstate(all="ignore"):
+        if np.nanmax(a["sntemp"]) < 100:  # :190-191 — a snow temperature archived in Celsius
+            a["sntemp"] = a["sntemp"] + ORAS6_TF
+    mask = a["siconc"] <= ORAS6_PUNY
+    for name in ("siue", "sivn", "icesalt", "sihc", "snhc", "sipf", "snvol", "sivol", "sialb"):
+        a[name][mask] = 0
+    for name in ("sitemptop", "sntemp", "vasit"):
+        a[name][mask] = ORAS6_TF
+    for name in ("sihc", "snhc"):
+        a[name][a[name] >= -ORAS6_PUNY] = 0
+    a["tos"][a["tos"] <= ORAS6_MINTF] = ORAS6_MINTF
+    return [(name, a[name]) for name in ORAS6_OUTPUT_ORDER]
+
+
+# ---- land parameters from soil / vegetation classes (R: filters/fields/land_parameters.py:20-52, 55-72) ----------------------
+SOIL_TABLE = {  # class: (theta_pwp, theta_cap)
+    0: (0.0, 0.0), 1: (0.059, 0.244), 2: (0.151, 0.347), 3: (0.133, 0.383), 4: (0.279, 0.448), 5: (0.335, 0.541), 6: (0.267, 0.663),
+    7: (0.151, 0.347),
+}
+VEGETATION_TABLE = {  # class: (veg_rsmin, veg_cov, veg_z0m)
+    0: (250.0, 0.0, 0.013), 1: (125.0, 0.9, 0.25), 2: (80.0, 0.85, 0.1), 3: (395.0, 0.9, 2.0), 4: (320.0, 0.9, 2.0), 5: (215.0, 0.9, 2.0),
+    6: (320.0, 0.99, 2.0), 7: (100.0, 0.7, 0.5), 8: (250.0, 0.0, 0.013), 9: (45.0, 0.5, 0.03), 10: (110.0, 0.9, 0.5), 11: (45.0, 0.1, 0.03),
+    12: (0.0, 0.0, 0.0013), 13: (130.0, 0.6, 0.25), 14: (0.0, 0.0, 0.0001), 15: (0.0, 0.0, 0.0001), 16: (230.0, 0.5, 0.5),
+    17: (110.0, 0.4, 0.1), 18: (180.0, 0.9, 1.50), 19: (175.0, 0.9, 1.1), 20: (150.0, 0.6, 0.02),
+}
+
+
+def crosswalk(classes, table):
+    """R: land_parameters.py:71 — one float64 array per table column, ``table[x][column]`` for every x of the class array in turn; a
+    class that is not a key (a fraction, NaN, beyond the table) raises KeyError as there."""
+    n_columns = len(table[0])
+    return [np.array([table[x][column] for x in classes]) for column in range(n_columns)]
+
+
 def filter_accum_to_interval(fields: list[dict], *, variables, zero_left: bool = True) -> list[dict]:
     """R: accum_to_interval.py:73-101 — per (param, level, levelType) group sorted by valid_datetime."""
     variables = set(variables)

@@ -132,7 +132,43 @@ def pointwise_stack(x, y, *, n_pts, n_lev, x_pitch, y_pitch, layout, prog, n_sta
     _epilogue(ys, prog, n_stage, point_mask, n_lev)
 
 
+_ORAS6_NAME = {native.ORAS6_KEEP: "siconc", native.ORAS6_ZERO: "siue", native.ORAS6_TEMPERATURE: "sitemptop", native.ORAS6_HEAT: "sihc",
+               native.ORAS6_SURFACE: "tos"}
+
+
+def _oras6_level(x, siconc, kind):
+    """One level through ``oracle.oras6_clipping``: the level plays the field of its kind, the other 12 are dummies (the statements of
+    the 14 fields do not depend on each other, only on siconc)."""
+    if kind == native.ORAS6_CELSIUS:  # the filter decided on the shift; here it is the statement of oras6_clipping.py:191
+        x, kind = x + x.dtype.type(oracle.ORAS6_TF), native.ORAS6_TEMPERATURE
+    arrays = {name: np.zeros_like(x) for name in oracle.ORAS6_FIELDS}
+    arrays["sntemp"] = np.full_like(x, 200.0)  # not in Celsius
+    arrays["siconc"] = siconc
+    name = _ORAS6_NAME[kind]
+    if name != "siconc":
+        arrays[name] = x
+    return dict(oracle.oras6_clipping(**arrays))[name] if name != "siconc" else x.copy()
+
+
 def combine_stack(op, inputs, outputs, *, n_pts, n_lev, pitch, layout, level_param=None, flags=0):
+    if op == native.COMB_ORAS6:  # the second operand is ONE field shared by the levels
+        xs = np.ascontiguousarray(_levels(inputs[0], n_pts, n_lev, layout))
+        ys = _levels(outputs[0], n_pts, n_lev, layout)
+        siconc = inputs[1].numpy().reshape(-1)[:n_pts]
+        for l in range(n_lev):
+            ys[l] = _oras6_level(xs[l], siconc.copy(), int(level_param[l]))
+        return
+    if op == native.COMB_LOOKUP:
+        xs = _levels(inputs[0], n_pts, n_lev, layout)
+        ys = _levels(outputs[0], n_pts, n_lev, layout)
+        n = int(level_param[0])
+        table = {c: (float(level_param[1 + c]),) for c in range(n)}
+        for l in range(n_lev):
+            try:
+                ys[l] = oracle.crosswalk(xs[l], table)[0]
+            except KeyError:  # the kernel's contract: NaN where the class is not a key
+                ys[l] = [table[c][0] if c in table else np.nan for c in xs[l]]
+        return
     xs = [np.ascontiguousarray(_levels(t, n_pts, n_lev, layout)) for t in inputs]
     ys = [_levels(t, n_pts, n_lev, layout) for t in outputs]
     deg = bool(flags & native.COMB_DEGREES)
@@ -159,6 +195,10 @@ def combine_stack(op, inputs, outputs, *, n_pts, n_lev, pitch, layout, level_par
             ys[0][l], ys[1][l] = oracle.xy_to_polar(a[0], a[1])
         elif op == native.COMB_POLAR_TO_XY:
             ys[0][l], ys[1][l] = oracle.polar_to_xy(a[0], a[1])
+        elif op == native.COMB_OPERA_CLIP:
+            ys[0][l], ys[1][l] = oracle.opera_clipping(a[0], a[1], float(level_param[l]))
+        elif op == native.COMB_OPERA_PREPROCESS:
+            ys[0][l], ys[1][l] = oracle.opera_preprocessing(a[0], a[1], a[2], float(level_param[l]))
         else:
             raise ValueError(op)
     for y in ys:

@@ -183,6 +183,31 @@ def main():
                n_pts=n_src, n_lev=L, pitch=x.pitch, layout=COLUMNS)), 3 * stack_bytes)
         record(f"combine cos_sin (1->2) {tag}", timeit(lambda: native.combine_stack(native.COMB_COS_SIN, [x.data], [y.data, z.data],
                n_pts=n_src, n_lev=L, pitch=x.pitch, layout=COLUMNS)), 3 * stack_bytes)
+        # ---- the numpy-only domain filters (filters/domain.py)
+        lim = torch.full((L,), 10000.0, dtype=torch.float64, device=dev)
+        w2 = x.new_like()
+        record(f"combine opera_clipping (2->2) {tag}", timeit(lambda: native.combine_stack(native.COMB_OPERA_CLIP, [x.data, y.data], [z.data, w2.data],
+               n_pts=n_src, n_lev=L, pitch=x.pitch, layout=COLUMNS, level_param=lim)), 4 * stack_bytes)
+        dm = x.new_like()
+        dm.data[:, :L] = torch.randint(0, 4, (n_src, L), device=dev).to(tdt)
+        record(f"combine opera_preprocessing (3->2) {tag}", timeit(lambda: native.combine_stack(native.COMB_OPERA_PREPROCESS, [x.data, y.data, dm.data], [z.data, w2.data],
+               n_pts=n_src, n_lev=L, pitch=x.pitch, layout=COLUMNS, level_param=lim)), 5 * stack_bytes)
+        del dm, w2
+        # one ORAS6 group: 14 fields and the ice concentration they share
+        o_in, o_out = Stack.empty(n_src, 14, tdt, dev, COLUMNS), Stack.empty(n_src, 14, tdt, dev, COLUMNS)
+        o_in.data.normal_()
+        ice = torch.rand(n_src, device=dev).to(tdt)
+        kinds = torch.tensor([0, 1, 1, 1, 4, 4, 1, 2, 3, 1, 1, 1, 2, 5], dtype=torch.float64, device=dev)
+        record(f"combine oras6_clipping (14 fields of one date) {tag}", timeit(lambda: native.combine_stack(native.COMB_ORAS6, [o_in.data, ice], [o_out.data],
+               n_pts=n_src, n_lev=14, pitch=o_in.pitch, layout=COLUMNS, level_param=kinds)), (2 * 14 + 1) * n_src * B,
+               "one launch per group; the shared ice field is read once per point")
+        cls = Stack.empty(n_src, 1, tdt, dev, COLUMNS)
+        cls.data[:, 0] = torch.randint(0, 21, (n_src,), device=dev).to(tdt)
+        val = cls.new_like()
+        tab = torch.tensor([21.0] + [float(i) for i in range(21)], dtype=torch.float64, device=dev)
+        record(f"combine lookup (land_parameters, 1 field) {tag}", timeit(lambda: native.combine_stack(native.COMB_LOOKUP, [cls.data], [val.data],
+               n_pts=n_src, n_lev=1, pitch=cls.pitch, layout=COLUMNS, level_param=tab)), 2 * n_src * B, "26 MB / 53 MB: launch-latency sized")
+        del o_in, o_out, ice, cls, val
         # ---- layout
         f = Stack.empty(n_src, L, tdt, dev, FIELDS)
         record(f"relayout columns->fields {tag}", timeit(lambda: native.relayout(x.data, f.data, n_pts=n_src, n_lev=L, src_pitch=x.pitch,
