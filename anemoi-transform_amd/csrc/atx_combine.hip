@@ -77,6 +77,61 @@ __device__ __forceinline__ bool sincos_moderate(double x, double& sn, double& cs
 #define ATX_FAST_SINCOS 1
 #endif
 
+// Saturation vapour pressure over water / ice and in the mixed phase, as earthkit-meteo (>= 0.4.1, absent here) publishes them
+// (thermo.array.saturation_vapour_pressure: the IFS formulas, c1 = 611.21 Pa, T0 = 273.16 K, water 17.502 / 32.19, ice 22.587 / -0.7, the liquid
+// fraction ((T - Ti) / (T0 - Ti))^2 between Ti = T0 - 23 and T0); restated in oracle.py, pinned by the reference's vectors at np.allclose.
+// The quotients of these formulas through a refined reciprocal instead of the IEEE division sequence (float64: ~35 instructions
+// each, four per element in q_to_r, which made the operator VALU-bound at 0.38 of the HBM peak): v_rcp + two Newton steps + one
+// residual correction, within 1 ulp of the correctly rounded quotient for the finite, normal operands these formulas see
+// (temperatures, pressures, vapour pressures; a zero or infinite divisor gives NaN where the division gives inf / 0 — no physical input).
+// ATX_HUMIDITY_IEEE_DIV=1 restores the plain division.  Measured on 137-level O1280 stacks: q_to_r 0.37 -> 0.52 (f32), 0.38 -> 0.50 (f64) of
+// 8 TB/s, r_to_d 0.56 -> 0.70 / 0.52 -> 0.57; an own float64 exp without the library's special cases and 1 or 4 vectors per lane instead of 2
+// changed nothing (profiles/r04_humidity_variants.log).
+#ifndef ATX_HUMIDITY_IEEE_DIV
+#define ATX_HUMIDITY_IEEE_DIV 0
+#endif
+__device__ __forceinline__ double quotient(double a, double b) {
+#if ATX_HUMIDITY_IEEE_DIV
+    return a / b;
+#else
+    double r = __builtin_amdgcn_rcp(b);
+    r = __builtin_fma(__builtin_fma(-b, r, 1.0), r, r);
+    r = __builtin_fma(__builtin_fma(-b, r, 1.0), r, r);
+    const double q = a * r;
+    return __builtin_fma(__builtin_fma(-b, q, a), r, q);
+#endif
+}
+__device__ __forceinline__ float quotient(float a, float b) {
+#if ATX_HUMIDITY_IEEE_DIV
+    return a / b;
+#else
+    float r = __builtin_amdgcn_rcpf(b);
+    r = __builtin_fmaf(__builtin_fmaf(-b, r, 1.0f), r, r);
+    const float q = a * r;
+    return __builtin_fmaf(__builtin_fmaf(-b, q, a), r, q);
+#endif
+}
+template <typename T>
+__device__ __forceinline__ T es_water(T t) { return T(611.21) * exp(quotient(T(17.502) * (t - T(273.16)), t - T(32.19))); }
+template <typename T>
+__device__ __forceinline__ T es_ice(T t) { return T(611.21) * exp(quotient(T(22.587) * (t - T(273.16)), t - T(-0.7))); }
+template <typename T>
+__device__ __forceinline__ T es_mixed(T t) {
+    const T t0 = T(273.16), ti = T(273.16 - 23.0);
+    T c = t < t0 ? t : t0;  // min(t0, t), max(ti, .)
+    c = c > ti ? c : ti;
+    T a = (c - ti) * (T(1) / (t0 - ti));
+    a = a * a;
+    a = a < T(1) ? a : T(1);
+    // each exponential only for the lanes it counts for (a column holds a whole profile: a wave usually has lanes on both sides, and
+    // then pays for two exponentials, not for the three branches "water / ice / both" one after the other); a NaN temperature
+    // takes neither branch and ends as NaN through `a`
+    T ew = T(0), ei = T(0);
+    if (a > T(0)) ew = es_water(t);
+    if (a < T(1)) ei = es_ice(t);
+    return a * ew + (T(1) - a) * ei;
+}
+
 // g = 9.80665 (R: constants.py:13, value pinned by filters/tabular/geopotential_to_height.py:51)
 // OP is a template parameter: every operator gets its own kernel.  With a runtime switch the float64 kernels carried the
 // inlined tanh, sincos and atan2 bodies for EVERY operator — 164-180 VGPRs, 2-3 waves per SIMD, even for `a - b` (round 2 called
@@ -226,6 +281,31 @@ __device__ __forceinline__ void combine_one(int flags, const T* x, int n_in, T l
             y0 = y;
             break;
         }
+        case ATX_COMB_R_TO_D: {  // (r, t) -> dewpoint; R: dewpoint.py:62-64 -> thermo.dewpoint_from_relative_humidity
+            T r = x[0];
+            r = (r == T(0)) ? T(1.0e-4) : r;  // `relative_humidity_values[relative_humidity_values == 0] = EPS`
+            const T e = quotient(r * es_water(x[1]), T(100));
+            const T ln = atx_log(quotient(e, T(611.21)));
+            y0 = quotient(T(32.19) * ln - T(17.502) * T(273.16), ln - T(17.502));
+            break;
+        }
+        case ATX_COMB_D_TO_R: y0 = quotient(T(100) * es_water(x[0]), es_water(x[1])); break;  // (td, t); R: dewpoint.py:71
+        case ATX_COMB_Q_TO_R: {  // (q, t[, p]); level = levelist in hPa when there is no pressure operand; R: q_to_r.py:72-74, q_height.py:117-121
+            const T eps = T(287.0597 / 461.5250);
+            const T p = n_in > 2 ? x[2] : T(100) * level;
+            const T e = quotient(p * x[0], eps + (eps * (T(1) / eps - T(1))) * x[0]);
+            y0 = quotient(T(100) * e, es_mixed(x[1]));
+            break;
+        }
+        case ATX_COMB_R_TO_Q: {  // (r, t[, p]); R: q_to_r.py:78-82, q_height.py:138-142
+            const T eps = T(287.0597 / 461.5250);
+            const T p = n_in > 2 ? x[2] : T(100) * level;
+            const T e = quotient(x[0] * es_mixed(x[1]), T(100));
+            T v = p - (T(1) - eps) * e;
+            if (p - e < T(1.0e-4)) v = quiet_nan<T>();  // specific_humidity_from_vapour_pressure: no humidity where e reaches p
+            y0 = quotient(eps * e, v);
+            break;
+        }
         default: y0 = x[0]; break;
     }
 }
@@ -306,7 +386,8 @@ combine_kernel(CombArgs a, int flags, int n_in, int n_out, int64_t n_rows, int64
     constexpr int U = comb_unroll(NIN, (int)sizeof(T), OP);
     constexpr int64_t kChunk = (int64_t)kBlock * U;
     constexpr bool kLevels = OP == ATX_COMB_W_TO_WZ || OP == ATX_COMB_WZ_TO_W || OP == ATX_COMB_OPERA_CLIP ||
-                             OP == ATX_COMB_OPERA_PREPROCESS || OP == ATX_COMB_ORAS6;  // the operators that read level_param[level]
+                             OP == ATX_COMB_OPERA_PREPROCESS || OP == ATX_COMB_ORAS6 || OP == ATX_COMB_Q_TO_R ||
+                             OP == ATX_COMB_R_TO_Q;  // the operators that read level_param[level] (when given one)
     constexpr bool kShared1 = OP == ATX_COMB_ORAS6;  // operand 1 is ONE field [n_pts] shared by every level, not a stack
     const bool small_rows = vec_per_row < (1 << 20);  // columns layout: (row, col) from 32-bit arithmetic
     // a workgroup takes a contiguous run of chunks, not every gridDim.x-th one: under the 65536-workgroup cap the grid stride is a
@@ -422,6 +503,10 @@ static int combine_typed(const CombArgs& a, int op, int flags, int n_in, int n_o
         ATX_COMB_CASE(ATX_COMB_OPERA_PREPROCESS, 3);
         ATX_COMB_CASE(ATX_COMB_ORAS6, 2);
         ATX_COMB_CASE(ATX_COMB_LOOKUP, 1);
+        ATX_COMB_CASE(ATX_COMB_R_TO_D, 2);
+        ATX_COMB_CASE(ATX_COMB_D_TO_R, 2);
+        ATX_COMB_CASE(ATX_COMB_Q_TO_R, 3);
+        ATX_COMB_CASE(ATX_COMB_R_TO_Q, 3);
         default:  // ATX_COMB_SUM
             if (vec_ok) {
                 if (n_in <= 1) ATX_COMB_LAUNCH(VEC, 1, ATX_COMB_SUM);
@@ -449,18 +534,20 @@ using namespace atx;
 extern "C" int atx_combine_stack(int op, const void* const* inputs, int32_t n_in, void* const* outputs, int32_t n_out,
                                  int64_t n_pts, int64_t n_lev, int64_t pitch, int dtype, int layout,
                                  const double* level_param, int32_t flags, void* stream) {
-    static const int kIn[ATX_COMB_COUNT_] = {2, 2, 1, 2, 3, 3, -1, 2, 2, 2, 2, 3, 2, 1};
-    static const int kOut[ATX_COMB_COUNT_] = {1, 1, 2, 1, 1, 1, 1, 1, 2, 2, 2, 2, 1, 1};
+    static const int kIn[ATX_COMB_COUNT_] = {2, 2, 1, 2, 3, 3, -1, 2, 2, 2, 2, 3, 2, 1, 2, 2, -2, -2};  // -1: any number, -2: two or three
+    static const int kOut[ATX_COMB_COUNT_] = {1, 1, 2, 1, 1, 1, 1, 1, 2, 2, 2, 2, 1, 1, 1, 1, 1, 1};
     ATX_REQUIRE(op >= 0 && op < ATX_COMB_COUNT_, ATX_EINVAL, "atx_combine_stack: bad operator %d", op);
     ATX_REQUIRE(inputs && outputs, ATX_EINVAL, "atx_combine_stack: null pointer table");
     ATX_REQUIRE(n_in >= 1 && n_in <= ATX_COMB_MAX_INPUTS, ATX_EINVAL, "atx_combine_stack: n_in=%d outside [1, %d]", n_in, ATX_COMB_MAX_INPUTS);
     ATX_REQUIRE(kIn[op] < 0 || kIn[op] == n_in, ATX_EINVAL, "atx_combine_stack: operator %d takes %d inputs, got %d", op, kIn[op], n_in);
+    ATX_REQUIRE(kIn[op] != -2 || n_in == 2 || n_in == 3, ATX_EINVAL, "atx_combine_stack: operator %d takes 2 or 3 inputs, got %d", op, n_in);
     ATX_REQUIRE(kOut[op] == n_out, ATX_EINVAL, "atx_combine_stack: operator %d gives %d outputs, got %d", op, kOut[op], n_out);
     ATX_REQUIRE(dtype == ATX_F32 || dtype == ATX_F64, ATX_EINVAL, "atx_combine_stack: bad dtype %d", dtype);
     ATX_REQUIRE(layout == ATX_COLUMNS || layout == ATX_FIELDS, ATX_EINVAL, "atx_combine_stack: bad layout %d", layout);
     ATX_REQUIRE(n_pts >= 0 && n_lev > 0 && n_lev <= INT32_MAX, ATX_EINVAL, "atx_combine_stack: bad sizes");
     ATX_REQUIRE(pitch >= (layout == ATX_COLUMNS ? n_lev : n_pts), ATX_ESHAPE, "atx_combine_stack: pitch %lld too small", (long long)pitch);
-    const bool reads_param = op == ATX_COMB_W_TO_WZ || op == ATX_COMB_WZ_TO_W || op >= ATX_COMB_OPERA_CLIP;
+    const bool reads_param = op == ATX_COMB_W_TO_WZ || op == ATX_COMB_WZ_TO_W || (op >= ATX_COMB_OPERA_CLIP && op <= ATX_COMB_LOOKUP) ||
+                             ((op == ATX_COMB_Q_TO_R || op == ATX_COMB_R_TO_Q) && n_in == 2);
     ATX_REQUIRE(level_param || !reads_param, ATX_EINVAL, "atx_combine_stack: operator %d needs level_param", op);
     CombArgs a{};
     for (int k = 0; k < n_in; ++k) {

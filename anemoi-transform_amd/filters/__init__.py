@@ -6,7 +6,8 @@ Registered names:
                   lnsp_to_sp, sp_to_lnsp, glacier_mask, noop,
                   snow_depth_m, snow_cover, cos_sin_from_rad, cos_sin_mean_wave_direction,
                   w_to_wz, wz_to_w, uv_to_ddff, ddff_to_uv, sum, accum_to_interval   (multi-input, filters/multi.py)
-                  rodeo_opera_clipping, rodeo_opera_preprocessing, oras6_clipping, land_parameters
+                  rodeo_opera_clipping, rodeo_opera_preprocessing, oras6_clipping, land_parameters,
+                  r_to_d, d_to_r, q_to_r, r_to_q, q_to_r_height_with_p, r_to_q_height_with_p
                                                              (multi-input, filters/domain.py)
                   rename_fields, clear_step, repeat_members, earthkitfieldlambda, empty,
                   icon_refinement_level   (re-labelling / re-listing, filters/metadata.py)

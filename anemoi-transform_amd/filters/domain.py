@@ -1,11 +1,20 @@
-"""The reference's remaining numpy-only per-point filters (no third-party arithmetic behind them):
+"""Domain filters of the reference's MatchingFieldsFilter family.
+
+Numpy-only in the reference (no third-party arithmetic behind them), bit for bit here:
 
   rodeo_opera_clipping        R: filters/fields/rodeo_opera_clipping.py
   rodeo_opera_preprocessing   R: filters/fields/rodeo_opera_preprocessing.py
   oras6_clipping              R: filters/fields/oras6_clipping.py
   land_parameters             R: filters/fields/land_parameters.py
 
-All four are ``MatchingFieldsFilter``s there: fields grouped by their MARS key minus ``param``, one numpy expression per group.
+Humidity conversions whose arithmetic is earthkit-meteo's (restated from its published formulas, pinned by the reference's test
+vectors at np.allclose — second half of this file):
+
+  r_to_d / d_to_r                                 R: filters/fields/dewpoint.py
+  q_to_r / r_to_q                                 R: filters/fields/q_to_r.py
+  q_to_r_height_with_p / r_to_q_height_with_p     R: filters/fields/q_height.py:57-152
+
+The first four are ``MatchingFieldsFilter``s there: fields grouped by their MARS key minus ``param``, one numpy expression per group.
 Here the OPERA filters run ONE ``atx_combine_stack`` launch for all groups (``StackMatchingFilter``); ``oras6_clipping`` runs one
 launch per group over the group's 14 fields (they share ONE ice mask, the group's ``siconc``); ``land_parameters`` runs one table
 look-up launch per output variable.
@@ -206,3 +215,117 @@ class LandParameters(MatchingFieldsFilter):
                 raise TypeError(f"unhashable type: 'numpy.ndarray' (land_parameters takes 1-D fields, got shape {tuple(template.shape)})")
             for name, stack in zip(names, read_crosswalking_table(fields_to_stack([template]), table)):
                 yield new_field_from_stack(stack, 0, template=template, metadata=dict(param=name))
+
+
+# =================================================================================
+# humidity conversions (the arithmetic is earthkit-meteo's thermo.array, restated in atx_combine.hip from its published form
+# and pinned by the reference's test vectors at np.allclose — see oracle.py)
+# =================================================================================
+class DewPoint(StackMatchingFilter):
+    """Relative humidity (%) and temperature (K) -> dewpoint temperature (K), and back (R: filters/fields/dewpoint.py:24-76).
+    A relative humidity of exactly 0 is replaced by 1e-4 before the dewpoint is taken, as in the reference."""
+
+    MATCHING = MatchingSpec(select="param", forward=("relative_humidity", "temperature"), backward=("dewpoint", "temperature"))
+
+    def __init__(self, *, relative_humidity: str = "r", temperature: str = "t", dewpoint: str = "d", return_inputs: Any = "all") -> None:
+        self.return_inputs = return_inputs
+        self.relative_humidity = relative_humidity
+        self.temperature = temperature
+        self.dewpoint = dewpoint
+        super().__init__()
+
+    def forward_plan(self, relative_humidity: Any, temperature: Any):
+        return native.COMB_R_TO_D, 0, [(relative_humidity, dict(param=self.dewpoint))], None
+
+    def backward_plan(self, dewpoint: Any, temperature: Any):
+        return native.COMB_D_TO_R, 0, [(temperature, dict(param=self.relative_humidity))], None
+
+    def forward_transform(self, relative_humidity: Any = None, temperature: Any = None) -> Iterator[Any]:
+        return super().forward_transform(relative_humidity=relative_humidity, temperature=temperature)
+
+    def backward_transform(self, dewpoint: Any = None, temperature: Any = None) -> Iterator[Any]:
+        return super().backward_transform(dewpoint=dewpoint, temperature=temperature)
+
+
+filter_registry.register("r_to_d", DewPoint)
+filter_registry.register("d_to_r", DewPoint.reversed)
+
+
+def _pressure_level(field: Any) -> float:
+    return float(field.metadata("levelist"))  # hPa; the kernel multiplies by 100 (R: q_to_r.py:72, :78)
+
+
+class HumidityConversion(StackMatchingFilter):
+    """Specific humidity (kg/kg) and temperature on a pressure level -> relative humidity (%), and back
+    (R: filters/fields/q_to_r.py:21-84).  The pressure is 100 x the ``levelist`` of the humidity (forward) or temperature (backward) field."""
+
+    MATCHING = MatchingSpec(select="param", forward=("humidity", "temperature"), backward=("relative_humidity", "temperature"))
+
+    def __init__(self, *, relative_humidity: str = "r", temperature: str = "t", humidity: str = "q", return_inputs: Any = "all") -> None:
+        self.return_inputs = return_inputs
+        self.relative_humidity = relative_humidity
+        self.temperature = temperature
+        self.humidity = humidity
+        super().__init__()
+
+    def forward_plan(self, humidity: Any, temperature: Any):
+        return native.COMB_Q_TO_R, 0, [(humidity, dict(param=self.relative_humidity))], _pressure_level(humidity)
+
+    def backward_plan(self, relative_humidity: Any, temperature: Any):
+        return native.COMB_R_TO_Q, 0, [(relative_humidity, dict(param=self.humidity))], _pressure_level(temperature)
+
+    def forward_transform(self, humidity: Any = None, temperature: Any = None) -> Iterator[Any]:
+        return super().forward_transform(humidity=humidity, temperature=temperature)
+
+    def backward_transform(self, relative_humidity: Any = None, temperature: Any = None) -> Iterator[Any]:
+        return super().backward_transform(relative_humidity=relative_humidity, temperature=temperature)
+
+
+filter_registry.register("q_to_r", HumidityConversion)
+filter_registry.register("r_to_q", HumidityConversion.reversed)
+
+
+class SpecificToRelativeAtHeightLevelWithP(StackMatchingFilter):
+    """The same conversion with the pressure given as a third field (Pa), e.g. on height levels
+    (R: filters/fields/q_height.py:57-152).  The two other filters of that file (``q_to_r_height``, ``q_to_d_height``) derive the
+    pressure from model levels with earthkit-meteo's ``vertical.pressure_at_height_levels`` and are not implemented."""
+
+    MATCHING = MatchingSpec(
+        select="param",
+        forward=("specific_humidity_at_height_level", "temperature_at_height_level", "pressure_at_height_level"),
+        backward=("relative_humidity_at_height_level", "temperature_at_height_level", "pressure_at_height_level"),
+        vertical=False,
+    )
+
+    def __init__(self, *, specific_humidity_at_height_level: str = "q", relative_humidity_at_height_level: str = "r",
+                 pressure_at_height_level: str = "pres", temperature_at_height_level: str = "t",
+                 return_inputs: Any = ("specific_humidity_at_height_level", "relative_humidity_at_height_level",
+                                       "temperature_at_height_level", "pressure_at_height_level")) -> None:
+        self.return_inputs = return_inputs
+        self.specific_humidity_at_height_level = specific_humidity_at_height_level
+        self.relative_humidity_at_height_level = relative_humidity_at_height_level
+        self.temperature_at_height_level = temperature_at_height_level
+        self.pressure_at_height_level = pressure_at_height_level
+        super().__init__()
+
+    def forward_plan(self, specific_humidity_at_height_level: Any, temperature_at_height_level: Any, pressure_at_height_level: Any):
+        return (native.COMB_Q_TO_R, 0, [(specific_humidity_at_height_level, dict(param=self.relative_humidity_at_height_level))], None)
+
+    def backward_plan(self, relative_humidity_at_height_level: Any, temperature_at_height_level: Any, pressure_at_height_level: Any):
+        return (native.COMB_R_TO_Q, 0, [(relative_humidity_at_height_level, dict(param=self.specific_humidity_at_height_level))], None)
+
+    def forward_transform(self, specific_humidity_at_height_level: Any = None, temperature_at_height_level: Any = None,
+                          pressure_at_height_level: Any = None) -> Iterator[Any]:
+        return super().forward_transform(specific_humidity_at_height_level=specific_humidity_at_height_level,
+                                         temperature_at_height_level=temperature_at_height_level,
+                                         pressure_at_height_level=pressure_at_height_level)
+
+    def backward_transform(self, relative_humidity_at_height_level: Any = None, temperature_at_height_level: Any = None,
+                           pressure_at_height_level: Any = None) -> Iterator[Any]:
+        return super().backward_transform(relative_humidity_at_height_level=relative_humidity_at_height_level,
+                                          temperature_at_height_level=temperature_at_height_level,
+                                          pressure_at_height_level=pressure_at_height_level)
+
+
+filter_registry.register("q_to_r_height_with_p", SpecificToRelativeAtHeightLevelWithP)
+filter_registry.register("r_to_q_height_with_p", SpecificToRelativeAtHeightLevelWithP.reversed)

@@ -40,7 +40,8 @@ CMP_GT, CMP_LT, CMP_EQ, CMP_NE, CMP_GE, CMP_LE, CMP_NOTNAN, CMP_ISNAN = range(8)
 ) = range(10)
 RED_MIN, RED_MAX, RED_NANCOUNT, RED_MINMAX = range(4)
 (COMB_SNOW_DEPTH_M, COMB_SNOW_COVER, COMB_COS_SIN, COMB_ATAN2, COMB_W_TO_WZ, COMB_WZ_TO_W, COMB_SUM, COMB_SUB, COMB_XY_TO_POLAR,
- COMB_POLAR_TO_XY, COMB_OPERA_CLIP, COMB_OPERA_PREPROCESS, COMB_ORAS6, COMB_LOOKUP) = range(14)
+ COMB_POLAR_TO_XY, COMB_OPERA_CLIP, COMB_OPERA_PREPROCESS, COMB_ORAS6, COMB_LOOKUP, COMB_R_TO_D, COMB_D_TO_R, COMB_Q_TO_R,
+ COMB_R_TO_Q) = range(18)
 # what a level of a COMB_ORAS6 stack holds (ATX_ORAS6_* of atx.h)
 ORAS6_KEEP, ORAS6_ZERO, ORAS6_TEMPERATURE, ORAS6_CELSIUS, ORAS6_HEAT, ORAS6_SURFACE = range(6)
 COMB_DEGREES = 1

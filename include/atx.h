@@ -44,7 +44,7 @@
 extern "C" {
 #endif
 
-#define ATX_VERSION 410 /* 0.4.1 — four more multi-input operators (ATX_COMB_OPERA_CLIP .. ATX_COMB_LOOKUP); nothing else changed.
+#define ATX_VERSION 410 /* 0.4.1 — eight more multi-input operators (ATX_COMB_OPERA_CLIP .. ATX_COMB_R_TO_Q); nothing else changed.
                            * 0.4.0 — round 4: atx_vector_program takes the CAPACITY of `out` (ATX_EWORKSPACE when too small — 0.3 wrote its
                            * grown table without asking), atx_reduce* keep the no-atomics route for every shape when given a workspace.
                            * 0.3.0 — round 3: atx_reduce* take a workspace, atx_regrid_*_ordered, two more multi-input operators, and the
@@ -280,7 +280,15 @@ typedef enum {
                                   level; level_param[l] = what level l is, an ATX_ORAS6_* code    R: filters/fields/oras6_clipping.py:189-215 */
     ATX_COMB_LOOKUP = 13,      /* (class) -> table[class]; level_param = double[1 + n]: n, then the value of class 0 .. n-1; a class that is
                                   not one of 0 .. n-1 (the reference's KeyError) gives NaN        R: filters/fields/land_parameters.py:71 */
-    ATX_COMB_COUNT_ = 14
+    /* humidity conversions: the arithmetic is earthkit-meteo's (thermo.array; IFS saturation formulas), restated from its published form */
+    ATX_COMB_R_TO_D = 14,      /* (r %, t) -> dewpoint: r == 0 -> 1e-4 first; e = r*es_water(t)/100; T(e) = (32.19 ln(e/611.21) - 17.502*273.16) /
+                                  (ln(e/611.21) - 17.502)                               R: filters/fields/dewpoint.py:59-65               */
+    ATX_COMB_D_TO_R = 15,      /* (td, t) -> 100*es_water(td)/es_water(t)                R: dewpoint.py:67-72                              */
+    ATX_COMB_Q_TO_R = 16,      /* (q, t) or (q, t, p) -> 100*e/es_mixed(t), e = p q/(eps + (1-eps) q), eps = 287.0597/461.5250; without a
+                                  pressure operand p = 100*level_param[l] (levelist, hPa)   R: filters/fields/q_to_r.py:70-75, q_height.py:117-121 */
+    ATX_COMB_R_TO_Q = 17,      /* (r, t) or (r, t, p) -> eps e/(p - (1-eps) e), e = r*es_mixed(t)/100; NaN where p - e < 1e-4
+                                                                                         R: q_to_r.py:77-83, q_height.py:138-142           */
+    ATX_COMB_COUNT_ = 18
 } atx_comb;
 #define ATX_COMB_DEGREES 1
 #define ATX_COMB_MAX_INPUTS 8
@@ -292,8 +300,8 @@ typedef enum {
 #define ATX_ORAS6_HEAT 4        /* 0 where there is no ice, then 0 wherever the value is >= -1e-5 (sihc, snhc) */
 #define ATX_ORAS6_SURFACE 5     /* tos: raised to 271.15 - 1e-5 where it is at or below it; the ice mask is not used */
 /* inputs / outputs: HOST arrays of n_in / n_out DEVICE pointers (n_in <= ATX_COMB_MAX_INPUTS, n_out <= 2).
- * level_param: device double[n_lev] or NULL (required by the W/WZ operators and by the operators from 10 on, which say above
- * what they read from it).
+ * level_param: device double[n_lev] or NULL (required by the W/WZ operators and by operators 10 to 13, which say above what they
+ * read from it, and by operators 16 / 17 when they get no pressure operand).
  * All stacks share n_pts, n_lev, pitch and layout; the padding of the outputs (elements between a row's length and the pitch) is
  * written with zeros. */
 int atx_combine_stack(int op, const void* const* inputs, int32_t n_in, void* const* outputs, int32_t n_out,

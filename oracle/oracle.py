@@ -585,6 +585,64 @@ def interval_difference(current, previous):
     return current - previous
 
 
+# ---- humidity conversions: earthkit-meteo's thermo.array functions, restated -----------------------------------------------------
+# R: filters/fields/dewpoint.py:62-71, q_to_r.py:72-82 and q_height.py:117-142 call ``earthkit.meteo.thermo[.array]`` — third-party
+# (earthkit-meteo >= 0.4.1, pyproject.toml:40; absent here).  Its published definitions, restated: the IFS saturation formulas
+# es(T) = c1 exp(c3 (T - T0) / (T - c4)) over water (17.502, 32.19) and ice (22.587, -0.7) with c1 = 611.21 Pa, T0 = 273.16 K; the
+# default "mixed" phase blends them with the liquid fraction ((T - Ti) / (T0 - Ti))^2, Ti = T0 - 23, held at 0 below Ti and 1 above T0;
+# epsilon = Rd / Rv = 287.0597 / 461.5250.  Pinned by the reference's own vectors (tests/field_filters/test_dewpoint.py:25-29,
+# test_pressure_level_humidity.py:27-40) at those tests' np.allclose — not bit for bit.
+MET_C1, MET_T0, MET_TI = 611.21, 273.16, 273.16 - 23.0
+MET_EPSILON = 287.0597 / 461.5250
+
+
+def es_water(t):
+    return MET_C1 * np.exp(17.502 * (t - MET_T0) / (t - 32.19))
+
+
+def es_ice(t):
+    return MET_C1 * np.exp(22.587 * (t - MET_T0) / (t - (-0.7)))
+
+
+def es_mixed(t):
+    """saturation_vapour_pressure(t) with its default phase "mixed"."""
+    alpha = np.minimum(1.0, (np.maximum(MET_TI, np.minimum(MET_T0, t)) - MET_TI) * (1.0 / (MET_T0 - MET_TI)) ) ** 2
+    return alpha * es_water(t) + (1.0 - alpha) * es_ice(t)
+
+
+def dewpoint_from_relative_humidity(relative_humidity, temperature):
+    """R: dewpoint.py:61-63 (the zero guard, EPS = 1e-4) -> thermo.dewpoint_from_relative_humidity: e = r es_water(t) / 100, then the
+    inverse of the water formula."""
+    r = np.array(relative_humidity, copy=True)
+    r[r == 0] = 1.0e-4
+    with np.errstate(all="ignore"):
+        lnes = np.log(r * es_water(temperature) / 100.0 / MET_C1)
+        return (32.19 * lnes - 17.502 * MET_T0) / (lnes - 17.502)
+
+
+def relative_humidity_from_dewpoint(dewpoint, temperature):
+    """R: dewpoint.py:71 -> thermo.relative_humidity_from_dewpoint: both pressures over water."""
+    with np.errstate(all="ignore"):
+        return 100.0 * es_water(dewpoint) / es_water(temperature)
+
+
+def relative_humidity_from_specific_humidity(temperature, q, pressure):
+    """R: q_to_r.py:73 / q_height.py:117 -> thermo.relative_humidity_from_specific_humidity: e = p q / (eps + eps (1/eps - 1) q)."""
+    with np.errstate(all="ignore"):
+        e = (pressure * q) / (MET_EPSILON + (MET_EPSILON * (1.0 / MET_EPSILON - 1.0)) * q)
+        return 100.0 * e / es_mixed(temperature)
+
+
+def specific_humidity_from_relative_humidity(temperature, r, pressure):
+    """R: q_to_r.py:79 / q_height.py:138 -> thermo.specific_humidity_from_relative_humidity: q = eps e / (p - (1 - eps) e), NaN where
+    p - e < 1e-4 (specific_humidity_from_vapour_pressure's guard)."""
+    with np.errstate(all="ignore"):
+        e = r * es_mixed(temperature) / 100.0
+        v = np.asarray(pressure - (1.0 - MET_EPSILON) * e).copy()
+        v[np.asarray(pressure - e) < 1.0e-4] = np.nan
+        return MET_EPSILON * e / v
+
+
 # ---- OPERA radar composites (R: filters/fields/rodeo_opera_preprocessing.py, rodeo_opera_clipping.py) -----------------------
 def opera_clip_variable(variable, max_value):
     """R: rodeo_opera_preprocessing.py:34-37 — two boolean-mask assignments: a NaN fails both tests and stays, and so does -0.0."""

@@ -195,6 +195,14 @@ def combine_stack(op, inputs, outputs, *, n_pts, n_lev, pitch, layout, level_par
             ys[0][l], ys[1][l] = oracle.xy_to_polar(a[0], a[1])
         elif op == native.COMB_POLAR_TO_XY:
             ys[0][l], ys[1][l] = oracle.polar_to_xy(a[0], a[1])
+        elif op == native.COMB_R_TO_D:
+            ys[0][l] = oracle.dewpoint_from_relative_humidity(a[0], a[1])
+        elif op == native.COMB_D_TO_R:
+            ys[0][l] = oracle.relative_humidity_from_dewpoint(a[0], a[1])
+        elif op in (native.COMB_Q_TO_R, native.COMB_R_TO_Q):
+            pressure = a[2] if len(a) > 2 else dt(100.0) * dt(float(level_param[l]))
+            fn = oracle.relative_humidity_from_specific_humidity if op == native.COMB_Q_TO_R else oracle.specific_humidity_from_relative_humidity
+            ys[0][l] = fn(a[1], a[0], pressure).astype(dt)
         elif op == native.COMB_OPERA_CLIP:
             ys[0][l], ys[1][l] = oracle.opera_clipping(a[0], a[1], float(level_param[l]))
         elif op == native.COMB_OPERA_PREPROCESS:

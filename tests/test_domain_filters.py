@@ -288,3 +288,186 @@ def test_domain_kernels_bit_for_bit(dev, np_dtype, layout):
     ok[0, :4] = False
     assert np.array_equal(got[ok], np.array(table)[classes[ok].astype(int)].astype(np_dtype))
     assert got.dtype == np_dtype and tdtype in (torch.float32, torch.float64)
+
+
+# =================================================================================
+# humidity conversions (R: tests/field_filters/test_dewpoint.py, test_pressure_level_humidity.py, test_q_height_with_p.py)
+# =================================================================================
+def arr(x):
+    return np.array(x, dtype=np.float64)
+
+
+def fields_equal(a, b):
+    """R: tests/utils/__init__.py:26-55 `assert_fields_equal`, the keys these tests use."""
+    for key in ("param", "valid_datetime", "levelist"):
+        assert a.metadata(key, default=None) == b.metadata(key, default=None)
+    assert np.allclose(a.to_numpy(), b.to_numpy(), equal_nan=True)
+    return True
+
+
+def select(fields, params):
+    """R: tests/utils/__init__.py `SelectFieldSource`: the fields of some params, as a source."""
+    return test_source_from([f for f in fields if f.metadata("param") in params])
+
+
+def test_source_from(fields):
+    from anemoi_transform_amd.core import source_registry
+    from anemoi_transform_amd.fields import FieldList
+
+    return source_registry.create("testing", dataset=FieldList(list(fields)))
+
+
+test_source_from.__test__ = False
+
+
+def test_oracle_humidity_statements_against_the_reference_vectors():
+    """The restated earthkit-meteo functions against the reference's literals, at its tests' own tolerance (np.allclose defaults)."""
+    d = GOLDEN["dewpoint"]
+    assert np.allclose(oracle.dewpoint_from_relative_humidity(arr(d["r"]), arr(d["t"])), arr(d["d"]))
+    assert np.allclose(oracle.relative_humidity_from_dewpoint(arr(d["d"]), arr(d["t"])), arr(d["r"]))
+    h = GOLDEN["pressure_level_humidity"]
+    for level in h["levels"]:
+        t, q, r = (arr(h[k][str(level)]) for k in ("t", "q", "r"))
+        assert np.allclose(oracle.relative_humidity_from_specific_humidity(t, q, 100.0 * level), r)
+        assert np.allclose(oracle.specific_humidity_from_relative_humidity(t, r, 100.0 * level), q)
+    # both phases are exercised by those vectors: 248.9 K and 250.15 K lie below Ti = 250.16 K (ice only), 260.5 K and 271.3 K in between
+    assert (arr(h["t"]["850"]) < oracle.MET_TI).any() and ((arr(h["t"]["850"]) > oracle.MET_TI) & (arr(h["t"]["850"]) < oracle.MET_T0)).any()
+    # the guard of specific_humidity_from_vapour_pressure and the zero guard of the dewpoint filter
+    assert np.isnan(oracle.specific_humidity_from_relative_humidity(np.array([373.0]), np.array([200.0]), 50000.0)[0])
+    assert np.isfinite(oracle.dewpoint_from_relative_humidity(np.array([0.0]), np.array([280.0]))[0])
+
+
+def test_relative_humidity_to_dewpoint(engine):
+    """R: test_dewpoint.py:49-70."""
+    g = GOLDEN["dewpoint"]
+    src = test_source([{"param": "r", "values": arr(g["r"]), **MD}, {"param": "t", "values": arr(g["t"]), **MD}])
+    inputs, out = collect_fields_by_param(src), collect_fields_by_param(src | create_filter_by_name("r_to_d"))
+    assert set(out) == {"r", "t", "d"} and len(out["d"]) == 1
+    assert all(fields_equal(inputs[p][0], out[p][0]) for p in ("r", "t"))
+    assert np.allclose(out["d"][0].to_numpy(), arr(g["d"]))
+    np.testing.assert_allclose(out["d"][0].to_numpy(), oracle.dewpoint_from_relative_humidity(arr(g["r"]), arr(g["t"])), rtol=1e-13)
+
+
+def test_dewpoint_to_relative_humidity_and_round_trip(engine):
+    """R: test_dewpoint.py:73-97, :127-146."""
+    g = GOLDEN["dewpoint"]
+    dsrc = test_source([{"param": "d", "values": arr(g["d"]), **MD}, {"param": "t", "values": arr(g["t"]), **MD}])
+    out = collect_fields_by_param(dsrc | create_filter_by_name("d_to_r"))
+    assert set(out) == {"d", "t", "r"} and np.allclose(out["r"][0].to_numpy(), arr(g["r"]))
+    src = test_source([{"param": "r", "values": arr(g["r"]), **MD}, {"param": "t", "values": arr(g["t"]), **MD}])
+    mid = list(src | create_filter_by_name("r_to_d"))
+    back = collect_fields_by_param(select(mid, ["t", "d"]) | create_filter_by_name("d_to_r"))  # r dropped: it has to be reconstructed
+    assert set(back) == {"r", "d", "t"}
+    assert np.allclose(back["r"][0].to_numpy(), arr(g["r"])) and fields_equal(back["t"][0], collect_fields_by_param(src)["t"][0])
+
+
+def test_zero_relative_humidity_is_guarded(engine):
+    """R: dewpoint.py:62 — r == 0 becomes 1e-4 before the dewpoint is taken (finite result)."""
+    r, t = np.array([[0.0, 50.0]]), np.array([[280.0, 280.0]])
+    md = {"latitudes": [0.0], "longitudes": [0.0, 1.0]}
+    out = collect_fields_by_param(test_source([{"param": "r", "values": r, **md}, {"param": "t", "values": t, **md}]) | create_filter_by_name("r_to_d", return_inputs="none"))
+    assert set(out) == {"d"}
+    got = out["d"][0].to_numpy()
+    assert np.isfinite(got).all() and got[0, 0] < got[0, 1] < 280.0
+    np.testing.assert_allclose(got, oracle.dewpoint_from_relative_humidity(r, t), rtol=1e-13)
+
+
+def _humidity_specs(g, name):
+    return [{"param": p, "levelist": level, "values": arr(g[key][str(level)]), **MD} for level in g["levels"] for p, key in ((name, name), ("t", "t"))]
+
+
+def test_pressure_level_specific_humidity_to_relative_humidity(engine):
+    """R: test_pressure_level_humidity.py:65-86."""
+    g = GOLDEN["pressure_level_humidity"]
+    src = test_source(_humidity_specs(g, "q"))
+    inputs, out = collect_fields_by_param(src), collect_fields_by_param(src | create_filter_by_name("q_to_r"))
+    assert set(out) == {"q", "t", "r"}
+    for p in ("q", "t"):
+        assert all(fields_equal(a, b) for a, b in zip(inputs[p], out[p]))
+    by_level = {f.metadata("levelist"): f.to_numpy() for f in out["r"]}
+    assert set(by_level) == {850, 1000}
+    for level, got in by_level.items():
+        assert np.allclose(got, arr(g["r"][str(level)]))
+        want = oracle.relative_humidity_from_specific_humidity(arr(g["t"][str(level)]), arr(g["q"][str(level)]), 100.0 * level)
+        np.testing.assert_allclose(got, want, rtol=1e-13)
+
+
+def test_pressure_level_relative_humidity_to_specific_humidity_and_round_trips(engine):
+    """R: test_pressure_level_humidity.py:89-114, :141-190."""
+    g = GOLDEN["pressure_level_humidity"]
+    rsrc = test_source(_humidity_specs(g, "r"))
+    out = collect_fields_by_param(rsrc | create_filter_by_name("r_to_q"))
+    assert set(out) == {"r", "t", "q"}
+    for f in out["q"]:
+        assert np.allclose(f.to_numpy(), arr(g["q"][str(f.metadata("levelist"))]))
+    qsrc = test_source(_humidity_specs(g, "q"))
+    mid = list(qsrc | create_filter_by_name("q_to_r"))
+    back = collect_fields_by_param(select(mid, ["r", "t"]) | create_filter_by_name("r_to_q"))
+    assert set(back) == {"q", "t", "r"}
+    for f in back["q"]:
+        assert np.allclose(f.to_numpy(), arr(g["q"][str(f.metadata("levelist"))]))
+    with pytest.raises(KeyError):  # R: q_to_r.py:72 `humidity.metadata("levelist")` of a field without a level
+        list(test_source([{"param": "q", "values": arr(g["q"]["850"]), **MD}, {"param": "t", "values": arr(g["t"]["850"]), **MD}]) | create_filter_by_name("q_to_r"))
+
+
+def test_q_to_r_height_with_p_and_round_trip(engine):
+    """R: test_q_height_with_p.py:57-110 (its expected values are computed by earthkit-meteo there; here by the oracle's restatement)."""
+    g = GOLDEN["height_level_humidity_with_p"]
+    t, q, p = arr(g["t"]), arr(g["q"]), arr(g["p"])
+    src = test_source([{"param": "q", "values": q.copy(), **MD}, {"param": "t", "values": t.copy(), **MD}, {"param": "pres", "values": p.copy(), **MD}])
+    inputs, out = collect_fields_by_param(src), collect_fields_by_param(src | create_filter_by_name("q_to_r_height_with_p"))
+    assert set(out) == {"q", "t", "pres", "r"}
+    assert all(fields_equal(inputs[k][0], out[k][0]) for k in ("q", "t", "pres"))
+    want = oracle.relative_humidity_from_specific_humidity(t, q, p)
+    np.testing.assert_allclose(out["r"][0].to_numpy(), want, rtol=1e-13)
+    assert (want > 20).all() and (want < 140).all()
+    mid = list(src | create_filter_by_name("q_to_r_height_with_p"))
+    back = collect_fields_by_param(select(mid, ["r", "t", "pres"]) | create_filter_by_name("r_to_q_height_with_p"))
+    assert set(back) == {"q", "t", "pres", "r"}
+    np.testing.assert_allclose(back["q"][0].to_numpy(), q)  # the reference's round-trip tolerance (assert_allclose defaults)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("np_dtype,rtol", [(np.float64, 2e-13), (np.float32, 2e-5)], ids=["f64", "f32"])
+@pytest.mark.parametrize("layout", [native.COLUMNS, native.FIELDS], ids=["columns", "fields"])
+def test_humidity_kernels_vs_oracle(dev, np_dtype, rtol, layout):
+    """Floating point with exp / log from the device library: held to the numpy restatement within a few ulp of the result
+    (float64 2e-13, float32 2e-5 relative) on the ranges the atmosphere has, all three phases of the saturation curve included."""
+    from anemoi_transform_amd.stack import Stack
+
+    rng = np.random.default_rng(41)
+    n_lev, n_pts = 6, 30011
+    t = rng.uniform(190.0, 320.0, (n_lev, n_pts)).astype(np_dtype)
+    t[:, :4] = np.array([250.16, 273.16, 250.15999, 273.16001], dtype=np_dtype)  # the ends of the mixed phase
+    r = rng.uniform(0.5, 110.0, (n_lev, n_pts)).astype(np_dtype)
+    r[0, 4:6] = [0.0, 100.0]
+    q = (10.0 ** rng.uniform(-6, -1.7, (n_lev, n_pts))).astype(np_dtype)
+    p = rng.uniform(20000.0, 105000.0, (n_lev, n_pts)).astype(np_dtype)
+    levels = np.array([50.0, 200.0, 500.0, 700.0, 850.0, 1000.0])
+
+    def run(op, ins, level_param=None):
+        stacks = [Stack.from_fields(x, dev=dev, layout=layout) for x in ins]
+        out = stacks[0].new_like(zero=False)
+        lp = None if level_param is None else torch.from_numpy(level_param).to(dev)
+        native.combine_stack(op, [s.data for s in stacks], [out.data], n_pts=n_pts, n_lev=n_lev, pitch=stacks[0].pitch, layout=layout, level_param=lp)
+        return out.numpy()
+
+    def close(got, want):
+        assert got.dtype == np_dtype
+        ok = np.isfinite(want)
+        assert np.array_equal(np.isnan(got), np.isnan(want))
+        np.testing.assert_allclose(got[ok], want[ok].astype(np_dtype), rtol=rtol)
+
+    td = oracle.dewpoint_from_relative_humidity(r, t).astype(np_dtype)
+    close(run(native.COMB_R_TO_D, [r, t]), td)
+    close(run(native.COMB_D_TO_R, [td, t]), oracle.relative_humidity_from_dewpoint(td, t))
+    close(run(native.COMB_Q_TO_R, [q, t, p]), oracle.relative_humidity_from_specific_humidity(t, q, p))
+    close(run(native.COMB_R_TO_Q, [r, t, p]), oracle.specific_humidity_from_relative_humidity(t, r, p))
+    want = np.stack([oracle.relative_humidity_from_specific_humidity(t[l], q[l], np_dtype(100.0) * np_dtype(levels[l])) for l in range(n_lev)])
+    close(run(native.COMB_Q_TO_R, [q, t], levels), want)
+    want = np.stack([oracle.specific_humidity_from_relative_humidity(t[l], r[l], np_dtype(100.0) * np_dtype(levels[l])) for l in range(n_lev)])
+    got = run(native.COMB_R_TO_Q, [r, t], levels)
+    close(got, want)
+    assert np.isnan(want).any()  # hot and humid at 50 hPa: e reaches p, the guard gives NaN on both sides
+    with pytest.raises(ValueError):
+        run(native.COMB_Q_TO_R, [q, t])  # two operands and no level_param

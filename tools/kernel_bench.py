@@ -193,6 +193,16 @@ def main():
         record(f"combine opera_preprocessing (3->2) {tag}", timeit(lambda: native.combine_stack(native.COMB_OPERA_PREPROCESS, [x.data, y.data, dm.data], [z.data, w2.data],
                n_pts=n_src, n_lev=L, pitch=x.pitch, layout=COLUMNS, level_param=lim)), 5 * stack_bytes)
         del dm, w2
+        # humidity conversions: q in [1e-6, 2e-2], t in [190, 320] K — water, mixed and ice branches of the saturation curve all present
+        qh, th = x.new_like(), x.new_like()
+        qh.data[:, :L] = (10.0 ** (-6.0 + 4.3 * torch.rand(n_src, L, device=dev))).to(tdt)
+        th.data[:, :L] = (190.0 + 130.0 * torch.rand(n_src, L, device=dev)).to(tdt)
+        plev = torch.linspace(1.0, 1000.0, L, dtype=torch.float64, device=dev)
+        record(f"combine q_to_r (2->1) {tag}", timeit(lambda: native.combine_stack(native.COMB_Q_TO_R, [qh.data, th.data], [z.data],
+               n_pts=n_src, n_lev=L, pitch=x.pitch, layout=COLUMNS, level_param=plev)), 3 * stack_bytes, "one or two exp per element (mixed phase)")
+        record(f"combine r_to_d (2->1) {tag}", timeit(lambda: native.combine_stack(native.COMB_R_TO_D, [y.data, th.data], [z.data],
+               n_pts=n_src, n_lev=L, pitch=x.pitch, layout=COLUMNS)), 3 * stack_bytes, "one exp and one log per element")
+        del qh, th
         # one ORAS6 group: 14 fields and the ice concentration they share
         o_in, o_out = Stack.empty(n_src, 14, tdt, dev, COLUMNS), Stack.empty(n_src, 14, tdt, dev, COLUMNS)
         o_in.data.normal_()
