@@ -139,6 +139,7 @@ class Oras6Clipping(MatchingFieldsFilter):
         names = [name for name, _ in _ORAS6_KINDS]
         x = fields_to_stack([given[name] for name in names])
         ice = fields_to_stack([siconc])  # one level: the contiguous field
+        assert ice.n_lev == 1 and ice.data.numel() == ice.n_pts, "a one-level stack is the field itself, contiguous"
         if ice.dtype != x.dtype:
             ice = type(ice)(ice.data.to(x.dtype), ice.n_pts, ice.n_lev, ice.layout)
         y = x.new_like(zero=False)
