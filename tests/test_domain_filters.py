@@ -471,3 +471,86 @@ def test_humidity_kernels_vs_oracle(dev, np_dtype, rtol, layout):
     assert np.isnan(want).any()  # hot and humid at 50 hPa: e reaches p, the guard gives NaN on both sides
     with pytest.raises(ValueError):
         run(native.COMB_Q_TO_R, [q, t])  # two operands and no level_param
+
+
+# ---- random shapes: odd sizes, thin stacks (scalar path), tails, both layouts ------------------------------------------------------
+# ATX_DOMAIN_SEEDS=first:count widens the sweep for a one-off soak run
+_FIRST, _COUNT = (int(v) for v in os.environ.get("ATX_DOMAIN_SEEDS", "0:0").split(":"))
+DOMAIN_SEEDS = range(_FIRST, _FIRST + _COUNT) if _COUNT else range(12)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", DOMAIN_SEEDS)
+def test_domain_and_humidity_kernels_on_random_shapes(dev, seed):
+    from anemoi_transform_amd.stack import Stack
+
+    rng = np.random.default_rng(1000 + seed)
+    np_dtype = [np.float64, np.float32][int(rng.integers(2))]
+    layout = [native.COLUMNS, native.FIELDS][int(rng.integers(2))]
+    n_lev = int(rng.choice([1, 2, 3, 4, 5, 7, 8, 14, 33, 137]))
+    n_pts = int(rng.choice([1, 2, 3, 5, 63, 64, 65, 255, 257, 1000, 4097, 20001]))
+    rtol = 2e-13 if np_dtype == np.float64 else 2e-5
+
+    def stacks_of(arrays):
+        return [Stack.from_fields(a, dev=dev, layout=layout) for a in arrays]
+
+    def run(op, ins, n_out, level_param=None, shared=None):
+        st = stacks_of(ins)
+        outs = [st[0].new_like(zero=False) for _ in range(n_out)]
+        for o in outs:
+            o.data.fill_(float("nan"))  # whatever is not written shows
+        tensors = [s.data for s in st] + ([] if shared is None else [torch.from_numpy(shared).to(dev)])
+        lp = None if level_param is None else torch.tensor(np.asarray(level_param, dtype=np.float64), device=dev)
+        native.combine_stack(op, tensors, [o.data for o in outs], n_pts=n_pts, n_lev=n_lev, pitch=st[0].pitch, layout=layout, level_param=lp)
+        for o in outs:  # the padding of the outputs is written with zeros (atx.h)
+            full = o.data.cpu().numpy()
+            pad = full[:, n_lev:] if layout == native.COLUMNS else full[:, n_pts:]
+            assert not np.isnan(pad).any() and not pad.any()
+        return [o.numpy() for o in outs]
+
+    def values(loc, scale):
+        x = rng.normal(loc, scale, (n_lev, n_pts)).astype(np_dtype)
+        flat = x.reshape(-1)
+        k = min(flat.size, 5)
+        flat[:k] = np.array([-0.0, np.nan, np.inf, 0.0, -np.inf], dtype=np_dtype)[:k]
+        return x
+
+    limits = rng.choice([0.0, 1.0, 12.5, 10000.0], n_lev)
+    tp, qi = values(5.0, 10.0), values(0.5, 0.6)
+    dm = rng.integers(0, 5, (n_lev, n_pts)).astype(np_dtype)
+    got = run(native.COMB_OPERA_CLIP, [tp, qi], 2, limits)
+    want = [oracle.opera_clipping(tp[l], qi[l], limits[l]) for l in range(n_lev)]
+    assert same_bits(got[0], np.stack([w[0] for w in want])) and same_bits(got[1], np.stack([w[1] for w in want]))
+    got = run(native.COMB_OPERA_PREPROCESS, [tp, qi, dm], 2, limits)
+    want = [oracle.opera_preprocessing(tp[l], qi[l], dm[l], limits[l]) for l in range(n_lev)]
+    assert same_bits(got[0], np.stack([w[0] for w in want])) and same_bits(got[1], np.stack([w[1] for w in want]))
+
+    siconc = np.where(rng.random(n_pts) < 0.5, rng.choice([0.0, 1e-5, 9e-6, -1.0, np.nan], n_pts), rng.random(n_pts)).astype(np_dtype)
+    kinds = rng.integers(0, 6, n_lev)
+    x = values(0.0, 3e-5)
+    (got,) = run(native.COMB_ORAS6, [x], 1, kinds.astype(float), shared=siconc)
+    assert same_bits(got, np.stack([native_double._oras6_level(x[l].copy(), siconc.copy(), int(kinds[l])) for l in range(n_lev)]))
+
+    classes = rng.integers(-1, 9, (n_lev, n_pts)).astype(np_dtype)
+    table = rng.normal(0, 1, 8)
+    (got,) = run(native.COMB_LOOKUP, [classes], 1, [8.0] + list(table))
+    known = (classes >= 0) & (classes < 8)
+    assert np.isnan(got[~known]).all() and np.array_equal(got[known], table[classes[known].astype(int)].astype(np_dtype))
+
+    t = rng.uniform(190.0, 320.0, (n_lev, n_pts)).astype(np_dtype)
+    r = rng.uniform(0.0, 110.0, (n_lev, n_pts)).astype(np_dtype)
+    q = (10.0 ** rng.uniform(-6, -1.7, (n_lev, n_pts))).astype(np_dtype)
+    p = rng.uniform(20000.0, 105000.0, (n_lev, n_pts)).astype(np_dtype)
+    levels = rng.choice([50.0, 200.0, 500.0, 850.0, 1000.0], n_lev)
+
+    def close(got, want):
+        want = np.asarray(want).astype(np_dtype)
+        assert np.array_equal(np.isnan(got), np.isnan(want))
+        ok = np.isfinite(want)
+        np.testing.assert_allclose(got[ok], want[ok], rtol=rtol)
+
+    close(run(native.COMB_R_TO_D, [r, t], 1)[0], oracle.dewpoint_from_relative_humidity(r, t))
+    close(run(native.COMB_D_TO_R, [t - np_dtype(3.0), t], 1)[0], oracle.relative_humidity_from_dewpoint(t - np_dtype(3.0), t))
+    close(run(native.COMB_Q_TO_R, [q, t, p], 1)[0], oracle.relative_humidity_from_specific_humidity(t, q, p))
+    close(run(native.COMB_R_TO_Q, [r, t], 1, levels)[0],
+          np.stack([oracle.specific_humidity_from_relative_humidity(t[l], r[l], np_dtype(100.0) * np_dtype(levels[l])) for l in range(n_lev)]))
