@@ -10,6 +10,8 @@
     thinning_mask         R: spatial.py:443-503
     global_on_lam_mask    R: spatial.py:506-536   distance_km = number / "lam" / "global" / None
     cropping_mask         R: spatial.py:236-275   boxes that wrap the dateline / the Greenwich meridian
+    regrid                R: regrid.py:380, :310  `field[..., idx]` and `csr_array(inverse-distance weights) @ field` evaluated by numpy / scipy
+                                                  on the index / distance tables nearest_grid_points returned above (seeded fields)
 
 How to run (build container only; neither the reference nor the shim travels to the GPU box — only the .npz does):
 
