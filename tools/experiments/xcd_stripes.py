@@ -31,6 +31,7 @@ def main():
     ap.add_argument("--inner", type=int, default=10)
     ap.add_argument("--ks", nargs="+", type=int, default=[16, 8, 4])
     ap.add_argument("--dtypes", nargs="+", default=["f32", "f64"])
+    ap.add_argument("--block-points", nargs="+", type=int, default=[0], help="widths of the column blocks (0: the package's default)")
     args = ap.parse_args()
     graft.load_package()
     from anemoi_transform_amd import interp, native
@@ -53,8 +54,9 @@ def main():
     src_grid, tgt_grid = lookup("o1280"), lookup("0.25")
     n_src, n_tgt = len(src_grid["latitudes"]), len(tgt_grid["latitudes"])
     idx16, w16 = interp.knn_inverse_distance(src_grid, tgt_grid, k=16, device=True, ties="index")
-    order = column_block_order(tgt_grid["latitudes"], tgt_grid["longitudes"])
-    rows_dev = torch.from_numpy(order.astype(np.int32)).to(dev)
+    orders = {("column blocks" if not bp else f"blocks of {bp}"): column_block_order(tgt_grid["latitudes"], tgt_grid["longitudes"], bp or None)
+              for bp in args.block_points}
+    rows_dev = {name: torch.from_numpy(o.astype(np.int32)).to(dev) for name, o in orders.items()}
     stream = lambda: torch.cuda.current_stream().cuda_stream  # noqa: E731
 
     def timed(fn):
@@ -74,7 +76,7 @@ def main():
             alg = bench.algorithmic_bytes(L, B, int(np.unique(idx16[:, :k]).size), n_tgt, k)
             wk = w16[:, :k] / w16[:, :k].sum(axis=1, keepdims=True)
             tables = {}
-            for oname, perm in (("natural", None), ("column blocks", order)):
+            for oname, perm in [("natural", None)] + list(orders.items()):
                 i = idx16[:, :k] if perm is None else idx16[perm, :k]
                 w = wk if perm is None else wk[perm]
                 tables[oname] = (torch.from_numpy(np.ascontiguousarray(i).astype(np.int32)).to(dev), torch.from_numpy(np.ascontiguousarray(w).astype(npdt)).to(dev))
@@ -87,7 +89,7 @@ def main():
                     rc = h.atx_regrid_ell(x.data.data_ptr(), out.data.data_ptr(), ik.data_ptr(), wd.data_ptr(), *tail)
                 else:
                     srcs, outs = (ctypes.c_void_p * 1)(x.data.data_ptr()), (ctypes.c_void_p * 1)(out.data.data_ptr())
-                    rc = h.atx_regrid_ell_ordered(srcs, outs, 1, ik.data_ptr(), wd.data_ptr(), rows_dev.data_ptr(), *tail)
+                    rc = h.atx_regrid_ell_ordered(srcs, outs, 1, ik.data_ptr(), wd.data_ptr(), rows_dev[oname].data_ptr(), *tail)
                 assert rc == 0, rc
 
             for rnd in range(args.rounds + 1):
