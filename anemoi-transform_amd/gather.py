@@ -383,11 +383,13 @@ def column_block_order(latitudes: np.ndarray, longitudes: np.ndarray, block_poin
     """A visiting order for ``GatherPlan.order_targets``: the target points in bands of longitude about ``block_points`` points
     wide, each band in the points' own order (row by row for a lat-lon or Gaussian grid).  ``None`` for small or degenerate grids.
 
-    Why: with 4-16 neighbours the source patches of vertically adjacent targets overlap; in row-major order a whole target row of
-    source columns (1440 targets x 3-6 distinct columns x 0.5-1.1 KB = 2-13 MB on O1280 -> 0.25 degree) passes through an XCD's
-    4 MB L2 before the next row asks for them again, in a band of 240 targets a sixth of that
-    (profiles/r03_column_blocks_experiment.log).  The output rows of an ordered launch are written band by band instead of end to
-    end, which costs 2-7 % by itself: see ``target_order_for`` for when the library uses it."""
+    Why (round 4 corrected round 3's reading, profiles/r04_tile_orders_experiment.log, r04_xcd_stripes_experiment.log): the kernel deals
+    its workgroups to the 8 XCDs in contiguous ranges, so in row-major order an XCD stays on ONE latitude belt — the polar ones, where
+    hundreds of targets share a few source columns, finish early, the equatorial ones fetch every column from HBM and carry the launch.
+    In full-height bands every XCD walks from pole to equator.  The number of bands is therefore kept a multiple of 4 (with 4 bands an
+    XCD takes half a band, with 8 a whole one; 2, 3, 6 or 10 bands leave the XCD ranges across band boundaries and lose 1-8 %,
+    profiles/r04_band_count_experiment.log).  The output rows of an ordered launch are written band by band instead of end to end, which
+    costs a few per cent by itself: see ``target_order_for`` for when the library uses it."""
     block_points = ORDER_BLOCK_POINTS if block_points is None else block_points
     lat = np.asarray(latitudes, dtype=np.float64).reshape(-1)
     lon = np.asarray(longitudes, dtype=np.float64).reshape(-1)
@@ -402,5 +404,6 @@ def column_block_order(latitudes: np.ndarray, longitudes: np.ndarray, block_poin
     n_bands = int(round(lon_span / (block_points * spacing)))
     if n_bands < 2:
         return None
+    n_bands = max(4, 4 * int(round(n_bands / 4)))  # whole or half bands per XCD
     band = np.minimum(((lon - lon.min()) * (n_bands / lon_span)).astype(np.int64), n_bands - 1)
     return np.argsort(band, kind="stable").astype(np.int32)

@@ -22,11 +22,14 @@ def test_column_block_order_is_a_banded_permutation(monkeypatch):
     n = len(g["latitudes"])
     assert order.dtype == np.int32 and np.array_equal(np.sort(order), np.arange(n))
     lon = g["longitudes"][order]
-    band = np.floor(lon / 60.0).astype(int)
-    assert np.all(np.diff(band) >= 0) and band.max() == 5  # six bands of 60 degrees, one after the other
+    band = np.floor(lon / 45.0).astype(int)
+    assert np.all(np.diff(band) >= 0) and band.max() == 7  # asked for six, got EIGHT bands of 45 degrees, one after the other: whole bands per XCD
     first = order[band == 0]
     assert np.all(np.diff(first) > 0)  # inside a band: the grid's own (row-major) order
     assert column_block_order(g["latitudes"], np.zeros(n)) is None and column_block_order(g["latitudes"], g["longitudes"], block_points=100000) is None
+    for asked, bands in ((180, 4), (120, 4), (90, 4), (72, 4), (45, 8), (36, 8), (30, 12), (20, 16)):  # the number of bands is a multiple of 4
+        lon = g["longitudes"][column_block_order(g["latitudes"], g["longitudes"], block_points=asked)]
+        assert len(np.unique(np.floor(lon / (360.0 / bands)).astype(int)[np.r_[True, np.diff(np.floor(lon / (360.0 / bands)).astype(int)) != 0]])) == bands, asked
 
 
 @pytest.mark.parametrize("k", [1, 4])
