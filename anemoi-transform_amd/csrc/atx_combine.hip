@@ -159,19 +159,24 @@ __device__ __forceinline__ void combine_one(int flags, const T* x, int n_in, T l
                 y0 = arg;
             } else {
                 // tanh through expm1: e = expm1(2|x|), tanh|x| = e / (e + 2) — no cancellation anywhere on (0, 2.65], 2-3 ulp — instead
-                // of the device library's tanh (float64: 907 VALU instructions per wave of 4 elements per lane against ~350 this way;
-                // profiles/r03_pmc_sq_combine.txt).  ATX_SNOW_TANH=1 restores the library call.
+                // of the device library's tanh (float64: 169 VALU instructions per element).  Round 3 took the library's expm1 and an
+                // IEEE division for it (907 -> ~350 instructions per wave of 4 elements per lane; profiles/r03_pmc_sq_combine.txt);
+                // round 5 the library's own atx_tanh_pos (atx_common.hpp: expm1 in ~24 instructions, the quotient in 7).
+                // ATX_SNOW_TANH=1 restores the device library's tanh, =2 round 3's form.
 #ifndef ATX_SNOW_TANH
 #define ATX_SNOW_TANH 0
 #endif
                 T sc;
-                if constexpr (ATX_SNOW_TANH || sizeof(T) == 4) {
+                if constexpr (ATX_SNOW_TANH == 1 || sizeof(T) == 4) {
                     sc = tanh(arg);
-                } else {
+                } else if constexpr (ATX_SNOW_TANH == 2) {
                     const T mag = fabs(arg);  // (only negative arguments get here beyond 2.65: they end up clipped to 0)
                     const T e = expm1(T(2) * (mag < T(20) ? mag : T(20)));
                     sc = copysign(mag < T(20) ? e / (e + T(2)) : T(1), arg);  // tanh(20) rounds to 1.0 in float64
                     if (arg != arg) sc = arg;  // NaN stays NaN
+                } else {
+                    // a negative argument (negative snow depth) ends up clipped to 0 two lines down whatever its tanh is: only its sign matters
+                    sc = copysign((T)atx_tanh_pos((double)fabs(arg)), arg);
                 }
                 sc = (sc < T(0)) ? T(0) : sc;
                 sc = (sc > T(1)) ? T(1) : sc;

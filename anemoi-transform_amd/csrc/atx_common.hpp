@@ -108,22 +108,58 @@ __device__ __forceinline__ double quiet_nan<double>() {
     return __longlong_as_double(0x7ff8000000000000ll);  // np.nan
 }
 
+// a / b for float64 WITHOUT the IEEE division sequence (v_div_scale x2, v_rcp, 5 fma, v_div_fmas, v_div_fixup = 13 VALU instructions):
+// hardware reciprocal (2^-23), one Newton step, the quotient and one correction with its exact residual — 7 instructions, <= 1 ulp.
+// For quotients INSIDE a library function (log's s = f / (2 + f), tanh's e / (e + 2)), whose own error budget is wider; the
+// reference's statements (`x / g`, `(x - b) / a`, `1000 sd / rsn`) keep the IEEE division and numpy's bits.  Operands must be
+// normal and finite (no scaling, no fix-up).
+__device__ __forceinline__ double quotient_1ulp(double a, double b) {
+    double r = __builtin_amdgcn_rcp(b);
+    r = __builtin_fma(__builtin_fma(-b, r, 1.0), r, r);
+    const double q = a * r;
+    return __builtin_fma(__builtin_fma(-b, q, a), r, q);
+}
+
 // Natural logarithm for the per-level operator ATX_OP_LOG (sp_to_lnsp, R: filters/fields/lnsp_to_sp.py:65).  float32: the device
-// library's.  float64: the classic argument reduction x = 2^k * m, m in [sqrt(2)/2, sqrt(2)), log(m) = f - s*(f - R(s^2)) with
-// s = f / (2 + f), f = m - 1 and a degree-14 minimax R (the published fdlibm coefficients, the one-form evaluation; measured <= 1 ulp
-// from numpy's in tests/test_gpu_kernels.py) — the device library's double log measured 3.18 ms over 137 levels of O1280 (0.57 of
-// the HBM peak, ALU-bound) where exp takes 2.34 ms; ATX_FAST_LOG=0 restores it.  Zero, negatives, infinities, NaN and subnormals
-// follow IEEE / numpy: -inf, NaN, +inf, NaN, exact scaling.
+// library's.  float64: the classic argument reduction x = 2^k * m, m in [sqrt(2)/2, sqrt(2)), log(m) = f - (f^2/2 - s*(f^2/2 + R(s^2)))
+// with s = f / (2 + f), f = m - 1 and a degree-14 minimax R (the published fdlibm coefficients) — the device library's double log
+// measured 3.18 ms over 137 levels of O1280 (0.57 of the HBM peak, ALU-bound: 102 VALU instructions per element, 43 of them plain
+// additions of its double-double arithmetic) where exp takes 2.34 ms.
+//   ATX_FAST_LOG=1 (round 3): fdlibm's integer bit manipulation and IEEE division, 59 VALU instructions per element, 2.50 ms (0.72).
+//   ATX_FAST_LOG=2 (round 5, default): the hardware's v_frexp_mant / v_frexp_exp (subnormals included) instead of the integer
+//     sequence, quotient_1ulp instead of the IEEE division, R by Horner in s^2 and the combination with fused multiply-adds,
+//     the special operands (0, negative, inf, NaN) behind ONE v_cmp_class and a branch no wave of real data takes:
+//     ~33 instructions per element (tools/kernel_isa.py).  Measured <= 1 ulp from numpy's (true error <= 0.73 ulp against
+//     200-bit arithmetic on the host prototype), exact at 1; zero, negatives, infinities and NaN follow IEEE / numpy: -inf, NaN, +inf, NaN.
+//   ATX_FAST_LOG=0: the device library.
 #ifndef ATX_FAST_LOG
-#define ATX_FAST_LOG 1
+#define ATX_FAST_LOG 2
 #endif
 __device__ __forceinline__ float atx_log(float x) { return log(x); }
 __device__ __forceinline__ double atx_log(double x) {
-#if ATX_FAST_LOG
-    constexpr double ln2_hi = 6.93147180369123816490e-01, ln2_lo = 1.90821492927058770002e-10;
-    constexpr double Lg1 = 6.666666666666735130e-01, Lg2 = 3.999999999940941908e-01, Lg3 = 2.857142874366239149e-01,
-                     Lg4 = 2.222219843214978396e-01, Lg5 = 1.818357216161805012e-01, Lg6 = 1.531383769920937332e-01,
-                     Lg7 = 1.479819860511658591e-01;
+    [[maybe_unused]] constexpr double ln2_hi = 6.93147180369123816490e-01, ln2_lo = 1.90821492927058770002e-10;
+    [[maybe_unused]] constexpr double Lg1 = 6.666666666666735130e-01, Lg2 = 3.999999999940941908e-01, Lg3 = 2.857142874366239149e-01,
+                                      Lg4 = 2.222219843214978396e-01, Lg5 = 1.818357216161805012e-01, Lg6 = 1.531383769920937332e-01,
+                                      Lg7 = 1.479819860511658591e-01;
+#if ATX_FAST_LOG == 2
+    double m = __builtin_amdgcn_frexp_mant(x);  // [0.5, 1), subnormals normalised by the instruction
+    int k = __builtin_amdgcn_frexp_exp(x);
+    const bool low = m < 0.70710678118654752440;  // m in [sqrt(2)/2, sqrt(2))
+    m = __builtin_amdgcn_ldexp(m, low ? 1 : 0);
+    k -= low ? 1 : 0;
+    const double f = m - 1.0;  // exact
+    const double s = quotient_1ulp(f, 2.0 + f);
+    const double z = s * s;
+    const double R = z * __builtin_fma(z, __builtin_fma(z, __builtin_fma(z, __builtin_fma(z, __builtin_fma(z, __builtin_fma(z, Lg7, Lg6), Lg5), Lg4), Lg3), Lg2), Lg1);
+    const double hfsq = 0.5 * f * f;
+    const double dk = (double)k;
+    double y = __builtin_fma(dk, ln2_hi, f - (hfsq - __builtin_fma(s, hfsq + R, dk * ln2_lo)));
+    // everything but positive normal / subnormal numbers: +-0, negatives, +-inf, NaN (class bits 0-6 and 9)
+    if (__builtin_amdgcn_class(x, 0x27f)) {
+        y = (x == 0.0) ? -__longlong_as_double(0x7ff0000000000000ll) : ((x < 0.0 || x != x) ? __longlong_as_double(0x7ff8000000000000ll) : x);
+    }
+    return y;
+#elif ATX_FAST_LOG == 1
     const double x0 = x;
     int k = 0;
     int hx = __double2hiint(x);
@@ -154,6 +190,40 @@ __device__ __forceinline__ double atx_log(double x) {
 #else
     return log(x);
 #endif
+}
+
+// expm1(y) for 0 <= y <= 40 in float64 and, on it, tanh of a positive argument — what `snow_cover` needs between bare ground and
+// deep snow (R: filters/fields/snow_cover.py:34-39; atx_combine.hip).  y = k ln2 + r, |r| <= ln2 / 2; expm1(r) = r + r^2 q(r) with
+// q the Taylor series to r^13 (truncation 1e-17 relative); 2^k (r + r^2 q) + (2^k - 1) evaluated as fma(2^k r^2, q, fma(2^k, r, 2^k - 1)):
+// the dominant part takes ONE rounding (k = 1, r < 0 would otherwise cancel a rounded expm1(r) against 1).  ~24 VALU instructions;
+// <= 1 ulp from numpy's expm1 (true error <= 1.2 ulp on the host prototype).  The device library's expm1: 57.
+__device__ __forceinline__ double atx_expm1_pos(double y) {
+    constexpr double log2e = 1.4426950408889634, ln2hi = 6.93147180559945286227e-01, ln2lo = 2.31904681384629955842e-17;
+    const double k = __builtin_rint(y * log2e);
+    double r = __builtin_fma(-k, ln2hi, y);
+    r = __builtin_fma(-k, ln2lo, r);
+    double q = 1.0 / 6227020800.0;  // 1 / 13!
+    q = __builtin_fma(q, r, 1.0 / 479001600.0);
+    q = __builtin_fma(q, r, 1.0 / 39916800.0);
+    q = __builtin_fma(q, r, 1.0 / 3628800.0);
+    q = __builtin_fma(q, r, 1.0 / 362880.0);
+    q = __builtin_fma(q, r, 1.0 / 40320.0);
+    q = __builtin_fma(q, r, 1.0 / 5040.0);
+    q = __builtin_fma(q, r, 1.0 / 720.0);
+    q = __builtin_fma(q, r, 1.0 / 120.0);
+    q = __builtin_fma(q, r, 1.0 / 24.0);
+    q = __builtin_fma(q, r, 1.0 / 6.0);
+    q = __builtin_fma(q, r, 0.5);
+    const double t = __hiloint2double(((int)k + 1023) << 20, 0);  // 2^k, 0 <= k <= 58
+    const double a = __builtin_fma(t, r, t - 1.0);
+    return __builtin_fma(t * (r * r), q, a);
+}
+// tanh(x) for x > 0 (NaN passes through): e / (e + 2) with e = expm1(2x) — no cancellation anywhere; 1.0 from 20 on (tanh(20) rounds to 1).
+__device__ __forceinline__ double atx_tanh_pos(double x) {
+    const bool small = x < 20.0;
+    const double e = atx_expm1_pos(2.0 * (small ? x : 20.0));
+    const double t = small ? quotient_1ulp(e, e + 2.0) : 1.0;
+    return (x != x) ? x : t;
 }
 
 // One per-level operator in the arithmetic type of the stack.

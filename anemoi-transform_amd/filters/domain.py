@@ -222,11 +222,17 @@ class LandParameters(MatchingFieldsFilter):
 # humidity conversions (the arithmetic is earthkit-meteo's thermo.array, restated in atx_combine.hip from its published form
 # and pinned by the reference's test vectors at np.allclose — see oracle.py)
 # =================================================================================
+HUMIDITY_NOTE = ("arithmetic restated from earthkit-meteo's thermo.array (IFS saturation formulas, mixed phase; package absent here); "
+                 "pinned only at the reference's test points (tests/field_filters/test_dewpoint.py, test_pressure_level_humidity.py) at "
+                 "np.allclose, not bit for bit")
+
+
 class DewPoint(StackMatchingFilter):
     """Relative humidity (%) and temperature (K) -> dewpoint temperature (K), and back (R: filters/fields/dewpoint.py:24-76).
     A relative humidity of exactly 0 is replaced by 1e-4 before the dewpoint is taken, as in the reference."""
 
     MATCHING = MatchingSpec(select="param", forward=("relative_humidity", "temperature"), backward=("dewpoint", "temperature"))
+    PARITY_NOTE = HUMIDITY_NOTE
 
     def __init__(self, *, relative_humidity: str = "r", temperature: str = "t", dewpoint: str = "d", return_inputs: Any = "all") -> None:
         self.return_inputs = return_inputs
@@ -261,6 +267,7 @@ class HumidityConversion(StackMatchingFilter):
     (R: filters/fields/q_to_r.py:21-84).  The pressure is 100 x the ``levelist`` of the humidity (forward) or temperature (backward) field."""
 
     MATCHING = MatchingSpec(select="param", forward=("humidity", "temperature"), backward=("relative_humidity", "temperature"))
+    PARITY_NOTE = HUMIDITY_NOTE
 
     def __init__(self, *, relative_humidity: str = "r", temperature: str = "t", humidity: str = "q", return_inputs: Any = "all") -> None:
         self.return_inputs = return_inputs
@@ -297,6 +304,7 @@ class SpecificToRelativeAtHeightLevelWithP(StackMatchingFilter):
         backward=("relative_humidity_at_height_level", "temperature_at_height_level", "pressure_at_height_level"),
         vertical=False,
     )
+    PARITY_NOTE = HUMIDITY_NOTE
 
     def __init__(self, *, specific_humidity_at_height_level: str = "q", relative_humidity_at_height_level: str = "r",
                  pressure_at_height_level: str = "pres", temperature_at_height_level: str = "t",

@@ -111,6 +111,9 @@ class MatchingFieldsFilter(Filter):
     """Converts groups of fields matched by their metadata (R: matching.py:90-311)."""
 
     MATCHING: MatchingSpec
+    #: set by the filters whose arithmetic lives in a third-party package that is absent here (earthkit-meteo): what the device
+    #: operator restates and what pins it.  Logged once per filter instance, as `regrid`'s default route does (filters/regrid.py).
+    PARITY_NOTE: str | None = None
 
     @staticmethod
     def _check_expected_method_parameters(method: Callable, expected: set[str]) -> None:
@@ -132,6 +135,8 @@ class MatchingFieldsFilter(Filter):
     def __init__(self, *args: Any, **kwargs: Any) -> None:
         super().__init__(*args, **kwargs)
         self._prepare_matching()
+        if self.PARITY_NOTE:
+            LOG.warning("%s: %s", type(self).__name__, self.PARITY_NOTE)
 
     def _prepare_matching(self) -> None:
         """Apply an instance-level ``return_inputs`` to the class's spec and warn about returned inputs that are not
@@ -493,6 +498,8 @@ class WindComponents(StackMatchingFilter):
     reference's own test vectors (tests/field_filters/test_uv_to_ddff.py)."""
 
     MATCHING = MatchingSpec(select="param", forward=("u_component", "v_component"), backward=("wind_speed", "wind_direction"))
+    PARITY_NOTE = ("arithmetic restated from earthkit-meteo's wind.xy_to_polar / polar_to_xy (package absent here); pinned only at the "
+                   "reference's test points (tests/field_filters/test_uv_to_ddff.py) at np.allclose, not bit for bit")
 
     def __init__(self, *, u_component: str = "u", v_component: str = "v", wind_speed: str = "ws", wind_direction: str = "wdir",
                  convention: str = "meteo", radians: bool = False) -> None:

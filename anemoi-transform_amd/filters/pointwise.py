@@ -15,6 +15,7 @@ one ``atx_pointwise_stack`` launch per stack (``engine.run_level_ops``):
 
 from __future__ import annotations
 
+import logging
 from typing import Any
 
 import numpy as np
@@ -24,6 +25,8 @@ from .. import native
 from ..core import Filter, SingleFieldFilter, filter_registry
 from ..fields import FieldList
 from .engine import LevelOp, PointMask, run_level_ops
+
+LOG = logging.getLogger(__name__)
 
 # R: constants.py:13 (earthkit.meteo g); value pinned by R: filters/tabular/geopotential_to_height.py:51
 g_gravitational_acceleration = 9.80665
@@ -124,6 +127,14 @@ _UNITS: dict[str, tuple[str, float, float]] = {
 }
 
 
+def _have_pint() -> bool:
+    try:
+        import pint  # noqa: F401
+    except ImportError:
+        return False
+    return True
+
+
 def _convert_value(x: float, unit_in: str, unit_out: str) -> float:
     try:
         import pint  # the reference's converter (R: rescale.py:94), if installed
@@ -155,6 +166,12 @@ class Convert(RescaleMixin, StackFieldFilter):
         scale = (y2 - y1) / (x2 - x1)
         offset = y1 - scale * x1
         self.rescaler = Rescaler(scale, offset)
+        if {self.unit_in, self.unit_out} != {"K", "degC"}:
+            # the one pair the reference pins is K -> degC (R: tests/field_filters/test_rescale.py:58-72); everything else comes from
+            # pint when it is installed, else from the private table above — say so, as `regrid`'s default route does
+            LOG.warning("convert(%s -> %s): scale %r and offset %r come from %s; only K <-> degC is pinned by the reference "
+                        "(tests/field_filters/test_rescale.py), other pairs are not held to a reference vector",
+                        self.unit_in, self.unit_out, scale, offset, "pint" if _have_pint() else "this package's private unit table (pint is not installed)")
 
 
 filter_registry.register("rescale", Rescale)

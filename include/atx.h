@@ -18,6 +18,18 @@
  *    Calls enqueue work and return without synchronising.
  *  - Return value: ATX_OK (0) or a negative ATX_E* code; atx_last_error()
  *    gives the message for the calling thread.  Nothing throws across the ABI.
+ *  - Threading: every entry point is re-entrant.  The library holds no state
+ *    between calls besides two PER-THREAD items — the error string and the
+ *    tuning hook (atx_set_tuning) — and the RCCL binding, resolved once under
+ *    std::call_once.  Several host threads may call at the same time, each on
+ *    its own stream and buffers (or one thread may drive several streams); a
+ *    call that fails in one thread leaves the other threads' atx_last_error()
+ *    untouched.  Two calls that write the same buffer, or share a `workspace`,
+ *    must be ordered by the caller (same stream, or an event).
+ *    tests/test_gpu_threads.py: 4 threads x 6 rounds of atx_regrid_ell (direct
+ *    and, through the per-thread tuning hook, tiled), atx_pointwise_stack,
+ *    atx_reduce_stack and atx_mask_build + atx_mask_to_index at once, every
+ *    result against the CPU oracle, one thread provoking ATX_EINVAL.
  *  - A *stack* is a batch of `n_lev` fields on one grid of `n_pts` points.
  *    Two HBM layouts (atx_layout):
  *      ATX_COLUMNS  element (point p, level l) at  base[p * pitch + l]

@@ -32,7 +32,9 @@ def test_single_gpu_line():
     assert run.returncode == 0, run.stderr[-2000:]
     d = last_json(run.stdout)
     assert KEYS <= set(d) and d["n_gpus"] == 1 and d["steps"] == 3 and d["warmup"] == 1
-    assert d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None and d["data"] == "synthetic"
+    # every line of the N = 1, 2, 4, 8 series does the SAME total work per step (one stack): the series is strong scaling
+    assert d["higher_is_better"] is True and d["scaling"] == "strong" and d["vs_baseline"] is None and d["data"] == "synthetic"
+    assert d["config"]["stacks_per_step"] == 1 and "fixed-total-work" in d["config"]["sharding"]
     assert d["unit"] == "grid-points/s" and d["value"] > 0 and d["dtype"] == "f64" and "workload" in d["config"]  # the reference's own arithmetic (R: fields.py:178-202)
     r = d["roofline"]
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
@@ -73,29 +75,33 @@ def test_two_ranks_without_a_launcher():
                           "--no-extras"], capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
     assert run.returncode == 0, run.stderr[-2000:]
     d = last_json(run.stdout)
-    assert KEYS <= set(d) and d["n_gpus"] == 2 and d["value"] > 0 and d["config"]["stacks_per_step"] == 2
-    # --no-extras: the mirror is there (the driver's record keeps `config` whole) and says that nothing was measured
+    assert KEYS <= set(d) and d["n_gpus"] == 2 and d["value"] > 0 and d["config"]["stacks_per_step"] == 1 and d["scaling"] == "strong"
+    # --no-extras: the mirror is there (the driver's record keeps `config` whole) and says that nothing BESIDE the headline was measured
     m = d["config"]["multi_gpu"]
-    assert m["strong"] is None and m["end_to_end"] is None and m["source_exchange_ms"] == {"broadcast": None, "all_gather": None, "bands": None}
+    assert m["strong"]["value"] == d["value"] and m["strong"]["ms_per_step"] == d["ms_per_step"]
+    assert m["weak"] is None and m["end_to_end"] is None and m["source_exchange_ms"] == {"broadcast": None, "all_gather": None, "bands": None}
 
 
 def assert_mirrored(d: dict) -> None:
     """`config.multi_gpu` repeats the numbers of the top-level sections (which the driver's record reduces to their names) and
     `config.sharding` says which of them answers north_star's ">= 6x at 8 GPUs"."""
     m = d["config"]["multi_gpu"]
-    for section in ("strong", "end_to_end", "end_to_end_bands", "end_to_end_all_gather", "field_axis_sharding"):
+    # the number the driver divides by the N = 1 line is the fixed-total-work one: it can fall short of N
+    assert d["scaling"] == "strong" and d["value"] == m["strong"]["value"] and d["ms_per_step"] == m["strong"]["ms_per_step"]
+    assert d["weak"]["scaling"] == "weak" and m["weak"]["stacks_per_step"] == d["n_gpus"]
+    for section in ("strong", "weak", "end_to_end", "end_to_end_bands", "end_to_end_all_gather", "field_axis_sharding"):
         assert m[section]["value"] == d[section]["value"] > 0 and m[section]["ms_per_step"] == d[section]["ms_per_step"], section
     assert m["source_exchange_ms"] == {k: d["source_exchange_ms"][k] for k in ("broadcast", "all_gather", "bands")}
     assert m["end_to_end"]["verified_bit_equal"] is True and m["end_to_end_bands"]["verified_bit_equal"] is True
     assert m["end_to_end_all_gather"]["verified_bit_equal"] is True
     assert m["secondary_timed_out_in"] is None
     text = d["config"]["sharding"]
-    assert "end_to_end" in text and "strong" in text and "north_star" in text and "WEAK" in text
+    assert "end_to_end" in text and "weak" in text and "north_star" in text and "STRONG" in text and "FIXED TOTAL WORK" in text
 
 
 def test_two_ranks_rehearsal_over_gloo():
-    """`--gpus 2` by default carries every N > 1 line: value (exchange excluded), both source exchanges timed and verified bit-equal,
-    end_to_end (exchange inside), strong scaling, field-axis sharding — no opt-in flags."""
+    """`--gpus 2` by default carries every N > 1 line: value (fixed total work = strong scaling, exchange excluded), the weak line of
+    rounds 1-4, the source exchanges timed and verified bit-equal, end_to_end (exchange inside), field-axis sharding — no opt-in flags."""
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
@@ -104,16 +110,16 @@ def test_two_ranks_rehearsal_over_gloo():
     run = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT)
     assert run.returncode == 0, run.stderr[-2000:]
     d = last_json(run.stdout)
-    assert KEYS <= set(d) and d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 0
-    assert d["config"]["stacks_per_step"] == 2 and d["config"]["launches_per_step_per_gpu"] == 1
+    assert KEYS <= set(d) and d["n_gpus"] == 2 and d["scaling"] == "strong" and d["value"] > 0
+    assert d["config"]["stacks_per_step"] == 1 and d["config"]["launches_per_step_per_gpu"] == 1 and d["weak"]["stacks_per_step"] == 2
     assert "EXCLUDES the source exchange" in d["config"]["sharding"] and "gloo" in d["config"]["collectives"]
     assert set(d["source_exchange_ms"]) == {"broadcast", "all_gather", "bands"} and all(v > 0 for v in d["source_exchange_ms"].values())
     for kind in ("broadcast", "all_gather", "bands"):
         assert d["source_exchange"][kind]["verified_bit_equal"] is True
     assert d["source_exchange"]["bands"]["bytes_received_per_gpu"] < d["source_exchange"]["broadcast"]["bytes_received_per_gpu"]
     assert d["end_to_end"]["verified_bit_equal"] is True and d["end_to_end_bands"]["verified_bit_equal"] is True  # (small grids: no section skipped)
-    assert d["end_to_end"]["value"] > 0 and d["end_to_end"]["value"] < d["value"]  # the exchange is inside that one
-    assert d["strong"]["scaling"] == "strong" and d["strong"]["value"] > 0
+    assert d["end_to_end"]["value"] > 0 and d["end_to_end"]["value"] < d["weak"]["value"]  # the same N-stack step with the exchange inside
+    assert d["strong"]["scaling"] == "strong" and d["strong"]["value"] == d["value"]
     assert d["config4"]["value"] > 0 and d["config4"]["fields"] == 24 * 7
     assert d["config5"]["value"] > 0 and d["config5"]["scaling"] == "strong"
     assert d["field_axis_sharding"]["value"] > 0  # the no-exchange comparison point rides along
@@ -153,7 +159,7 @@ def test_multi_gpu_sections_on_real_rccl_at_world_1():
     assert d["n_gpus"] == 1 and d["value"] > 0 and "secondary_timed_out_in" not in d and "nccl" in d["config"]["collectives"]
     ex = d["source_exchange"]
     assert ex["broadcast"]["verified_bit_equal"] is True and ex["bands"]["verified_bit_equal"] is True
-    assert d["end_to_end"]["verified_bit_equal"] is True and d["strong"]["value"] > 0
+    assert d["end_to_end"]["verified_bit_equal"] is True and d["strong"]["value"] == d["value"] and d["weak"]["value"] > 0
     assert d["end_to_end_bands"]["verified_bit_equal"] is True
     assert_mirrored(d)
     c = ex["c_abi"]

@@ -75,6 +75,40 @@ def test_headline_float64_sample_levels_are_scipys_bits(case64):
         assert np.array_equal(out.level_numpy(l), want), l  # bit-exact: scipy's summation order, no FMA
 
 
+def test_headline_float64_through_the_plugin_api(case64, tmp_path):
+    """BASELINE configs[2] by the DROP-IN route: `create_filter_by_name("regrid", matrix=<k = 4 npz>)` (R: filters/__init__.py:36-60,
+    regrid.py:174-208 — the per-field loop — and :283-285,310 — `MIRMatrix`) on a FieldList of 137 device-resident float64 O1280
+    fields.  Every output field must hold the bits `GatherPlan.apply` produces for its level (the route the other full-size tests and
+    the bench take), three of them are compared with scipy directly, and the fields come back in list order with the target grid's
+    coordinates and their own metadata."""
+    from anemoi_transform_amd import interp
+    from anemoi_transform_amd.fields import ArrayField, FieldList, new_field_from_stack
+    from anemoi_transform_amd.filters import create_filter_by_name
+
+    src, tgt, x = case64["src"], case64["tgt"], case64["x"]
+    matrix = interp.ell_to_csr(case64["idx"], case64["w"], case64["n_src"])
+    path = str(tmp_path / "o1280-to-0p25-knn4.npz")
+    interp.save_matrix_npz(path, matrix, src, tgt)  # the reference's own file layout (R: regrid.py:281-290)
+    template = ArrayField(np.zeros(1), {"param": "t"}, np.zeros(1), np.zeros(1))
+    fields = FieldList([new_field_from_stack(x, l, template=template, latitudes=src["latitudes"], longitudes=src["longitudes"],
+                                             metadata={"param": "t", "levelist": l + 1}) for l in range(N_LEV)])
+    out = create_filter_by_name("regrid", matrix=path).forward(fields)
+    assert len(out) == N_LEV
+    direct = case64["plan"].apply(x)
+    for l, f in enumerate(out):
+        assert f.metadata("param") == "t" and f.metadata("levelist") == l + 1
+        stack, level = f.stack_ref()  # still in HBM: no host round trip inside the filter
+        assert stack.n_pts == case64["n_tgt"] and stack.data.dtype == torch.float64
+        assert torch.equal(stack.data[:, level].view(torch.int64), direct.data[:, l].view(torch.int64)), l
+    lat, lon = out[0].grid_points()
+    assert np.array_equal(lat, tgt["latitudes"]) and np.array_equal(lon, tgt["longitudes"])
+    indptr = np.arange(case64["n_tgt"] + 1) * 4
+    for l in (0, 68, 136):
+        want = oracle.csr_apply(case64["w"].reshape(-1), case64["idx"].reshape(-1), indptr, (case64["n_tgt"], case64["n_src"]), x.level_numpy(l))
+        got = out[l].to_numpy()
+        assert got.dtype == np.float64 and np.array_equal(got, want), l  # scipy's bits through Filter.forward()
+
+
 def test_headline_float64_nearest_is_a_bit_copy(case64):
     """R: regrid.py:380 `x[..., nearest_grid_points]` at full size in float64 (the `extras.nearest_k1` launch of the bench)."""
     nearest = np.ascontiguousarray(case64["idx"][:, 0])

@@ -524,6 +524,56 @@ def test_float64_log_within_one_ulp_of_numpy(dev):
     assert run(special)[0] == 0.0  # log(1) is exactly 0
 
 
+def test_float64_exp_within_one_ulp_of_numpy(dev):
+    """ATX_OP_EXP in float64 (lnsp_to_sp, R: lnsp_to_sp.py:47): at most 1 ulp from numpy on the ranges the filter sees and beyond —
+    argument reduction x = k ln2 + r with fused multiply-adds, a degree-11 polynomial, exact scaling by 2^k: 22 VALU instructions per
+    element in the kernels (tools/kernel_isa.py), which is why round 5 left the device library's routine in place and rewrote log
+    instead —, exact at 0, IEEE results for overflow, underflow to subnormals and zero, inf and NaN; through every kernel that can run
+    the operator, and log(exp(x)) / exp(log(x)) round trips through a two-stage program."""
+    rng = np.random.default_rng(78)
+    n = 1 << 18
+    cases = {
+        "ln of surface pressure": rng.uniform(np.log(3.0e4), np.log(1.1e5), n),
+        "around 0": rng.uniform(-1.0, 1.0, n),
+        "next to 0": rng.uniform(-1e-9, 1e-9, n),
+        "every magnitude": rng.uniform(-708.0, 709.0, n),
+        "into the subnormals": rng.uniform(-745.0, -708.0, n),
+    }
+    special = np.array([0.0, -0.0, np.inf, -np.inf, np.nan, 710.0, -746.0, 1.0, -1.0, 709.782712893384, -745.1332191019411, 1e-300, 0.5])
+
+    def run(x, per_level=False, stages=(native.OP_EXP,)):
+        st = Stack.from_fields(np.stack([x, x[::-1].copy()]), dev=dev)
+        out = st.new_like()
+        rows = [[(op, 0, 0.0, 0.0), (op, 0, 1.0 if per_level else 0.0, 0.0)] for op in stages]  # different parameters: not uniform over the levels
+        prog = native.level_program(rows, dev)
+        native.pointwise_stack(st.data, out.data, n_pts=len(x), n_lev=2, x_pitch=st.pitch, y_pitch=out.pitch, layout=COLUMNS, prog=prog, n_stage=len(stages))
+        got = out.numpy()
+        assert np.array_equal(got[0], got[1][::-1], equal_nan=True)
+        return got[0]
+
+    for name, x in cases.items():
+        with np.errstate(all="ignore"):
+            want = np.exp(x)
+        for per_level in (False, True):
+            got = run(x, per_level)
+            err = np.abs(got - want) / np.spacing(np.abs(want))
+            assert float(err.max()) <= 1.0, (name, per_level, float(err.max()))
+    with np.errstate(all="ignore"):
+        want = np.exp(special)
+    for per_level in (False, True):
+        got = run(special, per_level)
+        assert np.array_equal(got[:7], want[:7], equal_nan=True), (got[:7], want[:7])  # 1, 1, inf, 0, NaN, inf, 0
+        assert np.all(np.abs(got[7:] - want[7:]) <= np.spacing(np.abs(want[7:])))
+    # sp_to_lnsp | lnsp_to_sp and back as ONE two-stage launch (what tools/kernel_bench.py times): each stage within 1 ulp of numpy's
+    # function of the previous stage's OWN result is what the chain can promise, i.e. 1 ulp + the conditioning of the second function
+    p = rng.uniform(3.0e4, 1.1e5, n)
+    got = run(p, stages=(native.OP_LOG, native.OP_EXP))
+    assert float(np.max(np.abs(got - p) / p)) <= 13 * 2.3e-16  # |d exp| = ln p (<= 11.6) ulps of the logarithm, + 1
+    lnp = np.log(p)
+    got = run(lnp, stages=(native.OP_EXP, native.OP_LOG))
+    assert float(np.max(np.abs(got - lnp) / np.spacing(lnp))) <= 2.0
+
+
 @pytest.mark.parametrize("tdtype,np_dtype", DTYPES)
 @pytest.mark.parametrize("in_place", [False, True])
 @pytest.mark.parametrize("program", ["uniform_1", "uniform_4", "uniform_5", "two_pieces", "two_pieces_one_idle", "masked_uniform", "masked_piece",

@@ -9,6 +9,7 @@ INTEGRATION.md are replaced (the newest round's record of each kind is used):
   kernel-table   profiles/rNN_kernel_bench.json   (tools/kernel_bench.py --out)
   bench-line     profiles/rNN_bench_latest.json   (python bench.py)
   host-fed       profiles/rNN_host_fed_path.json  (tools/host_path_bench.py) + the bench record's all-core CPU line
+  filter-parity  DESIGN.md §7's table of the reference's field filters (README.md repeats it: what is pinned, what says at run time that it is not)
 `--check` exits 1 if a document is not up to date (used by tests/test_host_api.py)."""
 
 from __future__ import annotations
@@ -126,7 +127,14 @@ def host_fed(path: str) -> str:
             f"result.  (`{os.path.relpath(path, ROOT)}`, `{bench_rel}`)")
 
 
-SOURCES = {"kernel-table": ("kernel_bench.json", kernel_table), "bench-line": ("bench_latest.json", bench_line), "host-fed": ("host_fed_path.json", host_fed)}
+def filter_parity(path: str) -> str:
+    """DESIGN.md §7's table — reference file, where it lives here, what pins it, whether the filter warns at run time — row for row."""
+    text = open(path).read()
+    section = text[text.index("| Reference file | Here | Parity | Says so at run time |"):]
+    return section[:section.index("\n\n")]
+
+
+SOURCES = {"filter-parity": ("DESIGN.md", filter_parity), "kernel-table": ("kernel_bench.json", kernel_table), "bench-line": ("bench_latest.json", bench_line), "host-fed": ("host_fed_path.json", host_fed)}
 
 
 def main():
@@ -139,7 +147,7 @@ def main():
         text = open(doc_path).read()
         new = text
         for name, (kind, fn) in SOURCES.items():
-            rel = newest(kind)
+            rel = kind if kind.endswith(".md") else newest(kind)
             path = os.path.join(ROOT, rel)
             pattern = re.compile(rf"(<!-- BEGIN generated: {name}[^\n]*-->\n)(.*?)(\n<!-- END generated: {name} -->)", re.S)
             if not pattern.search(new):

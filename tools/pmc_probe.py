@@ -36,10 +36,14 @@ def main():
     ap.add_argument("--k", type=int, default=4)
     ap.add_argument("--levels", type=int, default=137)
     ap.add_argument("--layout", default="columns", choices=["columns", "fields"])
-    ap.add_argument("--case", default="ell", choices=["ell", "csr34", "csr916", "box", "perlevel", "fieldspw", "pad916"],
+    ap.add_argument("--case", default="ell", choices=["ell", "csr34", "csr916", "box", "perlevel", "fieldspw", "pad916", "config4", "config5"],
                     help="ell: fixed k (--k); csr34 / csr916: general CSR with ragged rows of 3-4 / 9-16 entries; box: O1280 -> 1 degree box averages (~100 per row)")
     ap.add_argument("--ordered", action="store_true", help="ell only: visit the targets in column blocks (atx_regrid_ell_ordered)")
     ap.add_argument("--chunk", type=int, default=0, help="ell only: one launch per chunk of this many levels (the level-chunk-major traversal, emulated)")
+    ap.add_argument("--shard", type=int, default=-1, help="config4 / config5: time this one of the 8 traffic-balanced target shards (-1: all targets)")
+    ap.add_argument("--tall", action="store_true", help="config4: 4 stacks of 6 x 137 levels (the variables of a point share a column) instead of 24 x 137; "
+                                                        "config5: one stack of 3 x 137 levels instead of 137")
+    ap.add_argument("--plain", action="store_true", help="config5: the gather alone instead of the fused regrid | orog_to_z | convert launch")
     ap.add_argument("--meta", default=os.path.join(ROOT, "gpurun_out", "pmc_meta.json"))
     args = ap.parse_args()
 
@@ -54,6 +58,9 @@ def main():
     tdtype = torch.float32 if args.dtype == "f32" else torch.float64
     npdt = np.float32 if args.dtype == "f32" else np.float64
     itemsize = 4 if args.dtype == "f32" else 8
+
+    if args.case in ("config4", "config5"):
+        return baseline_configs(args, native, dev, tdtype, npdt, itemsize)
 
     src_grid, tgt_grid = lookup("o1280"), lookup("0.25")
     n_src, n_tgt = len(src_grid["latitudes"]), len(tgt_grid["latitudes"])
@@ -182,6 +189,66 @@ def main():
         "regrid_launches": args.launches,
         "algorithmic_bytes_per_launch": alg,
     }
+    os.makedirs(os.path.dirname(args.meta), exist_ok=True)
+    json.dump(meta, open(args.meta, "w"), indent=1)
+    print(json.dumps(meta))
+
+
+def baseline_configs(args, native, dev, tdtype, npdt, itemsize):
+    """BASELINE configs[3] and [4] as bench.py times them (extras.config4 / extras.config5), under the counters:
+    config4 — O1280 -> N320-sized, k = 4, 3 288 fields resident as 24 stacks of 137 levels (or, --tall, 4 stacks of 822), one of the 8
+    target shards (--shard) or all targets, one batched step per repetition; config5 — O2560 -> 0.25 degree, 137 levels (or, --tall,
+    3 x 137 sharing a column), the fused regrid | orog_to_z | convert launch (or, --plain, the gather alone)."""
+    from anemoi_transform_amd.gather import GatherPlan
+    from anemoi_transform_amd.grids import lookup
+    from anemoi_transform_amd.interp import knn_inverse_distance
+    from anemoi_transform_amd.stack import COLUMNS, Stack
+
+    def calibrate(n_elems):  # the library's fixed streaming copy over a known number of bytes, 16 bytes per lane
+        a = torch.zeros(n_elems, dtype=tdtype, device=dev)
+        b = torch.empty_like(a)
+        native.stream_copy(a, b)
+        torch.cuda.synchronize()
+        return n_elems * itemsize
+
+    which = "all targets" if args.shard < 0 else f"shard {args.shard} of 8"
+    if args.case == "config4":
+        g_src, g_tgt = lookup("o1280"), lookup("n320-sized")
+        n_src, n_tgt, n_var, n_time = len(g_src["latitudes"]), len(g_tgt["latitudes"]), 6, 4
+        idx, w = knn_inverse_distance(g_src, g_tgt, k=4)
+        cuts = GatherPlan(n_src, n_tgt, index=idx, weights=w).bounds(8)
+        lo, hi = (0, n_tgt) if args.shard < 0 else (cuts[args.shard], cuts[args.shard + 1])
+        n_stack, n_lev = (n_time, n_var * args.levels) if args.tall else (n_var * n_time, args.levels)
+        calib = calibrate(n_src * args.levels)
+        gen = torch.Generator(device=dev)
+        srcs = []
+        for i in range(n_stack):
+            gen.manual_seed(bench.SEED + 7 * i)
+            st = Stack.empty(n_src, n_lev, tdtype, dev, COLUMNS, zero=True)
+            st.data[:, :n_lev].normal_(250.0 + 5.0 * (i // 4), 20.0, generator=gen)
+            srcs.append(st)
+        outs = [Stack.empty(hi - lo, n_lev, tdtype, dev, COLUMNS) for _ in range(n_stack)]
+        idx_d, w_d, rows_d = bench.ordered_tables(idx, w, g_tgt, lo, hi, npdt, dev)
+        torch.cuda.synchronize()
+        for _ in range(args.launches):
+            native.regrid_ell_batch([s_.data for s_ in srcs], [o.data for o in outs], idx_d, w_d, n_src=n_src, n_tgt=hi - lo, k=4, n_lev=n_lev,
+                                    src_pitch=srcs[0].pitch, out_pitch=outs[0].pitch, layout=COLUMNS, tgt_rows=rows_d)
+        alg = n_stack * bench.algorithmic_bytes(n_lev, itemsize, int(np.unique(idx[lo:hi]).size), hi - lo, 4)
+        config = f"config4 o1280->n320-sized k=4 {n_stack}x{n_lev} levels {args.dtype} columns {which}"
+    else:
+        class A:  # what bench.config5_case reads of the bench's arguments
+            levels, natural_order = args.levels, False
+        calib = calibrate(len(lookup("o1280")["latitudes"]) * args.levels)
+        rank, world = (0, 1) if args.shard < 0 else (args.shard, 8)
+        plain, fused, _, _, alg, keep = bench.config5_case(A, dev, tdtype, npdt, rank=rank, world=world, variables=3 if args.tall else 1)
+        torch.cuda.synchronize()
+        for _ in range(args.launches):
+            (plain if args.plain else fused)()
+        n_lev = args.levels * (3 if args.tall else 1)
+        config = (f"config5 o2560->0.25 k=4 L={n_lev} {args.dtype} columns {'regrid only' if args.plain else 'fused regrid|orog_to_z|convert'} {which}")
+    torch.cuda.synchronize()
+    meta = {"config": config, "calibration_kernel": "stream_copy_kernel", "calibration_read_bytes": calib, "calibration_write_bytes": calib,
+            "regrid_kernel": "regrid_cols_ell_direct_kernel", "regrid_launches": args.launches, "algorithmic_bytes_per_launch": alg}
     os.makedirs(os.path.dirname(args.meta), exist_ok=True)
     json.dump(meta, open(args.meta, "w"), indent=1)
     print(json.dumps(meta))
