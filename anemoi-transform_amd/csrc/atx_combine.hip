@@ -144,9 +144,9 @@ __device__ __forceinline__ void combine_one(int flags, const T* x, int n_in, T l
         case ATX_COMB_SNOW_DEPTH_M: y0 = T(1000.0) * x[0] / x[1]; break;
         case ATX_COMB_SNOW_COVER: {
             const T tmp1 = (T(1000) * x[0]) / x[1];
-            T tmp2 = x[1];  // np.clip(rsn, 100, 400): NaN stays NaN
-            tmp2 = (tmp2 < T(100)) ? T(100) : tmp2;
-            tmp2 = (tmp2 > T(400)) ? T(400) : tmp2;
+            // np.clip(rsn, 100, 400) as one max and one min: a NaN density — which np.clip would keep — has made tmp1, and with it arg, a
+            // NaN already, so the hardware's "the other operand" for a NaN changes nothing (6 compare-and-select instructions -> 2-4)
+            const T tmp2 = __builtin_fmin(__builtin_fmax(x[1], T(100)), T(400));
             const T arg = (T(4000) * tmp1) / tmp2;
             // The two common cases need no tanh and give the statement's bits exactly: deep snow — every arg > atanh(0.99) =
             // 2.6467 has tanh(arg) > 0.99 (at 2.65: 0.990066, four orders above any rounding of tanh), which the last line
@@ -158,29 +158,35 @@ __device__ __forceinline__ void combine_one(int flags, const T* x, int n_in, T l
             } else if (arg == T(0)) {
                 y0 = arg;
             } else {
-                // tanh through expm1: e = expm1(2|x|), tanh|x| = e / (e + 2) — no cancellation anywhere on (0, 2.65], 2-3 ulp — instead
+                // tanh through expm1: e = expm1(2x), tanh x = e / (e + 2) — no cancellation anywhere on (0, 2.65], 2-3 ulp — instead
                 // of the device library's tanh (float64: 169 VALU instructions per element).  Round 3 took the library's expm1 and an
                 // IEEE division for it (907 -> ~350 instructions per wave of 4 elements per lane; profiles/r03_pmc_sq_combine.txt);
-                // round 5 the library's own atx_tanh_pos (atx_common.hpp: expm1 in ~24 instructions, the quotient in 7).
+                // round 5 the library's own atx_tanh_moderate (atx_common.hpp: expm1 in 24 instructions, the quotient in 7) and no
+                // clamping, sign or NaN handling around it: what reaches this branch is (0, 2.65], whose tanh lies in (0, 0.99007) and needs
+                // only the statement's last line; a NaN, which the arithmetic carries through (every comparison below is false for it);
+                // or a negative argument (a negative snow depth), whose tanh the clip to [0, 1] replaces by 0 whatever its value.
                 // ATX_SNOW_TANH=1 restores the device library's tanh, =2 round 3's form.
 #ifndef ATX_SNOW_TANH
 #define ATX_SNOW_TANH 0
 #endif
-                T sc;
-                if constexpr (ATX_SNOW_TANH == 1 || sizeof(T) == 4) {
-                    sc = tanh(arg);
-                } else if constexpr (ATX_SNOW_TANH == 2) {
-                    const T mag = fabs(arg);  // (only negative arguments get here beyond 2.65: they end up clipped to 0)
-                    const T e = expm1(T(2) * (mag < T(20) ? mag : T(20)));
-                    sc = copysign(mag < T(20) ? e / (e + T(2)) : T(1), arg);  // tanh(20) rounds to 1.0 in float64
-                    if (arg != arg) sc = arg;  // NaN stays NaN
+                if constexpr (ATX_SNOW_TANH == 0 && sizeof(T) == 8) {
+                    const T t = (T)atx_tanh_moderate((double)arg);
+                    const T sc = (t > T(0.99)) ? T(1.0) : t;
+                    y0 = (arg < T(0)) ? T(0) : sc;
                 } else {
-                    // a negative argument (negative snow depth) ends up clipped to 0 two lines down whatever its tanh is: only its sign matters
-                    sc = copysign((T)atx_tanh_pos((double)fabs(arg)), arg);
+                    T sc;
+                    if constexpr (ATX_SNOW_TANH == 2 && sizeof(T) == 8) {
+                        const T mag = fabs(arg);  // (only negative arguments get here beyond 2.65: they end up clipped to 0)
+                        const T e = expm1(T(2) * (mag < T(20) ? mag : T(20)));
+                        sc = copysign(mag < T(20) ? e / (e + T(2)) : T(1), arg);  // tanh(20) rounds to 1.0 in float64
+                        if (arg != arg) sc = arg;  // NaN stays NaN
+                    } else {
+                        sc = tanh(arg);
+                    }
+                    sc = (sc < T(0)) ? T(0) : sc;
+                    sc = (sc > T(1)) ? T(1) : sc;
+                    y0 = (sc > T(0.99)) ? T(1.0) : sc;
                 }
-                sc = (sc < T(0)) ? T(0) : sc;
-                sc = (sc > T(1)) ? T(1) : sc;
-                y0 = (sc > T(0.99)) ? T(1.0) : sc;
             }
             break;
         }
@@ -393,6 +399,9 @@ combine_kernel(CombArgs a, int flags, int n_in, int n_out, int64_t n_rows, int64
     constexpr bool kLevels = OP == ATX_COMB_W_TO_WZ || OP == ATX_COMB_WZ_TO_W || OP == ATX_COMB_OPERA_CLIP ||
                              OP == ATX_COMB_OPERA_PREPROCESS || OP == ATX_COMB_ORAS6 || OP == ATX_COMB_Q_TO_R ||
                              OP == ATX_COMB_R_TO_Q;  // the operators that read level_param[level] (when given one)
+    // every operator but the n-ary sum and the two humidity conversions that take the pressure as an optional third field has a fixed
+    // operand count, NIN == n_in — validated on the host: no run-time test per operand and element for them
+    constexpr bool kFixedOperands = OP != ATX_COMB_SUM && OP != ATX_COMB_Q_TO_R && OP != ATX_COMB_R_TO_Q;
     constexpr bool kShared1 = OP == ATX_COMB_ORAS6;  // operand 1 is ONE field [n_pts] shared by every level, not a stack
     const bool small_rows = vec_per_row < (1 << 20);  // columns layout: (row, col) from 32-bit arithmetic
     // a workgroup takes a contiguous run of chunks, not every gridDim.x-th one: under the 65536-workgroup cap the grid stride is a
@@ -440,7 +449,8 @@ combine_kernel(CombArgs a, int flags, int n_in, int n_out, int64_t n_rows, int64
             for (int e = 0; e < VEC; ++e) {
                 T xe[ATX_COMB_MAX_INPUTS];
 #pragma unroll
-                for (int k = 0; k < ATX_COMB_MAX_INPUTS; ++k) xe[k] = (k < NIN && k < n_in) ? x[u][k < NIN ? k : 0].v[e] : T(0);
+                for (int k = 0; k < ATX_COMB_MAX_INPUTS; ++k)
+                    xe[k] = (k < NIN && (kFixedOperands || k < n_in)) ? x[u][k < NIN ? k : 0].v[e] : T(0);
                 const bool live = (col + e) < row_len;
                 if constexpr (kShared1) {
                     const int64_t point = layout == ATX_COLUMNS ? row : col + e;

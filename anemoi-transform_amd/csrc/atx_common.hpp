@@ -108,6 +108,23 @@ __device__ __forceinline__ double quiet_nan<double>() {
     return __longlong_as_double(0x7ff8000000000000ll);  // np.nan
 }
 
+// fma(a, b, c) with c a compile-time constant held in SCALAR registers (v_fma_f64 v, v, v, s[..]).  Left to itself the compiler keeps the
+// coefficients of a float64 polynomial in vector registers and evaluates Horner steps with the two-address v_fmac_f64, which overwrites
+// its addend — so every step of every element first COPIES its coefficient (v_mov_b64): 12 extra instructions in a degree-13 Horner chain,
+// a third of it.  ATX_FMA_SGPR=0 restores __builtin_fma.
+#ifndef ATX_FMA_SGPR
+#define ATX_FMA_SGPR 1
+#endif
+__device__ __forceinline__ double fma_k(double a, double b, double c) {
+#if ATX_FMA_SGPR
+    double d;
+    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "s"(c));
+    return d;
+#else
+    return __builtin_fma(a, b, c);
+#endif
+}
+
 // a / b for float64 WITHOUT the IEEE division sequence (v_div_scale x2, v_rcp, 5 fma, v_div_fmas, v_div_fixup = 13 VALU instructions):
 // hardware reciprocal (2^-23), one Newton step, the quotient and one correction with its exact residual — 7 instructions, <= 1 ulp.
 // For quotients INSIDE a library function (log's s = f / (2 + f), tanh's e / (e + 2)), whose own error budget is wider; the
@@ -150,7 +167,7 @@ __device__ __forceinline__ double atx_log(double x) {
     const double f = m - 1.0;  // exact
     const double s = quotient_1ulp(f, 2.0 + f);
     const double z = s * s;
-    const double R = z * __builtin_fma(z, __builtin_fma(z, __builtin_fma(z, __builtin_fma(z, __builtin_fma(z, __builtin_fma(z, Lg7, Lg6), Lg5), Lg4), Lg3), Lg2), Lg1);
+    const double R = z * fma_k(z, fma_k(z, fma_k(z, fma_k(z, fma_k(z, fma_k(z, Lg7, Lg6), Lg5), Lg4), Lg3), Lg2), Lg1);
     const double hfsq = 0.5 * f * f;
     const double dk = (double)k;
     double y = __builtin_fma(dk, ln2_hi, f - (hfsq - __builtin_fma(s, hfsq + R, dk * ln2_lo)));
@@ -192,38 +209,38 @@ __device__ __forceinline__ double atx_log(double x) {
 #endif
 }
 
-// expm1(y) for 0 <= y <= 40 in float64 and, on it, tanh of a positive argument — what `snow_cover` needs between bare ground and
-// deep snow (R: filters/fields/snow_cover.py:34-39; atx_combine.hip).  y = k ln2 + r, |r| <= ln2 / 2; expm1(r) = r + r^2 q(r) with
-// q the Taylor series to r^13 (truncation 1e-17 relative); 2^k (r + r^2 q) + (2^k - 1) evaluated as fma(2^k r^2, q, fma(2^k, r, 2^k - 1)):
-// the dominant part takes ONE rounding (k = 1, r < 0 would otherwise cancel a rounded expm1(r) against 1).  ~24 VALU instructions;
-// <= 1 ulp from numpy's expm1 (true error <= 1.2 ulp on the host prototype).  The device library's expm1: 57.
-__device__ __forceinline__ double atx_expm1_pos(double y) {
+// expm1(y) in float64 for moderate arguments (|y| <= 40; beyond, or for NaN, the result is garbage or NaN but never a trap) and, on it,
+// tanh — what `snow_cover` needs between bare ground and deep snow (R: filters/fields/snow_cover.py:34-39; atx_combine.hip).
+// y = k ln2 + r, |r| <= ln2 / 2; expm1(r) = r + r^2 q(r) with q the Taylor series to r^13 (truncation 1e-17 relative);
+// 2^k (r + r^2 q) + (2^k - 1) evaluated as fma(2^k r^2, q, fma(2^k, r, 2^k - 1)): the dominant part takes ONE rounding (k = 1, r < 0 would
+// otherwise cancel a rounded expm1(r) against 1).  24 VALU instructions; <= 1 ulp from numpy's expm1 on (0, 40] (true error <= 1.2 ulp on
+// the host prototype).  The device library's expm1: 57.
+__device__ __forceinline__ double atx_expm1_moderate(double y) {
     constexpr double log2e = 1.4426950408889634, ln2hi = 6.93147180559945286227e-01, ln2lo = 2.31904681384629955842e-17;
     const double k = __builtin_rint(y * log2e);
     double r = __builtin_fma(-k, ln2hi, y);
     r = __builtin_fma(-k, ln2lo, r);
     double q = 1.0 / 6227020800.0;  // 1 / 13!
-    q = __builtin_fma(q, r, 1.0 / 479001600.0);
-    q = __builtin_fma(q, r, 1.0 / 39916800.0);
-    q = __builtin_fma(q, r, 1.0 / 3628800.0);
-    q = __builtin_fma(q, r, 1.0 / 362880.0);
-    q = __builtin_fma(q, r, 1.0 / 40320.0);
-    q = __builtin_fma(q, r, 1.0 / 5040.0);
-    q = __builtin_fma(q, r, 1.0 / 720.0);
-    q = __builtin_fma(q, r, 1.0 / 120.0);
-    q = __builtin_fma(q, r, 1.0 / 24.0);
-    q = __builtin_fma(q, r, 1.0 / 6.0);
-    q = __builtin_fma(q, r, 0.5);
-    const double t = __hiloint2double(((int)k + 1023) << 20, 0);  // 2^k, 0 <= k <= 58
+    q = fma_k(q, r, 1.0 / 479001600.0);
+    q = fma_k(q, r, 1.0 / 39916800.0);
+    q = fma_k(q, r, 1.0 / 3628800.0);
+    q = fma_k(q, r, 1.0 / 362880.0);
+    q = fma_k(q, r, 1.0 / 40320.0);
+    q = fma_k(q, r, 1.0 / 5040.0);
+    q = fma_k(q, r, 1.0 / 720.0);
+    q = fma_k(q, r, 1.0 / 120.0);
+    q = fma_k(q, r, 1.0 / 24.0);
+    q = fma_k(q, r, 1.0 / 6.0);
+    q = fma_k(q, r, 0.5);
+    const double t = __hiloint2double(((int)k + 1023) << 20, 0);  // 2^k, |k| <= 58
     const double a = __builtin_fma(t, r, t - 1.0);
     return __builtin_fma(t * (r * r), q, a);
 }
-// tanh(x) for x > 0 (NaN passes through): e / (e + 2) with e = expm1(2x) — no cancellation anywhere; 1.0 from 20 on (tanh(20) rounds to 1).
-__device__ __forceinline__ double atx_tanh_pos(double x) {
-    const bool small = x < 20.0;
-    const double e = atx_expm1_pos(2.0 * (small ? x : 20.0));
-    const double t = small ? quotient_1ulp(e, e + 2.0) : 1.0;
-    return (x != x) ? x : t;
+// tanh(x) for 0 < x <= 20 (NaN passes through; a negative x of moderate size gives tanh(x) too): e / (e + 2) with e = expm1(2x) — no
+// cancellation anywhere, 2-3 ulp from numpy's.
+__device__ __forceinline__ double atx_tanh_moderate(double x) {
+    const double e = atx_expm1_moderate(2.0 * x);
+    return quotient_1ulp(e, e + 2.0);
 }
 
 // One per-level operator in the arithmetic type of the stack.

@@ -1103,6 +1103,9 @@ static int pointwise_typed(const void* x_, void* y_, int64_t n_pts, int n_lev, i
 #ifndef ATX_PW_UNIFORM_NT
 #define ATX_PW_UNIFORM_NT 1
 #endif
+#ifndef ATX_PW_TRANS_U
+#define ATX_PW_TRANS_U 1  // vectors per lane of programs with exp / log (A/B knob, tools/experiments/trans_ab.py)
+#endif
 #ifndef ATX_PW_TRANS_NT
 #define ATX_PW_TRANS_NT 1  // non-temporal accesses for programs with exp / log too
 #endif
@@ -1114,13 +1117,13 @@ static int pointwise_typed(const void* x_, void* y_, int64_t n_pts, int n_lev, i
 #endif
                 const bool nt = ATX_PW_UNIFORM_NT && (ATX_PW_MASK_NT || !(uses_mask && mask));
                 if (in_place) {
-                    if (trans && nt && ATX_PW_TRANS_NT) ATX_PW_UNIFORM_LAUNCH(true, ATX_PW_UNIFORM_U_IN, true);
-                    else if (trans) ATX_PW_UNIFORM_LAUNCH(true, ATX_PW_UNIFORM_U_IN, false);
+                    if (trans && nt && ATX_PW_TRANS_NT) ATX_PW_UNIFORM_LAUNCH(true, ATX_PW_TRANS_U, true);
+                    else if (trans) ATX_PW_UNIFORM_LAUNCH(true, ATX_PW_TRANS_U, false);
                     else if (nt) ATX_PW_UNIFORM_LAUNCH(false, ATX_PW_UNIFORM_U_IN, true);
                     else ATX_PW_UNIFORM_LAUNCH(false, ATX_PW_UNIFORM_U_IN, false);
                 } else {
-                    if (trans && nt && ATX_PW_TRANS_NT) ATX_PW_UNIFORM_LAUNCH(true, ATX_PW_UNIFORM_U_OUT, true);
-                    else if (trans) ATX_PW_UNIFORM_LAUNCH(true, ATX_PW_UNIFORM_U_OUT, false);
+                    if (trans && nt && ATX_PW_TRANS_NT) ATX_PW_UNIFORM_LAUNCH(true, ATX_PW_TRANS_U, true);
+                    else if (trans) ATX_PW_UNIFORM_LAUNCH(true, ATX_PW_TRANS_U, false);
                     else if (nt) ATX_PW_UNIFORM_LAUNCH(false, ATX_PW_UNIFORM_U_OUT, true);
                     else ATX_PW_UNIFORM_LAUNCH(false, ATX_PW_UNIFORM_U_OUT, false);
                 }

@@ -32,6 +32,14 @@ from .stack import COLUMNS, Stack
 # batched launch of the direct kernel) the slowest rank is fastest for weights of 0.5-0.7 (0.448-0.451 ms at 8 shards against
 # 0.455 at 1.1-1.4 and 0.57 for equal counts).
 TARGET_COST = 0.6
+# The same weight for a step that is ONE SHORT launch per rank — the strong-scaling split of a single stack (bench.py's headline at
+# N > 1: 0.1 ms per rank at 8 ranks): a launch then pays per workgroup as well as per byte, and the polar shards — few source
+# columns, twice the targets of the others — are the slow ones under 0.6.  tools/experiments/shard_weight_sweep.py,
+# profiles/r05_shard_weight_sweep.log (every shard timed alone, O1280 -> 0.25 degree, 137 levels, float64): slowest of 8 shards 0.126 ms
+# at 0.6, 0.119 at 1.1, **0.117 at 1.3**, 0.118 at 1.5-1.8 (speed-up bound of the 8-rank line 6.67 -> 7.22); 4 shards: flat from 0.9 on; float32
+# keeps improving up to 1.8 (7.67 -> 8.5).  The batched step prefers 0.6-0.9 on the same tables, so the weight is an argument of
+# ``bounds`` / ``shard``, not a new default.
+TARGET_COST_SHORT_LAUNCH = 1.3
 
 
 class GatherPlan:
@@ -156,7 +164,7 @@ class GatherPlan:
             index = np.where(index < 0, index + n_src, index)  # numpy indexing accepts negatives
         return cls(n_src, len(index), index=index)
 
-    def bounds(self, world: int) -> list[int]:
+    def bounds(self, world: int, target_cost: float | None = None) -> list[int]:
         """Target boundaries ``b[0] = 0 <= ... <= b[world] = n_tgt`` of the ``world`` contiguous shards,
         balanced by estimated HBM TRAFFIC rather than by target count.
 
@@ -164,12 +172,15 @@ class GatherPlan:
         it writes.  On a lat-lon target grid equal-count shards are badly unbalanced — near the poles many
         targets share few source columns: measured 0.31 ms (polar) vs 0.57 ms (equatorial) per step on
         O1280 -> 0.25 degree at 8 shards, which would cap weak scaling at 82 %; balanced: within a few %
-        (profiles/r01_shard_balance.log).
+        (profiles/r01_shard_balance.log).  ``target_cost``: the weight of a target column (default ``TARGET_COST``; a step made
+        of one short launch per rank balances better with ``TARGET_COST_SHORT_LAUNCH``).
         """
+        weight = TARGET_COST if target_cost is None else float(target_cost)
         cached = self.__dict__.setdefault("_bounds", {})
-        if world not in cached:
+        key = (world, weight)
+        if key not in cached:
             if world <= 1 or self.n_tgt == 0:
-                cached[world] = [0] + [self.n_tgt] * max(world, 1)
+                cached[key] = [0] + [self.n_tgt] * max(world, 1)
             else:
                 if self.kind == "ell":
                     flat = self.index.reshape(-1).astype(np.int64)
@@ -182,32 +193,32 @@ class GatherPlan:
                 # source columns first referenced by each target, in target order
                 _, first = np.unique(flat, return_index=True)
                 new_sources = np.bincount(row_of[first], minlength=self.n_tgt).astype(np.float64)
-                cost = np.cumsum(new_sources + TARGET_COST)
+                cost = np.cumsum(new_sources + weight)
                 edges = np.searchsorted(cost, cost[-1] * np.arange(1, world) / world, side="left") + 1
                 b = [0] + [int(min(max(e, 0), self.n_tgt)) for e in edges] + [self.n_tgt]
                 for i in range(1, len(b)):
                     b[i] = max(b[i], b[i - 1])
-                cached[world] = b
-        return cached[world]
+                cached[key] = b
+        return cached[key]
 
-    def shard_range(self, rank: int, world: int) -> tuple[int, int]:
-        b = self.bounds(world)
+    def shard_range(self, rank: int, world: int, target_cost: float | None = None) -> tuple[int, int]:
+        b = self.bounds(world, target_cost)
         return b[rank], b[rank + 1]
 
-    def shard(self, rank: int, world: int) -> "GatherPlan":
+    def shard(self, rank: int, world: int, target_cost: float | None = None) -> "GatherPlan":
         """The ``rank``-th of ``world`` contiguous, traffic-balanced slices of the target points.  Remembered per (rank, world):
         a job asks for its shard at every step, and a fresh plan would re-validate its indices on the host and upload its tables
         again (O1280 -> 0.25 degree: 4 ms per call against 0.85 ms of kernel)."""
         cached = self.__dict__.setdefault("_shards", {})
-        key = (int(rank), int(world))
+        key = (int(rank), int(world), TARGET_COST if target_cost is None else float(target_cost))
         if key not in cached:
             if len(cached) >= 64:
                 cached.pop(next(iter(cached)))
-            cached[key] = self._cut_shard(rank, world)
+            cached[key] = self._cut_shard(rank, world, target_cost)
         return cached[key]
 
-    def _cut_shard(self, rank: int, world: int) -> "GatherPlan":
-        lo, hi = self.shard_range(rank, world)
+    def _cut_shard(self, rank: int, world: int, target_cost: float | None = None) -> "GatherPlan":
+        lo, hi = self.shard_range(rank, world, target_cost)
         if self.kind == "ell":
             part = GatherPlan(self.n_src, hi - lo, index=self.index[lo:hi],
                               weights=None if self.weights is None else self.weights[lo:hi], padded=self.padded)

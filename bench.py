@@ -347,7 +347,11 @@ def main():
         from anemoi_transform_amd.gather import target_order_for
 
         plan.order_targets(target_order_for(tgt_grid["latitudes"], tgt_grid["longitudes"], args.k))
-    bounds = plan.bounds(world)
+    # the headline step is ONE short launch per rank (0.1 ms at 8 ranks): cut with the weight measured for that shape
+    # (gather.TARGET_COST_SHORT_LAUNCH, profiles/r05_shard_weight_sweep.log); the weak / exchange sections keep the library's default cut
+    from anemoi_transform_amd.gather import TARGET_COST_SHORT_LAUNCH
+
+    bounds = plan.bounds(world, target_cost=TARGET_COST_SHORT_LAUNCH)
     lo, hi = bounds[rank], bounds[rank + 1]
 
     # ---- sources resident in HBM before the timed region: the N stacks of the step, each a pure function of its id
@@ -356,7 +360,7 @@ def main():
     # grid from k = 5 on: GatherPlan.order_targets / atx_regrid_ell_ordered, same results bit for bit)
     idx_d, w_d, rows_d = ordered_tables(idx64, w64, tgt_grid, lo, hi, np_dtype, dev, natural=layout != COLUMNS or args.natural_order)
     assert native.check_indices(idx_d, n_src) == 0
-    outs = [Stack.empty(hi - lo, args.levels, tdtype, dev, layout) for _ in stacks]
+    outs = [Stack.empty(hi - lo, args.levels, tdtype, dev, layout)]
 
     def launch(src, out, idx=None, w=w_d, k=args.k, n_t=hi - lo):
         rows = rows_d if idx is None else None  # callers that bring their own tables bring them in natural order
@@ -365,13 +369,6 @@ def main():
 
     def step():  # the job of EVERY N: stack 0 -> this rank's slice of the target grid, one launch (fixed total work: strong scaling)
         launch(stacks[0], outs[0])
-
-    def weak_step():  # rounds 1-4's step, now `weak`: one launch over the N stacks of the step (atx_regrid_ell_batch / _ordered: grid.y = stack)
-        if len(stacks) == 1:
-            launch(stacks[0], outs[0])
-        else:
-            native.regrid_ell_batch([s.data for s in stacks], [o.data for o in outs], idx_d, w_d, n_src=n_src, n_tgt=hi - lo,
-                                    k=args.k, n_lev=args.levels, src_pitch=stacks[0].pitch, out_pitch=outs[0].pitch, layout=layout, tgt_rows=rows_d)
 
     # ---- timed region: W warm-up steps, then exactly K steps between barriers
     for _ in range(args.warmup):
@@ -430,7 +427,7 @@ def main():
             "layout": args.layout,
             "target_order": "natural (row-major)" if rows_d is None else "column blocks of the target grid (results identical; atx_regrid_ell_ordered: the library's policy for k >= 5)",
             "stacks_per_step": 1,
-            "sharding": ("target points over ranks (contiguous, traffic-balanced), no collective in the data path; FIXED TOTAL WORK: every line of the "
+            "sharding": ("target points over ranks (contiguous, traffic-balanced with the weight measured for one short launch per rank), no collective in the data path; FIXED TOTAL WORK: every line of the "
                          "N = 1, 2, 4, 8 series regrids the same ONE stack (BASELINE configs[2], the loop at R: regrid.py:204-208) per step, each rank "
                          "its 1/N slice of the target points, the source stack resident on every rank before the timed region (inputs resident in "
                          "HBM) — `value` is STRONG scaling and EXCLUDES the source exchange: value(N) / value(1) is the driver's scaling figure, it is "
@@ -476,8 +473,8 @@ def main():
         quiet = quiet_stdout()
         quiet.__enter__()
         try:
-            multi_gpu_lines(args, result, dist, rank, world, dev, plan, stacks, outs, launch, weak_step, units_per_step * world, barrier, max_over_ranks,
-                            src_grid, n_src, n_tgt, tdtype, np_dtype, idx64, w64, layout, quiet.saved)
+            multi_gpu_lines(args, result, dist, rank, world, dev, plan, stacks, launch, units_per_step * world, barrier, max_over_ranks,
+                            src_grid, tgt_grid, n_src, n_tgt, tdtype, np_dtype, idx64, w64, layout, quiet.saved)
         finally:
             quiet.__exit__()
     if multi:
@@ -498,8 +495,8 @@ def main():
 # ------------------------------------------------------------------------------------------------------------------------
 # N > 1: what is measured AFTER `value` — the exchange over RCCL, end to end, strong scaling, field-axis sharding
 # ------------------------------------------------------------------------------------------------------------------------
-def multi_gpu_lines(args, result, dist, rank, world, dev, plan, stacks, outs, launch, weak_step, units_per_step, barrier, max_over_ranks,
-                    src_grid, n_src, n_tgt, tdtype, np_dtype, idx64, w64, layout, real_stdout_fd):
+def multi_gpu_lines(args, result, dist, rank, world, dev, plan, stacks, launch, units_per_step, barrier, max_over_ranks,
+                    src_grid, tgt_grid, n_src, n_tgt, tdtype, np_dtype, idx64, w64, layout, real_stdout_fd):
     from anemoi_transform_amd import distributed as atxd
     from anemoi_transform_amd import native
     from anemoi_transform_amd.stack import COLUMNS, Stack
@@ -541,6 +538,21 @@ def multi_gpu_lines(args, result, dist, rank, world, dev, plan, stacks, outs, la
         if flag.item() < 1.0 and ok == 1.0:
             out = {"error": "failed on another rank"}
         return out
+
+    # this rank's slice under the library's DEFAULT cut (GatherPlan.bounds(world): what distributed.py's functions take from the plan),
+    # its tables and one output stack per source stack — the weak step below fills them, the exchange sections verify against them
+    lo_w, hi_w = plan.shard_range(rank, world)
+    idx_w, w_w, rows_w = ordered_tables(idx64, w64, tgt_grid, lo_w, hi_w, np_dtype, dev, natural=layout != COLUMNS or args.natural_order)
+    outs = [Stack.empty(hi_w - lo_w, args.levels, tdtype, dev, layout) for _ in stacks]
+
+    def weak_step():  # rounds 1-4's step: one launch over the N stacks (atx_regrid_ell_batch / _ordered: grid.y = stack)
+        if len(stacks) == 1 or layout != COLUMNS:
+            for s_, o_ in zip(stacks, outs):
+                native.regrid_ell(s_.data, o_.data, idx_w, w_w, n_src=n_src, n_tgt=hi_w - lo_w, k=args.k, n_lev=args.levels, src_pitch=s_.pitch,
+                                  out_pitch=o_.pitch, layout=layout, tgt_rows=rows_w)
+        else:
+            native.regrid_ell_batch([s.data for s in stacks], [o.data for o in outs], idx_w, w_w, n_src=n_src, n_tgt=hi_w - lo_w,
+                                    k=args.k, n_lev=args.levels, src_pitch=stacks[0].pitch, out_pitch=outs[0].pitch, layout=layout, tgt_rows=rows_w)
 
     # ---- weak scaling (rounds 1-4's `value`): N stacks per step, every rank its 1/N target slice of ALL of them in one batched launch.
     #      Per-GPU work is that of the N = 1 job, so this approaches N x by construction; it also leaves in `outs` this rank's slice of
@@ -809,7 +821,7 @@ def multi_gpu_lines(args, result, dist, rank, world, dev, plan, stacks, outs, la
 def single_gpu_lines(args, result, dev, stacks, outs, launch, idx_d, w_d, rows_d, idx64, w64, n_src, n_tgt, n_unique, alg, src_grid, tgt_grid,
                      tdtype, np_dtype, itemsize, plan):
     from anemoi_transform_amd import interp, native
-    from anemoi_transform_amd.gather import GatherPlan
+    from anemoi_transform_amd.gather import TARGET_COST_SHORT_LAUNCH, GatherPlan
     from anemoi_transform_amd.grids import lookup
     from anemoi_transform_amd.stack import COLUMNS, FIELDS, Stack
 
@@ -896,7 +908,7 @@ def single_gpu_lines(args, result, dev, stacks, outs, launch, idx_d, w_d, rows_d
         base_ms = result["roofline"]["avg_launch_ms"]
         series = {}
         for parts in (2, 4, 8):
-            cuts = plan.bounds(parts)
+            cuts = plan.bounds(parts, target_cost=TARGET_COST_SHORT_LAUNCH)  # the cut the N-rank headline uses
             ms_each = []
             for r in range(parts):
                 a, b = cuts[r], cuts[r + 1]
@@ -910,6 +922,7 @@ def single_gpu_lines(args, result, dev, stacks, outs, launch, idx_d, w_d, rows_d
             series[str(parts)] = {"shard_ms": ms_each, "targets": [cuts[r + 1] - cuts[r] for r in range(parts)], "slowest_ms": slowest,
                                   "speedup_bound": base_ms / slowest, "value_bound": n_tgt * n_lev / (slowest * 1e-3)}
         extras["strong_scaling_shards_on_one_gpu"] = dict(series, n1_launch_ms=base_ms,
+            target_cost=TARGET_COST_SHORT_LAUNCH,
             note="each rank's shard of the N-rank headline step timed alone on this GPU (HIP events, 20 launches); speedup_bound = n1_launch_ms / slowest shard")
 
     # the one-off index build on the device instead of cKDTree: raw kernel order, and with equidistant candidates settled by
