@@ -52,10 +52,24 @@ __device__ __forceinline__ bool sincos_moderate(double x, double& sn, double& cs
     const double z = y0 * y0;
     // sin on [-pi/4, pi/4]
     const double v = z * y0;
+    // (round 5: the two kernel polynomials by Horner steps with the coefficient in scalar registers — fma_k, atx_common.hpp; a fused step
+    // rounds once where fdlibm's multiply and add round twice, so the results may differ from round 3's in the last bit and stay within
+    // the same 1 ulp of the true value; ATX_FMA_SGPR=0 + ATX_SINCOS_FMA=0 give round 3's instruction stream)
+#ifndef ATX_SINCOS_FMA
+#define ATX_SINCOS_FMA 1
+#endif
+#if ATX_SINCOS_FMA
+    const double rs = fma_k(z, fma_k(z, fma_k(z, fma_k(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08), 2.75573137070700676789e-06), -1.98412698298579493134e-04), 8.33333333332248946124e-03);
+#else
     const double rs = 8.33333333332248946124e-03 + z * (-1.98412698298579493134e-04 + z * (2.75573137070700676789e-06 + z * (-2.50507602534068634195e-08 + z * 1.58969099521155010221e-10)));
+#endif
     const double s = y0 - ((z * (0.5 * y1 - v * rs) - y1) - v * -1.66666666666666324348e-01);
     // cos on [-pi/4, pi/4]
+#if ATX_SINCOS_FMA
+    const double rc = z * fma_k(z, fma_k(z, fma_k(z, fma_k(z, fma_k(z, -1.13596475577881948265e-11, 2.08757232129817482790e-09), -2.75573143513906633035e-07), 2.48015872894767294178e-05), -1.38888888888741095749e-03), 4.16666666666666019037e-02);
+#else
     const double rc = z * (4.16666666666666019037e-02 + z * (-1.38888888888741095749e-03 + z * (2.48015872894767294178e-05 + z * (-2.75573143513906633035e-07 + z * (2.08757232129817482790e-09 + z * -1.13596475577881948265e-11)))));
+#endif
     const int iy = __double2hiint(y0) & 0x7fffffff;
     double c;
     if (iy < 0x3FD33333) {  // |y0| < 0.3

@@ -228,6 +228,18 @@ def mirror_multi_gpu_into_config(result: dict) -> None:
     }
 
 
+def carried_traffic(key: str) -> dict | None:
+    """The PMC record of one launch shape from profiles/traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of tools/pmc_probe.py,
+    calibrated on atx_stream_copy) — measured under the profiler in its own run, CARRIED here, never measured by this process."""
+    try:
+        rec = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))[key]
+    except Exception:  # noqa: BLE001 - absent file or key: nothing to carry
+        return None
+    return {"hbm_bytes_per_launch": rec["hbm_bytes_per_launch"], "algorithmic_bytes_per_launch": rec["algorithmic_bytes_per_launch"],
+            "traffic_over_algorithmic": rec["traffic_over_algorithmic"], "measured": rec.get("measured"),
+            "source": f"carried from profiles/traffic.json[{key!r}] (tools/pmc_probe.py under rocprofv3 --pmc), not re-measured in this run"}
+
+
 def line(n_units, ms, alg_bytes):
     gbs = alg_bytes / (ms * 1e-3) / 1e9
     return {"value": n_units / (ms * 1e-3), "avg_launch_ms": ms, "achieved_GBs": gbs, "frac": gbs / HBM_PEAK_GBS}
@@ -1017,6 +1029,11 @@ def single_gpu_lines(args, result, dev, stacks, outs, launch, idx_d, w_d, rows_d
     # ---- BASELINE configs[3]: O1280 -> N320-sized, 6 variables x 137 levels x 4 timesteps = 24 stacks, 8 target shards
     try:
         extras["config4"] = config4_lines(args, dev, torch.float32, np.float32, 4)  # float32 as SURVEY.md §8d sizes it (86.8 GB resident)
+        if args.levels == 137:
+            extras["config4"]["traffic"] = {
+                "slowest_shard_24_stacks_of_137": carried_traffic("config4 o1280->n320-sized k=4 24x137 levels f32 columns shard 7 of 8"),
+                "slowest_shard_4_stacks_of_822": carried_traffic("config4 o1280->n320-sized k=4 4x822 levels f32 columns shard 7 of 8"),
+                "all_targets_4_stacks_of_822": carried_traffic("config4 o1280->n320-sized k=4 4x822 levels f32 columns all targets")}
     except Exception as e:
         extras["config4"] = {"error": f"{type(e).__name__}: {e}"}
     torch.cuda.empty_cache()
@@ -1039,6 +1056,11 @@ def single_gpu_lines(args, result, dev, stacks, outs, launch, idx_d, w_d, rows_d
                         f"{keep[0].data.numel() * keep[0].data.element_size() / 1e9:.1f} GB resident",
             "regrid_only": line(units, ms_plain, alg5), "fused_chain_one_launch": line(units, ms_fused, alg5)}
         del plain, fused, keep
+        if args.levels == 137 and args.dtype == "f64":
+            extras["config5"]["traffic"] = {
+                "fused_137_levels": carried_traffic("config5 o2560->0.25 k=4 L=137 f64 columns fused regrid|orog_to_z|convert all targets"),
+                "regrid_only_137_levels": carried_traffic("config5 o2560->0.25 k=4 L=137 f64 columns regrid only all targets"),
+                "fused_3x137_levels": carried_traffic("config5 o2560->0.25 k=4 L=411 f64 columns fused regrid|orog_to_z|convert all targets")}
     except Exception as e:
         extras["config5"] = {"error": f"{type(e).__name__}: {e}"}
     torch.cuda.empty_cache()

@@ -31,7 +31,7 @@ from anemoi_transform_amd.fields import (
     new_field_from_latitudes_longitudes,
     new_field_from_numpy,
 )
-from anemoi_transform_amd.gather import GatherPlan, equal_count_bounds
+from anemoi_transform_amd.gather import TARGET_COST, TARGET_COST_SHORT_LAUNCH, GatherPlan, equal_count_bounds
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 GOLDEN = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "reference_vectors.json")))
@@ -629,6 +629,32 @@ def test_shard_bounds_invariants_on_random_plans(monkeypatch):
         full = plan.apply(x).numpy()
         parts = [plan.shard(r, world).apply(x).numpy() for r in range(world)]
         assert np.array_equal(np.concatenate(parts, axis=1), full, equal_nan=True), (case, kind, world)
+        # the same with another weight of the cost model (bench.py cuts its one-short-launch-per-rank step with TARGET_COST_SHORT_LAUNCH):
+        # its own cut, remembered beside the default one, same invariants, same bits
+        heavy = plan.bounds(world, target_cost=TARGET_COST_SHORT_LAUNCH)
+        assert len(heavy) == world + 1 and heavy[0] == 0 and heavy[-1] == n_tgt and all(x_ <= y_ for x_, y_ in zip(heavy, heavy[1:]))
+        assert plan.bounds(world) == b and plan.bounds(world, target_cost=TARGET_COST) == b  # the default cut is untouched
+        assert [plan.shard_range(r, world, TARGET_COST_SHORT_LAUNCH) for r in range(world)] == list(zip(heavy[:-1], heavy[1:]))
+        parts = [plan.shard(r, world, TARGET_COST_SHORT_LAUNCH).apply(x).numpy() for r in range(world)]
+        assert [p.shape[1] for p in parts] == [hi - lo for lo, hi in zip(heavy[:-1], heavy[1:])]
+        assert np.array_equal(np.concatenate(parts, axis=1), full, equal_nan=True), (case, kind, world)
+
+
+def test_a_heavier_target_weight_moves_targets_away_from_the_shards_that_share_sources():
+    """On a lat-lon target the polar shards read few source columns for many targets: the heavier a target weighs in the cost model,
+    the fewer targets they get (the cut bench.py uses for its strong-scaling step; gather.TARGET_COST_SHORT_LAUNCH)."""
+    from anemoi_transform_amd.grids import lookup
+    from anemoi_transform_amd.interp import knn_inverse_distance
+
+    src, tgt = lookup("o48"), lookup([2.0, 2.0])
+    idx, w = knn_inverse_distance(src, tgt, k=4)
+    plan = GatherPlan(len(src["latitudes"]), len(tgt["latitudes"]), index=idx, weights=w)
+    light, heavy = plan.bounds(8, target_cost=0.2), plan.bounds(8, target_cost=3.0)
+    size = lambda b, r: b[r + 1] - b[r]  # noqa: E731
+    assert size(heavy, 0) < size(light, 0) and size(heavy, 7) < size(light, 7)  # polar shards shrink
+    assert size(heavy, 3) > size(light, 3) and size(heavy, 4) > size(light, 4)  # equatorial ones grow
+    default = plan.bounds(8)
+    assert size(light, 0) > size(default, 0) > size(plan.bounds(8, target_cost=TARGET_COST_SHORT_LAUNCH), 0) > size(heavy, 0)
 
 
 def test_widths_between_the_compile_time_forms_are_padded(monkeypatch):

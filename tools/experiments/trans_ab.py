@@ -71,6 +71,10 @@ def main():
             ckw = dict(n_pts=n, n_lev=L, pitch=x.pitch, layout=COLUMNS)
             cases[f"snow_cover regions {tag}"] = (lambda sd=sd, rsn=rsn, z=z, ckw=ckw: native.combine_stack(native.COMB_SNOW_COVER, [sd.data, rsn.data], [z.data], **ckw), 3 * nb, z)
             cases[f"snow_cover thin cover everywhere {tag}"] = (lambda sd=sd_thin, rsn=rsn, z=z, ckw=ckw: native.combine_stack(native.COMB_SNOW_COVER, [sd.data, rsn.data], [z.data], **ckw), 3 * nb, z)
+            ang = x.new_like()
+            ang.data[:, :L] = ((torch.rand(n, L, device=dev, dtype=torch.float64) * 2.0 - 1.0) * 6.283185307179586).to(tdt)  # wave directions / phases in [-2 pi, 2 pi]
+            z2 = x.new_like()
+            cases[f"cos_sin {tag}"] = (lambda a=ang, z=z, z2=z2, ckw=ckw: native.combine_stack(native.COMB_COS_SIN, [a.data], [z.data, z2.data], **ckw), 3 * nb, z)
             cases[f"difference {tag}"] = (lambda a=x, b=rsn, z=z, ckw=ckw: native.combine_stack(native.COMB_SUB, [a.data, b.data], [z.data], **ckw), 3 * nb, z)
 
     def time_once(fn, reps=8):
