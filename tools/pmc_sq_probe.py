@@ -19,6 +19,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 CASES = ["difference f64", "cos_sin f64", "snow_cover f64 thin cover everywhere (tanh on every element)", "snow_cover f64 snow in regions",
+         "pointwise affine f64", "pointwise log f64 (sp_to_lnsp)", "pointwise exp f64 (lnsp_to_sp)", "pointwise log then exp f64 (one two-stage program)",
          "difference f32", "cos_sin f32", "snow_cover f32 thin cover everywhere"]
 
 
@@ -26,7 +27,7 @@ def summarize(directory: str) -> None:
     rows = []
     for path in glob.glob(os.path.join(directory, "**", "*_counter_collection.csv"), recursive=True):
         with open(path, newline="") as f:
-            rows += [r for r in csv.DictReader(f) if "combine_kernel" in r["Kernel_Name"]]
+            rows += [r for r in csv.DictReader(f) if "combine_kernel" in r["Kernel_Name"] or "pointwise_cols_uniform_kernel" in r["Kernel_Name"]]
     # dispatches in launch order; every case was launched REPS times in a row
     by_dispatch: dict[int, dict] = {}
     for r in rows:
@@ -80,6 +81,13 @@ def main():
                  lambda: native.combine_stack(native.COMB_SNOW_COVER, [sd_thin, rsn], [y], **kw)]
         if tdt == torch.float64:
             cases.append(lambda: native.combine_stack(native.COMB_SNOW_COVER, [sd_regions, rsn], [y], **kw))
+            # round 5: the per-point programs with library functions (x: K-like, positive; q: |q| <= 3.14 as an argument of exp)
+            pkw = dict(n_pts=n, n_lev=L, x_pitch=pitch, y_pitch=pitch, layout=COLUMNS)
+            progs = [([(native.OP_AFFINE, 1.0, -273.15)], x), ([(native.OP_LOG, 0.0, 0.0)], x), ([(native.OP_EXP, 0.0, 0.0)], q),
+                     ([(native.OP_LOG, 0.0, 0.0), (native.OP_EXP, 0.0, 0.0)], x)]
+            for ops, src in progs:
+                prog = native.level_program([[(op, 0, a, b)] * L for op, a, b in ops], dev)
+                cases.append(lambda prog=prog, ns=len(ops), src=src: native.pointwise_stack(src, y, prog=prog, n_stage=ns, **pkw))
         for fn in cases:
             for _ in range(args.reps):
                 fn()
