@@ -128,6 +128,28 @@ def test_two_ranks_rehearsal_over_gloo():
     assert d["config"]["multi_gpu"]["config4"]["value"] == d["config4"]["value"] and d["config"]["multi_gpu"]["config5"]["value"] == d["config5"]["value"]
 
 
+def test_four_ranks_rehearsal_over_gloo():
+    """The same line at world 4 (four ranks sharing the test box's GPU over gloo — within the six processes a box allows on its card): the
+    strong-scaling headline, the weak line with four stacks per step, every exchange verified bit-equal between four ranks — what the
+    first real N = 4 run prints, minus the speed."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "4", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "4", *SMALL, "--backend", "gloo", "--share-device"]
+    run = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert run.returncode == 0, run.stderr[-2000:]
+    d = last_json(run.stdout)
+    assert KEYS <= set(d) and d["n_gpus"] == 4 and d["scaling"] == "strong" and d["value"] > 0
+    assert d["config"]["stacks_per_step"] == 1 and d["weak"]["stacks_per_step"] == 4
+    for kind in ("broadcast", "all_gather", "bands"):
+        assert d["source_exchange"][kind]["verified_bit_equal"] is True, kind
+    assert d["end_to_end"]["verified_bit_equal"] is True and d["end_to_end_bands"]["verified_bit_equal"] is True
+    assert d["end_to_end_all_gather"]["verified_bit_equal"] is True
+    assert d["config4"]["value"] > 0 and d["config5"]["value"] > 0 and "secondary_timed_out_in" not in d
+    assert_mirrored(d)
+
+
 def test_secondary_lines_cannot_cost_the_value():
     """A stuck secondary section (budget of 0 seconds: the watchdog fires at once) still yields the ONE JSON line with `value`."""
     with socket.socket() as s:
