@@ -40,7 +40,10 @@ def main():
                     help="ell: fixed k (--k); csr34 / csr916: general CSR with ragged rows of 3-4 / 9-16 entries; box: O1280 -> 1 degree box averages (~100 per row)")
     ap.add_argument("--ordered", action="store_true", help="ell only: visit the targets in column blocks (atx_regrid_ell_ordered)")
     ap.add_argument("--chunk", type=int, default=0, help="ell only: one launch per chunk of this many levels (the level-chunk-major traversal, emulated)")
-    ap.add_argument("--shard", type=int, default=-1, help="config4 / config5: time this one of the 8 traffic-balanced target shards (-1: all targets)")
+    ap.add_argument("--shard", type=int, default=-1, help="config4 / config5: time this one of the 8 traffic-balanced target shards (-1: all targets); "
+                                                          "ell with --world: this rank's shard of the strong-scaling step")
+    ap.add_argument("--world", type=int, default=1, help="ell only: the headline launch of rank --shard (default 0) of a --world-rank run, cut as bench.py cuts it "
+                                                         "(GatherPlan.bounds(world, TARGET_COST_SHORT_LAUNCH)); recorded under the bench's traffic key `... gpus=<world>`")
     ap.add_argument("--tall", action="store_true", help="config4: 4 stacks of 6 x 137 levels (the variables of a point share a column) instead of 24 x 137; "
                                                         "config5: one stack of 3 x 137 levels instead of 137")
     ap.add_argument("--plain", action="store_true", help="config5: the gather alone instead of the fused regrid | orog_to_z | convert launch")
@@ -65,6 +68,13 @@ def main():
     src_grid, tgt_grid = lookup("o1280"), lookup("0.25")
     n_src, n_tgt = len(src_grid["latitudes"]), len(tgt_grid["latitudes"])
     idx64, w64 = knn_inverse_distance(src_grid, tgt_grid, k=args.k)
+    if args.world > 1:  # one rank's shard of the strong-scaling step (bench.py's headline at N > 1)
+        assert args.case == "ell" and args.layout == "columns" and not args.ordered and args.chunk <= 0
+        from anemoi_transform_amd.gather import TARGET_COST_SHORT_LAUNCH, GatherPlan
+
+        cut = GatherPlan(n_src, n_tgt, index=idx64, weights=w64).bounds(args.world, target_cost=TARGET_COST_SHORT_LAUNCH)
+        lo, hi = cut[max(args.shard, 0)], cut[max(args.shard, 0) + 1]
+        idx64, w64, n_tgt = idx64[lo:hi], w64[lo:hi], hi - lo
     idx = torch.from_numpy(idx64.astype(np.int32)).to(dev)
     w = torch.from_numpy(w64.astype(npdt)).to(dev) if args.k > 1 else None
     src = bench.synth_stack(src_grid, args.levels, tdtype, dev, 0, COLUMNS)
@@ -97,7 +107,7 @@ def main():
 
     kernel = "regrid_fields_ell_kernel" if args.layout == "fields" else ("regrid_cols_ell_direct_kernel" if args.k <= 4 else "regrid_cols_ell_kernel")
     alg = bench.algorithmic_bytes(args.levels, itemsize, int(np.unique(idx64).size), n_tgt, args.k)
-    config = f"o1280->0.25 k={args.k} L={args.levels} {args.dtype} {args.layout} gpus=1"
+    config = f"o1280->0.25 k={args.k} L={args.levels} {args.dtype} {args.layout} gpus={args.world}" + (f" rank {args.shard}" if args.world > 1 and args.shard > 0 else "")
     if args.case == "ell":
         per16 = 16 // itemsize
         chunk = args.levels if args.chunk <= 0 else (args.chunk + per16 - 1) // per16 * per16
