@@ -137,6 +137,16 @@ __device__ __forceinline__ double quotient_1ulp(double a, double b) {
     return __builtin_fma(__builtin_fma(-b, q, a), r, q);
 }
 
+// The same quotient in 6 instructions: the raw reciprocal (2^-23 relative: "2^29 ulp" in the ISA manual) and TWO corrections of the quotient with
+// its exact residual — relative error 2^-23 -> 2^-46 -> below one rounding.  (quotient_1ulp refines the reciprocal first, which tanh's
+// e / (e + 2) keeps: there the same reciprocal error would enter a result that has no other slack.)
+__device__ __forceinline__ double quotient_2fix(double a, double b) {
+    const double r = __builtin_amdgcn_rcp(b);
+    double q = a * r;
+    q = __builtin_fma(__builtin_fma(-b, q, a), r, q);
+    return __builtin_fma(__builtin_fma(-b, q, a), r, q);
+}
+
 // Natural logarithm for the per-level operator ATX_OP_LOG (sp_to_lnsp, R: filters/fields/lnsp_to_sp.py:65).  float32: the device
 // library's.  float64: the classic argument reduction x = 2^k * m, m in [sqrt(2)/2, sqrt(2)), log(m) = f - (f^2/2 - s*(f^2/2 + R(s^2)))
 // with s = f / (2 + f), f = m - 1 and a degree-14 minimax R (the published fdlibm coefficients) — the device library's double log
@@ -146,7 +156,7 @@ __device__ __forceinline__ double quotient_1ulp(double a, double b) {
 //   ATX_FAST_LOG=2 (round 5, default): the hardware's v_frexp_mant / v_frexp_exp (subnormals included) instead of the integer
 //     sequence, quotient_1ulp instead of the IEEE division, R by Horner in s^2 and the combination with fused multiply-adds,
 //     the special operands (0, negative, inf, NaN) behind ONE v_cmp_class and a branch no wave of real data takes:
-//     ~33 instructions per element (tools/kernel_isa.py).  Measured <= 1 ulp from numpy's (true error <= 0.73 ulp against
+//     31 instructions per element (tools/kernel_isa.py).  Measured <= 1 ulp from numpy's (true error <= 0.73 ulp against
 //     200-bit arithmetic on the host prototype), exact at 1; zero, negatives, infinities and NaN follow IEEE / numpy: -inf, NaN, +inf, NaN.
 //   ATX_FAST_LOG=0: the device library.
 #ifndef ATX_FAST_LOG
@@ -159,13 +169,13 @@ __device__ __forceinline__ double atx_log(double x) {
                                       Lg4 = 2.222219843214978396e-01, Lg5 = 1.818357216161805012e-01, Lg6 = 1.531383769920937332e-01,
                                       Lg7 = 1.479819860511658591e-01;
 #if ATX_FAST_LOG == 2
-    double m = __builtin_amdgcn_frexp_mant(x);  // [0.5, 1), subnormals normalised by the instruction
+    const double m = __builtin_amdgcn_frexp_mant(x);  // [0.5, 1), subnormals normalised by the instruction
     int k = __builtin_amdgcn_frexp_exp(x);
-    const bool low = m < 0.70710678118654752440;  // m in [sqrt(2)/2, sqrt(2))
-    m = __builtin_amdgcn_ldexp(m, low ? 1 : 0);
+    const bool low = m < 0.70710678118654752440;  // bring m into [sqrt(2)/2, sqrt(2)): double it, k - 1
     k -= low ? 1 : 0;
-    const double f = m - 1.0;  // exact
-    const double s = quotient_1ulp(f, 2.0 + f);
+    // f = m' - 1 in ONE instruction: 2.0 and 1.0 differ in their high word only, so the factor is one 32-bit select; the fma is exact
+    const double f = __builtin_fma(m, __hiloint2double(low ? 0x40000000 : 0x3ff00000, 0), -1.0);
+    const double s = quotient_2fix(f, 2.0 + f);
     const double z = s * s;
     const double R = z * fma_k(z, fma_k(z, fma_k(z, fma_k(z, fma_k(z, fma_k(z, Lg7, Lg6), Lg5), Lg4), Lg3), Lg2), Lg1);
     const double hfsq = 0.5 * f * f;
@@ -206,6 +216,45 @@ __device__ __forceinline__ double atx_log(double x) {
     return y;
 #else
     return log(x);
+#endif
+}
+
+// exp for the per-level operator ATX_OP_EXP (lnsp_to_sp, R: filters/fields/lnsp_to_sp.py:47).  float32: the device library's.  float64
+// (ATX_FAST_EXP=1, round 5): x = k ln2 + r with two fused multiply-adds (|r| <= ln2 / 2), exp(r) = 1 + r (1 + r q(r)) with q of degree 9 —
+// a Chebyshev fit of (e^r - 1 - r) / r^2 on the interval, relative error 0.15 x 2^-53 before rounding (derived with 300-bit arithmetic,
+// tools/experiments/exp_polynomial.py) — exact scaling by v_ldexp_f64, which also delivers +inf beyond 709.78 and the subnormal
+// results and 0 below -708.4 with one rounding.  What is left for a branch no wave of real data takes: |x| > 2^50 (the reduction loses k),
+// +-inf, NaN.  18 VALU instructions per element against the device library's 22 (it spends 5 on range checks that ldexp makes
+// unnecessary); <= 1 ulp from numpy's on every range of tests/test_gpu_kernels.py::test_float64_exp_within_one_ulp_of_numpy (true error
+// <= 0.9 ulp on a host prototype against 200-bit arithmetic).  ATX_FAST_EXP=0: the device library.
+#ifndef ATX_FAST_EXP
+#define ATX_FAST_EXP 1
+#endif
+__device__ __forceinline__ float atx_exp(float x) { return exp(x); }
+__device__ __forceinline__ double atx_exp(double x) {
+#if ATX_FAST_EXP
+    constexpr double log2e = 1.4426950408889634, ln2hi = 6.93147180559945286227e-01, ln2lo = 2.31904681384629955842e-17;
+    const double k = __builtin_rint(x * log2e);
+    double r = __builtin_fma(-k, ln2hi, x);
+    r = __builtin_fma(-k, ln2lo, r);
+    double q = 0x1.af38d53857513p-26;
+    q = fma_k(q, r, 0x1.2891a8c1d838dp-22);
+    q = fma_k(q, r, 0x1.71de0d9c145d0p-19);
+    q = fma_k(q, r, 0x1.a019b8ef67c6cp-16);
+    q = fma_k(q, r, 0x1.a01a01a7c8d47p-13);
+    q = fma_k(q, r, 0x1.6c16c17893833p-10);
+    q = fma_k(q, r, 0x1.11111111109adp-7);
+    q = fma_k(q, r, 0x1.5555555553d4fp-5);
+    q = fma_k(q, r, 0x1.5555555555556p-3);
+    q = fma_k(q, r, 0x1.0000000000001p-1);
+    const double p = __builtin_fma(r, __builtin_fma(r, q, 1.0), 1.0);
+    double y = __builtin_amdgcn_ldexp(p, (int)k);  // (int) saturates: an enormous k still means +inf or 0
+    if (!(__builtin_fabs(x) <= 1125899906842624.0)) {  // 2^50; NaN fails the comparison too
+        y = (x != x) ? x : (x > 0.0 ? __longlong_as_double(0x7ff0000000000000ll) : 0.0);
+    }
+    return y;
+#else
+    return exp(x);
 #endif
 }
 
@@ -284,7 +333,7 @@ __device__ __forceinline__ T apply_level_op(const LevelOp<T>& o, T x, bool maske
             break;
         case ATX_OP_IMPUTE_NAN: y = (x != x) ? o.p0 : x; break;
         case ATX_OP_EXP:
-            if constexpr (TRANS) y = exp(x);
+            if constexpr (TRANS) y = atx_exp(x);
             break;
         case ATX_OP_LOG:
             if constexpr (TRANS) y = atx_log(x);
@@ -336,7 +385,7 @@ __device__ __forceinline__ void apply_level_op_vec(const LevelOp<T>& o, Pack<T, 
         case ATX_OP_EXP:
             if constexpr (TRANS) {
 #pragma unroll
-                for (int e = 0; e < VEC; ++e) v.v[e] = exp(v.v[e]);
+                for (int e = 0; e < VEC; ++e) v.v[e] = atx_exp(v.v[e]);
             }
             break;
         case ATX_OP_LOG:
@@ -396,7 +445,7 @@ __device__ __forceinline__ void apply_level_op_params(int op, bool use_mask, con
         case ATX_OP_EXP:
             if constexpr (TRANS) {
 #pragma unroll
-                for (int e = 0; e < VEC; ++e) v.v[e] = exp(v.v[e]);
+                for (int e = 0; e < VEC; ++e) v.v[e] = atx_exp(v.v[e]);
             }
             break;
         case ATX_OP_LOG:

@@ -154,7 +154,7 @@ def main():
                "per-level tables: LDS kernel (f32 out of place), typed no-loop kernel (f64)")
         pe = native.level_program([[(native.OP_LOG, 0, 0.0, 0.0)] * L, [(native.OP_EXP, 0, 0.0, 0.0)] * L], dev)
         record(f"pointwise log then exp (sp_to_lnsp | lnsp_to_sp) {tag} out-of-place", timeit(lambda: native.pointwise_stack(x.data, y.data, prog=pe, n_stage=2, **kw)), 2 * stack_bytes,
-               "log (the library's own, atx_common.hpp) and exp (the device library's) on every element")
+               "log and exp (the library's own routines in float64, atx_common.hpp) on every element")
         pm = (torch.rand(n_src + 8, device=dev) < 0.3).to(torch.uint8)
         pmask = native.level_program([[(native.OP_COPY, 1, 0.0, 0.0)] * L], dev)
         record(f"apply_mask {tag}", timeit(lambda: native.pointwise_stack(x.data, y.data, prog=pmask, n_stage=1, point_mask=pm, **kw)), 2 * stack_bytes + n_src)
