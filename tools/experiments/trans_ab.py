@@ -75,6 +75,8 @@ def main():
             ang.data[:, :L] = ((torch.rand(n, L, device=dev, dtype=torch.float64) * 2.0 - 1.0) * 6.283185307179586).to(tdt)  # wave directions / phases in [-2 pi, 2 pi]
             z2 = x.new_like()
             cases[f"cos_sin {tag}"] = (lambda a=ang, z=z, z2=z2, ckw=ckw: native.combine_stack(native.COMB_COS_SIN, [a.data], [z.data, z2.data], **ckw), 3 * nb, z)
+            cases[f"atan2 (cos, sin -> direction) {tag}"] = (lambda a=x, b=rsn, z=z, ckw=ckw: native.combine_stack(native.COMB_ATAN2, [a.data, b.data], [z.data], **ckw), 3 * nb, z)
+            cases[f"atan2 in degrees, wrapped to [0, 360) {tag}"] = (lambda a=x, b=rsn, z=z, ckw=ckw: native.combine_stack(native.COMB_ATAN2, [a.data, b.data], [z.data], flags=native.COMB_DEGREES, **ckw), 3 * nb, z)
             cases[f"difference {tag}"] = (lambda a=x, b=rsn, z=z, ckw=ckw: native.combine_stack(native.COMB_SUB, [a.data, b.data], [z.data], **ckw), 3 * nb, z)
 
     def time_once(fn, reps=8):
