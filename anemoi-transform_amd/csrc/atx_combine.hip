@@ -160,7 +160,9 @@ __device__ __forceinline__ void combine_one(int flags, const T* x, int n_in, T l
             const T tmp1 = (T(1000) * x[0]) / x[1];
             // np.clip(rsn, 100, 400) as one max and one min: a NaN density — which np.clip would keep — has made tmp1, and with it arg, a
             // NaN already, so the hardware's "the other operand" for a NaN changes nothing (6 compare-and-select instructions -> 2-4)
-            const T tmp2 = __builtin_fmin(__builtin_fmax(x[1], T(100)), T(400));
+            T tmp2;
+            if constexpr (sizeof(T) == 4) tmp2 = __builtin_fminf(__builtin_fmaxf(x[1], 100.0f), 400.0f);  // (the unsuffixed builtins are the float64 ones)
+            else tmp2 = __builtin_fmin(__builtin_fmax(x[1], 100.0), 400.0);
             const T arg = (T(4000) * tmp1) / tmp2;
             // The two common cases need no tanh and give the statement's bits exactly: deep snow — every arg > atanh(0.99) =
             // 2.6467 has tanh(arg) > 0.99 (at 2.65: 0.990066, four orders above any rounding of tanh), which the last line

@@ -111,7 +111,8 @@ __device__ __forceinline__ double quiet_nan<double>() {
 // fma(a, b, c) with c a compile-time constant held in SCALAR registers (v_fma_f64 v, v, v, s[..]).  Left to itself the compiler keeps the
 // coefficients of a float64 polynomial in vector registers and evaluates Horner steps with the two-address v_fmac_f64, which overwrites
 // its addend — so every step of every element first COPIES its coefficient (v_mov_b64): 12 extra instructions in a degree-13 Horner chain,
-// a third of it.  ATX_FMA_SGPR=0 restores __builtin_fma.
+// a third of it.  `c` MUST be a compile-time constant (the "s" constraint would otherwise take the first lane's value for the whole wave).
+// ATX_FMA_SGPR=0 restores __builtin_fma.
 #ifndef ATX_FMA_SGPR
 #define ATX_FMA_SGPR 1
 #endif
