@@ -109,6 +109,38 @@ def test_headline_float64_through_the_plugin_api(case64, tmp_path):
         assert got.dtype == np.float64 and np.array_equal(got, want), l  # scipy's bits through Filter.forward()
 
 
+def test_headline_meets_the_north_star_roofline_target(case64, dev):
+    """BASELINE.json north_star: ">= 60 % of per-GPU HBM3E bandwidth on O1280 -> 0.25 degree 137-level regrid at 1 GPU" — the headline
+    launch (float64, k = 4) and the k = 1 gather on the same stack, priced as bench.py prices them: SURVEY.md §8d's algorithmic bytes over
+    the average HIP-event duration of single launches against 8 TB/s.  Measured 0.70-0.71 and 0.72 on every box of rounds 2-5; the
+    floor asserted is the target itself."""
+    n_src, n_tgt, x = case64["n_src"], case64["n_tgt"], case64["x"]
+    out = Stack.empty(n_tgt, N_LEV, torch.float64, dev, COLUMNS)
+    idx_d = torch.from_numpy(case64["idx"].astype(np.int32)).to(dev)
+    w_d = torch.from_numpy(case64["w"]).to(dev)
+    idx1_d = torch.from_numpy(np.ascontiguousarray(case64["idx"][:, 0]).astype(np.int32)).to(dev)
+
+    def frac(fn, k, n_unique):
+        for _ in range(5):
+            fn()
+        torch.cuda.synchronize()
+        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(20)]
+        for a, b in evs:
+            a.record()
+            fn()
+            b.record()
+        torch.cuda.synchronize()
+        ms = float(np.mean([a.elapsed_time(b) for a, b in evs]))
+        alg = N_LEV * 8 * (n_unique + n_tgt) + n_tgt * k * 4 + (n_tgt * k * 8 if k > 1 else 0)
+        return alg / (ms * 1e-3) / 8.0e12
+
+    kw = dict(n_src=n_src, n_tgt=n_tgt, n_lev=N_LEV, src_pitch=x.pitch, out_pitch=out.pitch, layout=COLUMNS)
+    k4 = frac(lambda: native.regrid_ell(x.data, out.data, idx_d, w_d, k=4, **kw), 4, int(np.unique(case64["idx"]).size))
+    k1 = frac(lambda: native.regrid_ell(x.data, out.data, idx1_d, None, k=1, **kw), 1, int(np.unique(case64["idx"][:, 0]).size))
+    assert k4 >= 0.60, f"headline at {k4:.3f} of the HBM peak"
+    assert k1 >= 0.60, f"k = 1 gather at {k1:.3f} of the HBM peak"
+
+
 def test_headline_float64_nearest_is_a_bit_copy(case64):
     """R: regrid.py:380 `x[..., nearest_grid_points]` at full size in float64 (the `extras.nearest_k1` launch of the bench)."""
     nearest = np.ascontiguousarray(case64["idx"][:, 0])
