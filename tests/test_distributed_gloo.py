@@ -116,9 +116,10 @@ def _worker(rank: int, world: int, port: int, kind: str, tmpdir: str) -> None:
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("kind,world", [("ell", 2), ("csr", 2), ("ell", 3)])
+@pytest.mark.parametrize("kind,world", [("ell", 2), ("csr", 2), ("ell", 3), ("ell", 8)])
 def test_target_sharded_regrid(tmp_path, kind, world):
     """World 2 for both plan kinds; world 3 as well: the double-buffered step then re-uses a receive buffer (stack r + 1 may get
-    the block of stack r - 1) and every rank has two peers in the band exchange."""
+    the block of stack r - 1) and every rank has two peers in the band exchange; world 8 — the node size north_star names: eight shards,
+    seven peers per rank in the band exchange, eight broadcasts in the double-buffered step."""
     mp.spawn(_worker, args=(world, _free_port(), kind, str(tmp_path)), nprocs=world, join=True)
     assert all((tmp_path / f"ok{r}").exists() for r in range(world))
