@@ -1,5 +1,6 @@
 # Evidence batch of round 5 (run on the MI355X box through gpurun): files land in gpurun_out/, the ones to keep are copied to profiles/.
-#   bash tools/r05_evidence.sh [bench|pmc|all]
+#   bash tools/r05_evidence.sh [bench|pmc|around|all]      (around: tools/r05_around.sh — rocprofv3 summary of the per-kernel table, host-fed job, Filter.forward() wall times;
+#                                                          SQ counters: tools/r05_sq_run.sh; A/B of library builds: tools/experiments/trans_ab.py)
 set -e
 R=$GRAFT_REPO_ROOT
 cd $R
@@ -27,4 +28,7 @@ if [ "$WHAT" = "pmc" ] || [ "$WHAT" = "all" ]; then
   bash tools/pmc_run.sh "--case config4 --dtype f32 --shard 7" "--case config4 --dtype f32 --shard 7 --tall" "--case config4 --dtype f32 --tall" \
                         "--case config5 --dtype f64" "--case config5 --dtype f64 --tall" "--case config5 --dtype f64 --plain"
   echo "pmc done"
+fi
+if [ "$WHAT" = "around" ] || [ "$WHAT" = "all" ]; then
+  bash tools/r05_around.sh
 fi
