@@ -404,6 +404,14 @@ def main():
     shard_unique = int(np.unique(idx64[lo:hi]).size)
     alg = algorithmic_bytes(args.levels, itemsize, shard_unique, hi - lo, args.k)
     achieved = alg / (avg_ms * 1e-3) / 1e9
+    # the same figure for the WHOLE job: the algorithmic bytes of all ranks' launches of one step over the step time the driver's value is
+    # computed from (max over ranks, wall clock of the K steps) against N x the peak — "fraction of the HBM roofline at 1, 2, 4, 8 GPUs"
+    alg_all = float(alg)
+    if multi:
+        t_alg = torch.tensor([alg_all], dtype=torch.float64)
+        dist.all_reduce(t_alg, op=dist.ReduceOp.SUM)
+        alg_all = float(t_alg.item())
+    job_gbs = alg_all / (elapsed / args.steps) / 1e9
     traffic, traffic_source = None, None
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tpath):
@@ -470,6 +478,9 @@ def main():
             "median_launch_ms": median_ms,
             "min_launch_ms": min_ms,
             "distinct_source_points": shard_unique,
+            # all ranks together, on the wall clock of the timed region (what `value` is computed from); at N = 1 the launch-gap-inclusive twin of `frac`
+            "job": {"algorithmic_bytes_per_step_all_ranks": alg_all, "achieved": job_gbs, "peak": HBM_PEAK_GBS * world, "unit": "GB/s",
+                    "frac": job_gbs / (HBM_PEAK_GBS * world), "ms_per_step": elapsed / args.steps * 1e3},
         },
         "precompute_s": precompute_s,
     }

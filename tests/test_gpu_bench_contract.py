@@ -39,6 +39,8 @@ def test_single_gpu_line():
     r = d["roofline"]
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
     assert r["min_launch_ms"] <= r["median_launch_ms"] and r["min_launch_ms"] <= r["avg_launch_ms"]  # HIP events around single launches
+    j = r["job"]  # the whole job on the wall clock of the timed region: at N = 1 the same bytes as the launch
+    assert j["algorithmic_bytes_per_step_all_ranks"] == r["algorithmic_bytes_per_launch"] and j["peak"] == 8000.0 and 0 < j["frac"] <= 1.0
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] == 1 and c["value"] > 0 and "sample" in c
     # both reference statements (csr_array @ x, x[..., idx]) in both widths
@@ -112,6 +114,8 @@ def test_two_ranks_rehearsal_over_gloo():
     d = last_json(run.stdout)
     assert KEYS <= set(d) and d["n_gpus"] == 2 and d["scaling"] == "strong" and d["value"] > 0
     assert d["config"]["stacks_per_step"] == 1 and d["config"]["launches_per_step_per_gpu"] == 1 and d["weak"]["stacks_per_step"] == 2
+    j = d["roofline"]["job"]  # both ranks' bytes against 2 x the peak
+    assert j["peak"] == 16000.0 and j["algorithmic_bytes_per_step_all_ranks"] > d["roofline"]["algorithmic_bytes_per_launch"] and j["frac"] > 0
     assert "EXCLUDES the source exchange" in d["config"]["sharding"] and "gloo" in d["config"]["collectives"]
     assert set(d["source_exchange_ms"]) == {"broadcast", "all_gather", "bands"} and all(v > 0 for v in d["source_exchange_ms"].values())
     for kind in ("broadcast", "all_gather", "bands"):
