@@ -56,7 +56,10 @@
 extern "C" {
 #endif
 
-#define ATX_VERSION 410 /* 0.4.1 — eight more multi-input operators (ATX_COMB_OPERA_CLIP .. ATX_COMB_R_TO_Q); nothing else changed.
+#define ATX_VERSION 420 /* 0.4.2 — round 5: no signature, enum or layout changed.  The float64 library functions are the library's own routines now
+                           * (ATX_OP_EXP, ATX_OP_LOG, the tanh of ATX_COMB_SNOW_COVER, the polynomials of ATX_COMB_COS_SIN): results may differ from 0.4.1 in the
+                           * last bit and stay within 1 ulp (exp, log), 2 ulp (cos, sin) and 4 ulp (tanh) of numpy's, as before.
+                           * 0.4.1 — eight more multi-input operators (ATX_COMB_OPERA_CLIP .. ATX_COMB_R_TO_Q); nothing else changed.
                            * 0.4.0 — round 4: atx_vector_program takes the CAPACITY of `out` (ATX_EWORKSPACE when too small — 0.3 wrote its
                            * grown table without asking), atx_reduce* keep the no-atomics route for every shape when given a workspace.
                            * 0.3.0 — round 3: atx_reduce* take a workspace, atx_regrid_*_ordered, two more multi-input operators, and the

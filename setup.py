@@ -23,7 +23,7 @@ class BuildWithHip(build_py):
 
 setup(
     name="anemoi-transform-amd",
-    version="0.4.1",
+    version="0.4.2",
     description="MI355X-native (gfx950 HIP) filter hot path of ecmwf/anemoi-transform",
     packages=["anemoi_transform_amd", "anemoi_transform_amd.filters"],
     package_dir={"anemoi_transform_amd": "anemoi-transform_amd"},

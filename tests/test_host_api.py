@@ -443,7 +443,7 @@ def test_header_is_plain_c_and_links(tmp_path):
 def test_abi_argument_validation_without_a_gpu():
     """Bad arguments are rejected before anything touches HIP, with the reference's exception types."""
     lib = native.load()
-    assert lib.atx_version() == 410
+    assert lib.atx_version() == 420
     assert lib.atx_strerror(native.ESHAPE) == b"shape mismatch"
     assert lib.atx_regrid_ell(None, None, None, None, 1, 1, 1, 1, 1, 1, 0, 0, 0, None, None, None, 0, None, None) == native.EINVAL
     assert b"null" in lib.atx_last_error()
