@@ -497,6 +497,17 @@ def test_float64_log_within_one_ulp_of_numpy(dev):
         "every magnitude": 10.0 ** rng.uniform(-307, 308, n),
         "subnormal": rng.uniform(5e-324, 2.2e-308, n),
     }
+    # where the reduction switches: powers of two and 2^k sqrt(1/2) (the mantissa is doubled below sqrt(1/2)), a few ulp either side, every exponent
+    k = np.arange(-1074, 1024, dtype=np.float64)
+    near = []
+    for base in (np.ldexp(1.0, k.astype(int)), np.ldexp(np.sqrt(0.5), k[k > -1073].astype(int))):
+        for step in (-3, -2, -1, 0, 1, 2, 3):
+            v = base.copy()
+            for _ in range(abs(step)):
+                v = np.nextafter(v, np.inf if step > 0 else 0.0)
+            near.append(v)
+    near = np.concatenate(near)
+    cases["reduction boundaries"] = np.resize(near[near > 0], n)
     special = np.array([1.0, 0.0, -0.0, -1.0, np.inf, -np.inf, np.nan, 5e-324, 2.2250738585072014e-308, 1.7976931348623157e308, 2.0, 0.5, np.e])
 
     def run(x, per_level=False):
@@ -539,6 +550,16 @@ def test_float64_exp_within_one_ulp_of_numpy(dev):
         "every magnitude": rng.uniform(-708.0, 709.0, n),
         "into the subnormals": rng.uniform(-745.0, -708.0, n),
     }
+    # where the reduction switches: x log2(e) next to a half-integer (k = rint(...) ties) and x next to a multiple of ln 2 (r next to 0)
+    m = np.arange(-1074, 1023, dtype=np.float64)  # (results stay finite and above the smallest subnormal: the ulp distance is defined)
+    near = []
+    for base in ((m + 0.5) * np.log(2.0), m * np.log(2.0)):
+        for step in (-2, -1, 0, 1, 2):
+            v = base.copy()
+            for _ in range(abs(step)):
+                v = np.nextafter(v, np.inf if step > 0 else -np.inf)
+            near.append(v)
+    cases["reduction boundaries"] = np.resize(np.concatenate(near), n)
     special = np.array([0.0, -0.0, np.inf, -np.inf, np.nan, 710.0, -746.0, 1.0, -1.0, 709.782712893384, -745.1332191019411, 1e-300, 0.5])
 
     def run(x, per_level=False, stages=(native.OP_EXP,)):
