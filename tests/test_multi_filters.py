@@ -365,6 +365,10 @@ def test_snow_cover_float64_tanh_within_ulps_of_numpy(dev):
     rng = np.random.default_rng(9)
     n = 1 << 18
     arg = np.concatenate([rng.uniform(0.0, 2.65, n // 2), 10.0 ** rng.uniform(-12, 0.4, n // 2)])
+    # next to where the reduction of expm1(2 arg) switches (2 arg log2(e) at a half-integer: k = 0 .. 7) and where its r is next to 0
+    edges = np.concatenate([(np.arange(0, 8) + 0.5) * np.log(2.0) / 2.0, np.arange(1, 8) * np.log(2.0) / 2.0])
+    edges = edges[edges < 2.65]
+    arg[:edges.size * 41] = (edges[:, None] * (1.0 + np.arange(-20, 21)[None, :] * 2.0 ** -51)).reshape(-1)
     rsn = rng.uniform(100.0, 400.0, n)
     sd = arg * rsn * rsn / 4.0e6  # 4000 * (1000 * sd / rsn) / clip(rsn, 100, 400) == arg up to rounding
     want = oracle.snow_cover(sd[None, :].copy(), rsn[None, :].copy())[0]
