@@ -420,6 +420,7 @@ combine_kernel(CombArgs a, int flags, int n_in, int n_out, int64_t n_rows, int64
     constexpr bool kFixedOperands = OP != ATX_COMB_SUM && OP != ATX_COMB_Q_TO_R && OP != ATX_COMB_R_TO_Q;
     constexpr bool kShared1 = OP == ATX_COMB_ORAS6;  // operand 1 is ONE field [n_pts] shared by every level, not a stack
     const bool small_rows = vec_per_row < (1 << 20);  // columns layout: (row, col) from 32-bit arithmetic
+    const float inv_vec_per_row = __builtin_amdgcn_rcpf((float)vec_per_row);
     // a workgroup takes a contiguous run of chunks, not every gridDim.x-th one: under the 65536-workgroup cap the grid stride is a
     // power of two (1 GiB for f64) and drifting workgroups alias onto the same HBM channels (atx_pointwise.hip, ATX_PW_ASSIGN)
 #ifndef ATX_COMB_ASSIGN
@@ -452,8 +453,17 @@ combine_kernel(CombArgs a, int flags, int n_in, int n_out, int64_t n_rows, int64
             if (!ok[u]) continue;
             int64_t row, col;
             if (small_rows) {
+                // (row, column) of the lane's vector from the workgroup's: off < vec_per_row + kBlock * U <= 2^20 + 512.  The quotient through the
+                // float reciprocal — floor((off + 0.5) * rcp(vec_per_row)) — is EXACT there: off + 0.5 lies at least 0.5 / vec_per_row from the
+                // nearest multiple of vec_per_row, and three roundings of 2^-24 (the hardware reciprocal: 2^-23) move the product by at most
+                // (1 + 512.5 / vec_per_row) x 1.8e-7 — smaller for every vec_per_row below 2.8e6 (tests/test_host_api.py checks the arithmetic
+                // over 6 000 divisors with the reciprocal off by an ulp either way).  6 instructions instead of the ~16 of an integer division,
+                // per vector, in every multi-input operator.  ATX_COMB_INT_DIV=1 restores the division.
+#ifndef ATX_COMB_INT_DIV
+#define ATX_COMB_INT_DIV 0
+#endif
                 const int off = col_b + u * kBlock + threadIdx.x;
-                const int dr = off / vec_per_row;
+                const int dr = ATX_COMB_INT_DIV ? off / vec_per_row : (int)(((float)off + 0.5f) * inv_vec_per_row);
                 row = row_b + dr;
                 col = (int64_t)(off - dr * vec_per_row) * VEC;
             } else {

@@ -773,3 +773,21 @@ def test_design_tables_are_generated():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     run = subprocess.run([sys.executable, os.path.join(root, "tools", "design_tables.py"), "--check"], capture_output=True, text=True)
     assert run.returncode == 0, run.stderr
+
+
+def test_row_split_through_the_float_reciprocal_is_exact():
+    """atx_combine.hip splits a lane's vector index into (row, column) with floor((off + 0.5) * rcp(vec_per_row)) in float32 instead of an
+    integer division (off < vec_per_row + 512, vec_per_row < 2^20).  The same arithmetic in numpy float32, with the reciprocal one ulp low,
+    exact and one ulp high (the hardware's v_rcp_f32 is good to an ulp): equal to the integer quotient for every offset of 6 000 divisors —
+    all of 1 .. 2048, the column counts of the stacks in use, random ones up to 2^20."""
+    rng = np.random.default_rng(0)
+    divisors = np.unique(np.concatenate([np.arange(1, 2049), rng.integers(2049, 1 << 20, 4000), [35, 69, 138, 206, (1 << 20) - 1]]))
+    for vpr in divisors:
+        off = np.arange(0, vpr + 513, dtype=np.int64)
+        if off.size > 200_000:  # long rows: both ends, the neighbourhood of the row boundary and a random middle
+            off = np.unique(np.concatenate([off[:50_000], off[-50_000:], vpr + np.arange(-600, 513), rng.integers(0, vpr + 513, 50_000)]))
+        want = off // vpr
+        inv0 = np.float32(1.0) / np.float32(vpr)
+        for inv in (np.nextafter(inv0, np.float32(0)), inv0, np.nextafter(inv0, np.float32(1))):
+            got = ((off.astype(np.float32) + np.float32(0.5)) * inv).astype(np.int64)
+            assert np.array_equal(got, want), (int(vpr), float(inv))
