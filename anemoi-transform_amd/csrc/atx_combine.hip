@@ -126,9 +126,9 @@ __device__ __forceinline__ float quotient(float a, float b) {
 #endif
 }
 template <typename T>
-__device__ __forceinline__ T es_water(T t) { return T(611.21) * exp(quotient(T(17.502) * (t - T(273.16)), t - T(32.19))); }
+__device__ __forceinline__ T es_water(T t) { return T(611.21) * atx_exp(quotient(T(17.502) * (t - T(273.16)), t - T(32.19))); }
 template <typename T>
-__device__ __forceinline__ T es_ice(T t) { return T(611.21) * exp(quotient(T(22.587) * (t - T(273.16)), t - T(-0.7))); }
+__device__ __forceinline__ T es_ice(T t) { return T(611.21) * atx_exp(quotient(T(22.587) * (t - T(273.16)), t - T(-0.7))); }
 template <typename T>
 __device__ __forceinline__ T es_mixed(T t) {
     const T t0 = T(273.16), ti = T(273.16 - 23.0);
