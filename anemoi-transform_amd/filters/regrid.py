@@ -159,6 +159,12 @@ class MIRMatrix(_Interpolator):
         self.plan = _ordered(GatherPlan.from_matrix(loaded), self.out_grid)
 
     def plan_for(self, first_field: Any) -> GatherPlan:
+        # R: regrid.py:310 — `csr_array(...) @ field.to_numpy(flatten=True)`: scipy raises ValueError for a field of the wrong length
+        # (the nearest-neighbour interpolator asserts instead, R: regrid.py:377-378; the mask one raises numpy's IndexError)
+        n = int(np.prod(first_field.shape))
+        if n != self.plan.n_src:
+            raise ValueError(f"matmul: dimension mismatch: the matrix has {self.plan.n_src} columns (shape "
+                             f"({self.plan.n_tgt}, {self.plan.n_src})), the field has {n} points")
         return self.plan
 
     def out_latlon(self, first_field: Any):

@@ -161,6 +161,10 @@ class GatherPlan:
             if n_src is None:
                 raise ValueError("an integer mask needs the number of source points")
             index = mask.reshape(-1)
+            if index.size and index.dtype.kind in "iu" and (int(index.min()) < -n_src or int(index.max()) >= n_src):
+                # R: regrid.py:420 `data[..., self.mask]` — numpy's own error for an index list made for another grid
+                bad = int(index.max()) if int(index.max()) >= n_src else int(index.min())
+                raise IndexError(f"index {bad} is out of bounds for axis 0 with size {n_src}")
             index = np.where(index < 0, index + n_src, index)  # numpy indexing accepts negatives
         return cls(n_src, len(index), index=index)
 

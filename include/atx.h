@@ -52,6 +52,15 @@
 #include <stddef.h>
 #include <stdint.h>
 
+/* The library is built with -fvisibility=hidden: the ATX_API declarations below are its ONLY dynamic symbols
+ * (tests/test_host_api.py checks `nm -D --defined-only` against this header), so nothing of its C++ internals can
+ * interpose, or be interposed by, another library of the process (torch's own HIP libraries, RCCL). */
+#if defined(_WIN32)
+#define ATX_API
+#else
+#define ATX_API __attribute__((visibility("default")))
+#endif
+
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -125,16 +134,16 @@ typedef struct {
 } atx_level_op;
 
 /* ---- library ------------------------------------------------------------- */
-int atx_version(void);
-const char* atx_last_error(void);          /* host string, valid until the next failing call of this thread */
-const char* atx_strerror(int code);        /* host string, static */
+ATX_API int atx_version(void);
+ATX_API const char* atx_last_error(void);          /* host string, valid until the next failing call of this thread */
+ATX_API const char* atx_strerror(int code);        /* host string, static */
 /* Number of HIP devices visible, or a negative ATX_EHIP. */
-int atx_device_count(void);
+ATX_API int atx_device_count(void);
 /* Tuning hook for benchmarks and tests: tile > 0 runs the ATX_COLUMNS regrid through the TILED kernels with that
  * many targets per workgroup; 0 = built-in choice (the direct kernel where it applies, else the tile heuristic).
  * Per CALLING THREAD (thread-local since round 3: the launches of other threads are not affected); results never depend on it,
  * only speed. */
-int atx_set_tuning(int tile);
+ATX_API int atx_set_tuning(int tile);
 
 /* ---- regrid: precomputed index(+weight) gather ---------------------------- */
 
@@ -173,21 +182,21 @@ int atx_set_tuning(int tile);
  *   GatherPlan.apply does by itself).  The per-point entry points run field-major stacks at full speed (0.79-0.84).
  */
 #define ATX_ELL_PADDED 1
-int atx_regrid_ell(const void* src, void* out, const int32_t* idx, const void* w,
-                   int64_t n_src, int64_t n_tgt, int32_t k, int64_t n_lev,
-                   int64_t src_pitch, int64_t out_pitch, int dtype, int layout, int32_t flags,
-                   const atx_level_op* prog, const atx_level_op* vec_prog, const atx_level_op* host_prog,
-                   int32_t n_stage, const uint8_t* tgt_mask, void* stream);
+ATX_API int atx_regrid_ell(const void* src, void* out, const int32_t* idx, const void* w,
+                           int64_t n_src, int64_t n_tgt, int32_t k, int64_t n_lev,
+                           int64_t src_pitch, int64_t out_pitch, int dtype, int layout, int32_t flags,
+                           const atx_level_op* prog, const atx_level_op* vec_prog, const atx_level_op* host_prog,
+                           int32_t n_stage, const uint8_t* tgt_mask, void* stream);
 
 /* atx_regrid_ell applied to n_stack source stacks of identical shape, dtype and pitch with ONE launch per 16 stacks
  * (ATX_COLUMNS: grid.y = stack, no launch gaps or per-launch tails; field-major stacks are launched one after the
  * other).  srcs / outs are HOST arrays of n_stack device pointers; any n_stack >= 1.
  *   R: regrid.py:204-208 — the per-field loop, when the FieldList holds several variables / time steps on one grid
  *      pair (BASELINE config 4), or the N source stacks of a target-sharded multi-GPU step. */
-int atx_regrid_ell_batch(const void* const* srcs, void* const* outs, int32_t n_stack, const int32_t* idx, const void* w,
-                         int64_t n_src, int64_t n_tgt, int32_t k, int64_t n_lev, int64_t src_pitch, int64_t out_pitch,
-                         int dtype, int layout, int32_t flags, const atx_level_op* prog, const atx_level_op* vec_prog,
-                         const atx_level_op* host_prog, int32_t n_stage, const uint8_t* tgt_mask, void* stream);
+ATX_API int atx_regrid_ell_batch(const void* const* srcs, void* const* outs, int32_t n_stack, const int32_t* idx, const void* w,
+                                 int64_t n_src, int64_t n_tgt, int32_t k, int64_t n_lev, int64_t src_pitch, int64_t out_pitch,
+                                 int dtype, int layout, int32_t flags, const atx_level_op* prog, const atx_level_op* vec_prog,
+                                 const atx_level_op* host_prog, int32_t n_stage, const uint8_t* tgt_mask, void* stream);
 
 /* The same with an ORDERED traversal of the targets: row t of idx / w is the table row of OUTPUT row tgt_rows[t] (a permutation
  * of 0 .. n_tgt-1, device int32; tgt_mask stays indexed by output row).  The result is identical to atx_regrid_ell_batch on the
@@ -195,11 +204,11 @@ int atx_regrid_ell_batch(const void* const* srcs, void* const* outs, int32_t n_s
  * in column blocks (each block top to bottom) lets vertically adjacent targets, whose neighbour patches overlap, meet in an XCD's
  * L2.  Measured on O1280 -> 0.25 degree, 137 levels (profiles/r03_column_blocks_experiment.log): k = 16 +9-12 %, k = 8 +5-9 %;
  * k <= 4 is 2-7 % SLOWER (the output rows are then written band by band) — order long rows only.  ATX_COLUMNS only. */
-int atx_regrid_ell_ordered(const void* const* srcs, void* const* outs, int32_t n_stack, const int32_t* idx, const void* w,
-                           const int32_t* tgt_rows, int64_t n_src, int64_t n_tgt, int32_t k, int64_t n_lev, int64_t src_pitch,
-                           int64_t out_pitch, int dtype, int layout, int32_t flags, const atx_level_op* prog,
-                           const atx_level_op* vec_prog, const atx_level_op* host_prog, int32_t n_stage, const uint8_t* tgt_mask,
-                           void* stream);
+ATX_API int atx_regrid_ell_ordered(const void* const* srcs, void* const* outs, int32_t n_stack, const int32_t* idx, const void* w,
+                                   const int32_t* tgt_rows, int64_t n_src, int64_t n_tgt, int32_t k, int64_t n_lev, int64_t src_pitch,
+                                   int64_t out_pitch, int dtype, int layout, int32_t flags, const atx_level_op* prog,
+                                   const atx_level_op* vec_prog, const atx_level_op* host_prog, int32_t n_stage, const uint8_t* tgt_mask,
+                                   void* stream);
 
 /*
  * General CSR interpolation: out[t, l] = sum_{jj in [indptr[t], indptr[t+1])} data[jj] * src[indices[jj], l]
@@ -208,17 +217,17 @@ int atx_regrid_ell_ordered(const void* const* srcs, void* const* outs, int32_t n
  *   R: regrid.py:310
  * indptr int32 [n_tgt+1] (device), indices int32 [nnz], data dtype [nnz].
  */
-int atx_regrid_csr(const void* src, void* out, const int32_t* indptr, const int32_t* indices,
-                   const void* data, int64_t n_src, int64_t n_tgt, int64_t nnz, int64_t n_lev,
-                   int64_t src_pitch, int64_t out_pitch, int dtype, int layout,
-                   const atx_level_op* prog, int32_t n_stage, const uint8_t* tgt_mask,
-                   void* stream);
+ATX_API int atx_regrid_csr(const void* src, void* out, const int32_t* indptr, const int32_t* indices,
+                           const void* data, int64_t n_src, int64_t n_tgt, int64_t nnz, int64_t n_lev,
+                           int64_t src_pitch, int64_t out_pitch, int dtype, int layout,
+                           const atx_level_op* prog, int32_t n_stage, const uint8_t* tgt_mask,
+                           void* stream);
 /* atx_regrid_csr with an ORDERED traversal: CSR row t (indptr[t] .. indptr[t+1]) is the row of OUTPUT point tgt_rows[t] — see
  * atx_regrid_ell_ordered; rows of 9-16 entries gain like k = 16 there.  ATX_COLUMNS only. */
-int atx_regrid_csr_ordered(const void* src, void* out, const int32_t* indptr, const int32_t* indices, const void* data,
-                           const int32_t* tgt_rows, int64_t n_src, int64_t n_tgt, int64_t nnz, int64_t n_lev, int64_t src_pitch,
-                           int64_t out_pitch, int dtype, int layout, const atx_level_op* prog, int32_t n_stage,
-                           const uint8_t* tgt_mask, void* stream);
+ATX_API int atx_regrid_csr_ordered(const void* src, void* out, const int32_t* indptr, const int32_t* indices, const void* data,
+                                   const int32_t* tgt_rows, int64_t n_src, int64_t n_tgt, int64_t nnz, int64_t n_lev, int64_t src_pitch,
+                                   int64_t out_pitch, int dtype, int layout, const atx_level_op* prog, int32_t n_stage,
+                                   const uint8_t* tgt_mask, void* stream);
 
 /* Debugging aid for binders that build their own tables: with ATX_VALIDATE=1 in the environment (read once per process) every
  * atx_regrid_* call first range-checks idx / indices / indptr / tgt_rows on the device and refuses the launch with ATX_EINVAL if an
@@ -228,7 +237,7 @@ int atx_regrid_csr_ordered(const void* src, void* out, const int32_t* indptr, co
 /* Counts entries of idx[0..n) outside [0, n_src) into *n_bad (device int64,
  * zeroed by the call).  cKDTree returns n_src for "no neighbour within
  * distance_upper_bound" (R: spatial.py:630-632) — reject before gathering. */
-int atx_check_indices(const int32_t* idx, int64_t n, int64_t n_src, int64_t* n_bad, void* stream);
+ATX_API int atx_check_indices(const int32_t* idx, int64_t n, int64_t n_src, int64_t* n_bad, void* stream);
 
 /* ---- per-point transforms -------------------------------------------------- */
 
@@ -244,10 +253,10 @@ int atx_check_indices(const int32_t* idx, int64_t n, int64_t n_src, int64_t* n_b
  *      orog_to_z.py:59,77, clipper.py:69, impute_nans.py:53-54, lnsp_to_sp.py:47,65,
  *      apply_mask.py:183-185, glacier_mask.py:33
  */
-int atx_pointwise_stack(const void* x, void* y, int64_t n_pts, int64_t n_lev,
-                        int64_t x_pitch, int64_t y_pitch, int dtype, int layout,
-                        const atx_level_op* prog, const atx_level_op* vec_prog, const atx_level_op* host_prog,
-                        int32_t n_stage, const uint8_t* point_mask, void* stream);
+ATX_API int atx_pointwise_stack(const void* x, void* y, int64_t n_pts, int64_t n_lev,
+                                int64_t x_pitch, int64_t y_pitch, int dtype, int layout,
+                                const atx_level_op* prog, const atx_level_op* vec_prog, const atx_level_op* host_prog,
+                                int32_t n_stage, const uint8_t* point_mask, void* stream);
 
 /* Companion table of a per-level program, computed on the HOST (no device access), in two parts.
  * (1) Per 16-byte vector: out[s*C + c] is the operator shared by the levels c*V .. c*V+V-1 of stage s (V = 16 bytes /
@@ -264,7 +273,7 @@ int atx_pointwise_stack(const void* x, void* y, int64_t n_pts, int64_t n_lev,
  * atx_regrid_ell fuse multiply-add programs on its fastest kernel and atx_pointwise_stack run without any per-workgroup set-up;
  * vec_prog == NULL is always valid (the kernels then derive what they need themselves). */
 #define ATX_OP_MIXED (-1)
-int64_t atx_vector_program(const atx_level_op* prog, int32_t n_stage, int64_t n_lev, int dtype, atx_level_op* out, int64_t out_entries);
+ATX_API int64_t atx_vector_program(const atx_level_op* prog, int32_t n_stage, int64_t n_lev, int dtype, atx_level_op* out, int64_t out_entries);
 
 /* ---- multi-input per-point transforms ------------------------------------------ */
 /* Operators of the reference's MatchingFieldsFilter family (R: filters/fields/matching.py:90-311):
@@ -319,9 +328,9 @@ typedef enum {
  * read from it, and by operators 16 / 17 when they get no pressure operand).
  * All stacks share n_pts, n_lev, pitch and layout; the padding of the outputs (elements between a row's length and the pitch) is
  * written with zeros. */
-int atx_combine_stack(int op, const void* const* inputs, int32_t n_in, void* const* outputs, int32_t n_out,
-                      int64_t n_pts, int64_t n_lev, int64_t pitch, int dtype, int layout,
-                      const double* level_param, int32_t flags, void* stream);
+ATX_API int atx_combine_stack(int op, const void* const* inputs, int32_t n_in, void* const* outputs, int32_t n_out,
+                              int64_t n_pts, int64_t n_lev, int64_t pitch, int dtype, int layout,
+                              const double* level_param, int32_t flags, void* stream);
 
 /* ---- masks ------------------------------------------------------------------ */
 
@@ -329,20 +338,20 @@ int atx_combine_stack(int op, const void* const* inputs, int32_t n_in, void* con
  *   R: apply_mask.py:160-163  `OPERATORS[op](mask_values, threshold)` / `mask_values == mask_value`
  *   R: remove_nans.py:101     `~np.isnan(data)`  (ATX_CMP_NOTNAN)
  * m_stride in elements (1 for a flat field, the pitch for a level of an ATX_COLUMNS stack). */
-int atx_mask_build(const void* m, int64_t m_stride, uint8_t* mask, int64_t n, int cmp, double threshold,
-                   int dtype, void* stream);
+ATX_API int atx_mask_build(const void* m, int64_t m_stride, uint8_t* mask, int64_t n, int cmp, double threshold,
+                           int dtype, void* stream);
 
 /* *count (device int64) = number of non-zero mask bytes.  R: numpy boolean indexing output size. */
-int atx_mask_count(const uint8_t* mask, int64_t n, int64_t* count, void* stream);
+ATX_API int atx_mask_count(const uint8_t* mask, int64_t n, int64_t* count, void* stream);
 
 /* Stable compaction: index[0..count) = ascending positions i with mask[i] != 0;
  * *count (device int64) receives the total.  The index list turns
  * `data[bool_mask]` into atx_regrid_ell(k=1, w=NULL).
  *   R: remove_nans.py:110-116, regrid.py:420 (boolean mask)
  * workspace: device scratch of at least atx_mask_to_index_workspace(n) bytes. */
-size_t atx_mask_to_index_workspace(int64_t n);
-int atx_mask_to_index(const uint8_t* mask, int64_t n, int32_t* index, int64_t* count,
-                      void* workspace, size_t workspace_bytes, void* stream);
+ATX_API size_t atx_mask_to_index_workspace(int64_t n);
+ATX_API int atx_mask_to_index(const uint8_t* mask, int64_t n, int32_t* index, int64_t* count,
+                              void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---- reductions (range / validity checks) ---------------------------------- */
 typedef enum { ATX_RED_MIN = 0, ATX_RED_MAX = 1, ATX_RED_NANCOUNT = 2, ATX_RED_MINMAX = 3 } atx_red;
@@ -356,11 +365,11 @@ typedef enum { ATX_RED_MIN = 0, ATX_RED_MAX = 1, ATX_RED_NANCOUNT = 2, ATX_RED_M
  * synchronising the stream (no copy back) — for EVERY shape: lengths that are not a multiple of the 16-byte vector, unaligned
  * bases (two scalar passes for MINMAX) and empty input (the identities: +inf, -inf, 0).  Without a workspace the workgroups
  * combine through atomics on `result`, which must then be DEVICE memory. */
-size_t atx_reduce_workspace(void);
-int atx_reduce(const void* x, int64_t n, int red, double* result, int dtype, void* workspace, size_t workspace_bytes, void* stream);
+ATX_API size_t atx_reduce_workspace(void);
+ATX_API int atx_reduce(const void* x, int64_t n, int red, double* result, int dtype, void* workspace, size_t workspace_bytes, void* stream);
 /* the same over the n_pts x n_lev elements of a (pitched) stack, padding excluded */
-int atx_reduce_stack(const void* x, int64_t n_pts, int64_t n_lev, int64_t pitch, int red, double* result,
-                     int dtype, int layout, void* workspace, size_t workspace_bytes, void* stream);
+ATX_API int atx_reduce_stack(const void* x, int64_t n_pts, int64_t n_lev, int64_t pitch, int red, double* result,
+                             int dtype, int layout, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---- k-nearest-neighbour index build ---------------------------------------- */
 /* Exact k-NN on the unit sphere by chord distance — device counterpart of
@@ -374,10 +383,10 @@ int atx_reduce_stack(const void* x, int64_t n_pts, int64_t n_lev, int64_t pitch,
  * (16 neighbours plus one to look ahead: a caller that needs cKDTree's own order among
  * EXACTLY equidistant candidates queries k+1, finds the rows with equal adjacent distances and
  * re-resolves those with cKDTree — what the host mirror's nearest_grid_points_device does). */
-size_t atx_knn_workspace_bytes(int64_t n_src);
-int atx_knn_build(const double* src_xyz, int64_t n_src, void* workspace, size_t workspace_bytes, void* stream);
-int atx_knn_query(const void* workspace, int64_t n_src, const double* tgt_xyz, int64_t n_tgt, int32_t k,
-                  int32_t* idx_out, double* d2_out, void* stream);
+ATX_API size_t atx_knn_workspace_bytes(int64_t n_src);
+ATX_API int atx_knn_build(const double* src_xyz, int64_t n_src, void* workspace, size_t workspace_bytes, void* stream);
+ATX_API int atx_knn_query(const void* workspace, int64_t n_src, const double* tgt_xyz, int64_t n_tgt, int32_t k,
+                          int32_t* idx_out, double* d2_out, void* stream);
 
 /* ---- mask builders ------------------------------------------------------------- */
 /* inside[i] = 1 if the ray from the Earth's centre through global point i hits any of the `k`
@@ -387,8 +396,8 @@ int atx_knn_query(const void* workspace, int64_t n_src, const double* tgt_xyz, i
  * evaluated for all points at once.  global_xyz [n,3] and lam_xyz [n_lam,3] float64 unit-sphere
  * coordinates, neighbours int32 [n,k] (from atx_knn_query; k <= 17), inside uint8 [n].  A triangle with a vertex
  * index outside [0, n_lam) is skipped, never dereferenced. */
-int atx_cutout_inside(const double* global_xyz, int64_t n, const double* lam_xyz, int64_t n_lam,
-                      const int32_t* neighbours, int32_t k, uint8_t* inside, void* stream);
+ATX_API int atx_cutout_inside(const double* global_xyz, int64_t n, const double* lam_xyz, int64_t n_lam,
+                              const int32_t* neighbours, int32_t k, uint8_t* inside, void* stream);
 
 /* ---- multi-GPU: the source exchange of a target-sharded regrid ------------------------ */
 /* One process per GPU; RCCL (over xGMI on an MI355X node) is bound at first use (dlopen), so the library loads without
@@ -405,51 +414,51 @@ int atx_cutout_inside(const double* global_xyz, int64_t n, const double* lam_xyz
 typedef struct atx_comm atx_comm;
 #define ATX_COMM_ID_BYTES 128
 /* RCCL's version code (e.g. 22205), or a negative status if RCCL cannot be loaded. */
-int atx_comm_version(void);
+ATX_API int atx_comm_version(void);
 /* Rank 0 fills `id` (HOST, ATX_COMM_ID_BYTES) and hands it to every rank out of band (file, socket, MPI, a
  * torch.distributed store ...). */
-int atx_comm_unique_id(void* id);
+ATX_API int atx_comm_unique_id(void* id);
 /* Collective over all `world` ranks: join the job identified by `id` as `rank`, on the current HIP device. */
-int atx_comm_init(atx_comm** comm, int32_t world, int32_t rank, const void* id);
-int atx_comm_destroy(atx_comm* comm);
-int atx_comm_rank(const atx_comm* comm);
-int atx_comm_world(const atx_comm* comm);
+ATX_API int atx_comm_init(atx_comm** comm, int32_t world, int32_t rank, const void* id);
+ATX_API int atx_comm_destroy(atx_comm* comm);
+ATX_API int atx_comm_rank(const atx_comm* comm);
+ATX_API int atx_comm_world(const atx_comm* comm);
 /* buf[0..n_bytes) of rank `root` onto every rank, in place. */
-int atx_bcast(atx_comm* comm, void* buf, int64_t n_bytes, int32_t root, void* stream);
+ATX_API int atx_bcast(atx_comm* comm, void* buf, int64_t n_bytes, int32_t root, void* stream);
 /* Every rank contributes send[0..bytes_per_rank); afterwards recv[p * bytes_per_rank ...) holds rank p's contribution on every rank
  * (recv: world * bytes_per_rank bytes; send may be the rank's own slot of recv).  The whole-stack exchange of a job in which every
  * rank owns one source stack, as ONE collective instead of `world` broadcasts. */
-int atx_all_gather(atx_comm* comm, const void* send, void* recv, int64_t bytes_per_rank, void* stream);
+ATX_API int atx_all_gather(atx_comm* comm, const void* send, void* recv, int64_t bytes_per_rank, void* stream);
 /* send_ptrs / send_bytes / recv_ptrs / recv_bytes: HOST arrays of `world` entries, one per peer; entry p of the send
  * side goes to rank p, entry p of the receive side is filled by rank p (byte counts must match pairwise across ranks;
  * zero skips the pair; the own entry is a device-to-device copy). */
-int atx_exchange(atx_comm* comm, const void* const* send_ptrs, const int64_t* send_bytes, void* const* recv_ptrs,
-                 const int64_t* recv_bytes, void* stream);
+ATX_API int atx_exchange(atx_comm* comm, const void* const* send_ptrs, const int64_t* send_bytes, void* const* recv_ptrs,
+                         const int64_t* recv_bytes, void* stream);
 /* byte_offsets: HOST array of world + 1 non-decreasing offsets into buf; rank p owns [byte_offsets[p], byte_offsets[p+1])
  * and has filled it; afterwards every rank holds all ranges (ATX_COLUMNS: a rank's target slice is such a range). */
-int atx_gather_shards(atx_comm* comm, void* buf, const int64_t* byte_offsets, void* stream);
+ATX_API int atx_gather_shards(atx_comm* comm, void* buf, const int64_t* byte_offsets, void* stream);
 
 /* ---- measurement aid ------------------------------------------------------------ */
 /* dst[0..n_bytes) = src[0..n_bytes): a plain streaming copy, one 16-byte vector per lane, one workgroup per 4 KB, never
  * tuned again.  It exists so that profiling has a FIXED kernel with a known byte count in the library's access width:
  * tools/pmc_probe.py calibrates the FETCH_SIZE / WRITE_SIZE counters on it, tools/hbm_ceiling.py reports it as the
  * device's practical 1 read : 1 write rate.  n_bytes a multiple of 16, both pointers 16-byte aligned. */
-int atx_stream_copy(const void* src, void* dst, int64_t n_bytes, void* stream);
+ATX_API int atx_stream_copy(const void* src, void* dst, int64_t n_bytes, void* stream);
 
 /* ---- layout --------------------------------------------------------------- */
 /* dst[p, l] = src[p, l] between layouts / pitches (LDS-tiled transpose when the
  * layouts differ, strided copy when they agree).  No reference counterpart:
  * `field.to_numpy()` (R: fields.py:178-202) is the field-major view of a stack. */
-int atx_relayout(const void* src, void* dst, int64_t n_pts, int64_t n_lev,
-                 int64_t src_pitch, int64_t dst_pitch, int src_layout, int dst_layout,
-                 int dtype, void* stream);
+ATX_API int atx_relayout(const void* src, void* dst, int64_t n_pts, int64_t n_lev,
+                         int64_t src_pitch, int64_t dst_pitch, int src_layout, int dst_layout,
+                         int dtype, void* stream);
 
 /* dst level j = src level level_map[j] for j in [0, n_map); a negative entry leaves dst level j untouched.
  * Both stacks in `layout`; level_map is a HOST array (validated before launch, passed to the kernel by value).
  *   R: filter.py:188-196 / fields.py:35-48 — the reference re-lists fields freely (a FieldList is a Python
  *      list of independent arrays); on a stack, re-listing is this level gather. */
-int atx_select_levels(const void* src, void* dst, const int32_t* level_map, int32_t n_map, int64_t n_pts,
-                      int64_t n_src_lev, int64_t src_pitch, int64_t dst_pitch, int dtype, int layout, void* stream);
+ATX_API int atx_select_levels(const void* src, void* dst, const int32_t* level_map, int32_t n_map, int64_t n_pts,
+                              int64_t n_src_lev, int64_t src_pitch, int64_t dst_pitch, int dtype, int layout, void* stream);
 
 #ifdef __cplusplus
 }

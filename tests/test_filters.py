@@ -478,6 +478,45 @@ def test_regrid_nearest_checks(engine):
         list(source | wrong)
 
 
+def test_regrid_wrong_field_size_raises_what_the_reference_raises(engine):
+    """One exception type per interpolator, each the type of the reference's own statement on a field of the wrong length:
+    ``matrix=`` -> ValueError (scipy's ``csr_array @ x``, R: regrid.py:310), ``method="nearest"`` -> AssertionError
+    (R: regrid.py:377-378), ``mask=`` -> IndexError (numpy's ``x[..., mask]``, R: regrid.py:420)."""
+    import scipy.sparse
+
+    from anemoi_transform_amd import interp
+    from anemoi_transform_amd.grids import lookup
+
+    src, other, tgt = lookup("o32"), lookup("o48"), lookup([5.0, 5.0])
+    source = test_source(synthetic_fields(src, 2))
+    n_src, n_other = len(src["latitudes"]), len(other["latitudes"])
+
+    # the reference's statements themselves, on the same sizes
+    with pytest.raises(ValueError, match="dimension mismatch"):
+        scipy.sparse.csr_array((np.ones(2), np.array([0, 1]), np.array([0, 1, 2])), shape=(2, n_other)) @ np.zeros(n_src)
+    with pytest.raises(IndexError):
+        np.zeros(n_src)[..., np.zeros(n_other, dtype=bool)]
+    with pytest.raises(IndexError):
+        np.zeros(n_src)[..., np.array([0, n_other - 1])]
+
+    idx, w = interp.knn_inverse_distance(other, tgt, k=4)
+    n_tgt = len(idx)
+    matrix = dict(matrix_data=w.reshape(-1), matrix_indices=idx.reshape(-1).astype(np.int32), matrix_indptr=np.arange(n_tgt + 1, dtype=np.int32) * 4,
+                  matrix_shape=np.array([n_tgt, n_other]))
+    matrix = {**matrix, "in_latitudes": other["latitudes"], "in_longitudes": other["longitudes"],
+              "out_latitudes": tgt["latitudes"], "out_longitudes": tgt["longitudes"]}
+    with pytest.raises(ValueError, match="dimension mismatch"):
+        list(source | create_filter_by_name("regrid", matrix=matrix))
+    with pytest.raises(AssertionError):
+        list(source | create_filter_by_name("regrid", in_grid="o48", out_grid=[5.0, 5.0], method="nearest"))
+    with pytest.raises(IndexError):
+        list(source | create_filter_by_name("regrid", mask=np.zeros(n_other, dtype=bool)))
+    with pytest.raises(IndexError):
+        list(source | create_filter_by_name("regrid", mask=np.array([0, n_other - 1])))
+    # and the right sizes go through
+    assert len(list(test_source(synthetic_fields(other, 2)) | create_filter_by_name("regrid", matrix=matrix))) == 2
+
+
 def test_regrid_default_route(engine, tmp_path, caplog):
     """R: regrid.py:455-467 + 211-259 — no ``method`` (the reference's stock recipe form) resolves to the default
     interpolator with method="linear"; here the matrix is the in-tree bilinear one (earthkit-regrid's inventory is

@@ -422,6 +422,31 @@ def test_library_exports_every_declared_symbol():
     assert set(declared) == set(native.SIGNATURES), "native.py must bind exactly the header's entry points"
 
 
+def test_library_exports_nothing_but_the_header():
+    """The dynamic symbol table of libatx.so is EXACTLY the ATX_API declarations of include/atx.h (= native.SIGNATURES): built with
+    -fvisibility=hidden and a version script, so no C++ helper, kernel stub or template instance can interpose — or be interposed by —
+    another library loaded into the same process (round 5 leaked 1 252 such names)."""
+    import shutil
+    import subprocess
+
+    nm = shutil.which("nm") or "/opt/rocm/lib/llvm/bin/llvm-nm"
+    if not (shutil.which("nm") or os.path.exists(nm)):
+        pytest.skip("no nm")
+    listing = subprocess.run([nm, "-D", "--defined-only", native.lib_path()], capture_output=True, text=True, check=True).stdout
+    defined = sorted(line.split()[-1].split("@")[0] for line in listing.splitlines() if line.strip())
+    assert defined == sorted(native.SIGNATURES), sorted(set(defined) ^ set(native.SIGNATURES))[:20]
+    assert defined == header_symbols()
+    # every one of them a function in the text section, none weak
+    kinds = {line.split()[-2] for line in listing.splitlines() if line.strip()}
+    assert kinds == {"T"}, kinds
+    # the header marks each declaration, and only those, with ATX_API
+    text = open(os.path.join(ROOT, "include", "atx.h")).read()
+    assert sorted(re.findall(r"^ATX_API [^;(]*?\b(atx_[a-z_0-9]+)\(", text, flags=re.M)) == defined
+    # RCCL stays a run-time binding (dlopen in atx_comm.hip), not a link-time dependency the stand-in could not replace
+    undefined = subprocess.run([nm, "-D", "--undefined-only", native.lib_path()], capture_output=True, text=True, check=True).stdout
+    assert "nccl" not in undefined.lower()
+
+
 def test_header_is_plain_c_and_links(tmp_path):
     """include/atx.h compiles as C99 with warnings as errors, and a C program linked against libatx.so runs (tests/c_abi/abi_check.c)."""
     import shutil

@@ -14,7 +14,7 @@ mkdir -p $OUT $OBJ
 SAN="-Xarch_host -fsanitize=address,undefined -Xarch_host -fno-sanitize-recover=all -Xarch_host -fno-omit-frame-pointer"
 cd $ROOT/anemoi-transform_amd/csrc
 # one object per source, in parallel (the gather kernels' file alone is half of the build)
-ls *.hip | xargs -P 8 -I{} sh -c "/opt/rocm/bin/hipcc --offload-arch=gfx950 -O1 -g -std=c++17 -fPIC -ffp-contract=off -Wno-unused-function $SAN -c {} -o $OBJ/{}.o"
+ls *.hip | xargs -P 8 -I{} sh -c "/opt/rocm/bin/hipcc --offload-arch=gfx950 -O1 -g -std=c++17 -fPIC -ffp-contract=off -fvisibility=hidden -fvisibility-inlines-hidden -Wno-unused-function $SAN -c {} -o $OBJ/{}.o"
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -fsanitize=address,undefined -shared-libasan -o $OUT/libatx_hostsan.so $OBJ/*.o
 cd $ROOT/tests/rccl_stub
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O1 -g -std=c++17 -fPIC -shared $SAN -fsanitize=address,undefined -shared-libasan -o $OUT/librccl_stub_hostsan.so rccl_stub.cpp -lpthread
