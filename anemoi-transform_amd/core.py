@@ -26,6 +26,21 @@ from typing import Any, Callable
 
 LOG = logging.getLogger(__name__)
 
+# ---- notes a filter logs about its own parity (unpinned third-party arithmetic, a jump in a statement): a pipeline that builds its
+#      filters per batch or per date must not repeat them — the first construction in a process says it at the given level, later
+#      ones at DEBUG
+_NOTES_SAID: set[Any] = set()
+
+
+def say_once(logger: logging.Logger, key: Any, message: str, *args: Any, level: int = logging.WARNING) -> None:
+    logger.log(logging.DEBUG if key in _NOTES_SAID else level, message, *args)
+    _NOTES_SAID.add(key)
+
+
+def reset_notes() -> None:
+    """Forget which notes were said (tests)."""
+    _NOTES_SAID.clear()
+
 
 # =================================================================================
 # Registry

@@ -111,19 +111,22 @@ __device__ __forceinline__ double quiet_nan<double>() {
 // fma(a, b, c) with c a compile-time constant held in SCALAR registers (v_fma_f64 v, v, v, s[..]).  Left to itself the compiler keeps the
 // coefficients of a float64 polynomial in vector registers and evaluates Horner steps with the two-address v_fmac_f64, which overwrites
 // its addend — so every step of every element first COPIES its coefficient (v_mov_b64): 12 extra instructions in a degree-13 Horner chain,
-// a third of it.  `c` MUST be a compile-time constant (the "s" constraint would otherwise take the first lane's value for the whole wave).
+// a third of it.  Used with literal coefficients; a `c` that is not a compile-time constant falls back to __builtin_fma.
 // ATX_FMA_SGPR=0 restores __builtin_fma.
 #ifndef ATX_FMA_SGPR
 #define ATX_FMA_SGPR 1
 #endif
 __device__ __forceinline__ double fma_k(double a, double b, double c) {
 #if ATX_FMA_SGPR
-    double d;
-    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "s"(c));
-    return d;
-#else
-    return __builtin_fma(a, b, c);
+    // the scalar-register form only for an addend the compiler KNOWS to be a constant once this is inlined; anything per-lane takes the
+    // ordinary fma (without this check the "s" constraint would silently broadcast lane 0's addend through v_readfirstlane)
+    if (__builtin_constant_p(c)) {
+        double d;
+        asm("v_fma_f64 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "s"(c));
+        return d;
+    }
 #endif
+    return __builtin_fma(a, b, c);
 }
 
 // a / b for float64 WITHOUT the IEEE division sequence (v_div_scale x2, v_rcp, 5 fma, v_div_fmas, v_div_fixup = 13 VALU instructions):
@@ -224,8 +227,8 @@ __device__ __forceinline__ double atx_log(double x) {
 // (ATX_FAST_EXP=1, round 5): x = k ln2 + r with two fused multiply-adds (|r| <= ln2 / 2), exp(r) = 1 + r (1 + r q(r)) with q of degree 9 —
 // a Chebyshev fit of (e^r - 1 - r) / r^2 on the interval, relative error 0.15 x 2^-53 before rounding (derived with 300-bit arithmetic,
 // tools/experiments/exp_polynomial.py) — exact scaling by v_ldexp_f64, which also delivers +inf beyond 709.78 and the subnormal
-// results and 0 below -708.4 with one rounding.  What is left for a branch no wave of real data takes: |x| > 2^50 (the reduction loses k),
-// +-inf, NaN.  18 VALU instructions per element against the device library's 22 (it spends 5 on range checks that ldexp makes
+// results and 0 below -708.4 with one rounding.  The argument is clamped to +-1100 first (see below) and a NaN passed through at the
+// end: no branch.  18 VALU instructions per element against the device library's 22 (it spends 5 on range checks that ldexp makes
 // unnecessary); <= 1 ulp from numpy's on every range of tests/test_gpu_kernels.py::test_float64_exp_within_one_ulp_of_numpy (true error
 // <= 0.9 ulp on a host prototype against 200-bit arithmetic).  ATX_FAST_EXP=0: the device library.
 #ifndef ATX_FAST_EXP
@@ -235,6 +238,12 @@ __device__ __forceinline__ float atx_exp(float x) { return exp(x); }
 __device__ __forceinline__ double atx_exp(double x) {
 #if ATX_FAST_EXP
     constexpr double log2e = 1.4426950408889634, ln2hi = 6.93147180559945286227e-01, ln2lo = 2.31904681384629955842e-17;
+    // Everything beyond +-1100 already has its answer (+inf above 709.78, 0 below -745.1): clamping there keeps k = rint(x log2e)
+    // within +-1587, so the conversion to int below is always in range (an out-of-range double -> int cast is undefined in C++ and
+    // poison in LLVM, whatever v_cvt_i32_f64 does), and ldexp delivers +inf / 0 for the clamped operands, +-inf included.  A NaN
+    // comes out of the clamp as a number (fmax / fmin return the other operand) and is put back by the last line.
+    const double xin = x;
+    x = __builtin_fmin(__builtin_fmax(x, -1100.0), 1100.0);
     const double k = __builtin_rint(x * log2e);
     double r = __builtin_fma(-k, ln2hi, x);
     r = __builtin_fma(-k, ln2lo, r);
@@ -249,11 +258,8 @@ __device__ __forceinline__ double atx_exp(double x) {
     q = fma_k(q, r, 0x1.5555555555556p-3);
     q = fma_k(q, r, 0x1.0000000000001p-1);
     const double p = __builtin_fma(r, __builtin_fma(r, q, 1.0), 1.0);
-    double y = __builtin_amdgcn_ldexp(p, (int)k);  // (int) saturates: an enormous k still means +inf or 0
-    if (!(__builtin_fabs(x) <= 1125899906842624.0)) {  // 2^50; NaN fails the comparison too
-        y = (x != x) ? x : (x > 0.0 ? __longlong_as_double(0x7ff0000000000000ll) : 0.0);
-    }
-    return y;
+    const double y = __builtin_amdgcn_ldexp(p, (int)k);  // |k| <= 1587
+    return (xin != xin) ? xin : y;
 #else
     return exp(x);
 #endif
@@ -282,7 +288,11 @@ __device__ __forceinline__ double atx_expm1_moderate(double y) {
     q = fma_k(q, r, 1.0 / 24.0);
     q = fma_k(q, r, 1.0 / 6.0);
     q = fma_k(q, r, 0.5);
-    const double t = __hiloint2double(((int)k + 1023) << 20, 0);  // 2^k, |k| <= 58
+    // 2^k for |k| <= 58 (|y| <= 40).  Callers may hand over anything and discard the result (a negative or NaN snow-cover argument):
+    // the exponent is built from a CLAMPED k, so the double -> int conversion is always in range and the shifted value never negative —
+    // r keeps the unclamped k, so a NaN still comes out as NaN and an oversized |y| as (defined) garbage.
+    const int ki = (int)__builtin_fmin(__builtin_fmax(k, -60.0), 60.0);
+    const double t = __hiloint2double((int)((unsigned)(ki + 1023) << 20), 0);
     const double a = __builtin_fma(t, r, t - 1.0);
     return __builtin_fma(t * (r * r), q, a);
 }

@@ -31,7 +31,7 @@ import numpy as np
 import torch
 
 from .. import native
-from ..core import Filter, filter_registry
+from ..core import Filter, filter_registry, say_once
 from ..fields import FieldList, fields_to_stack, new_field_from_numpy, new_field_from_stack, new_fieldlist_from_list
 from ..grouping import GroupByParam, GroupByParamVertical
 
@@ -112,7 +112,8 @@ class MatchingFieldsFilter(Filter):
 
     MATCHING: MatchingSpec
     #: set by the filters whose arithmetic lives in a third-party package that is absent here (earthkit-meteo): what the device
-    #: operator restates and what pins it.  Logged once per filter instance, as `regrid`'s default route does (filters/regrid.py).
+    #: operator restates and what pins it — or where a statement of the reference makes the last bit of a library function visible
+    #: (snow_cover).  Logged at WARNING by the first instance of the class in a process, at DEBUG by later ones (core.say_once).
     PARITY_NOTE: str | None = None
 
     @staticmethod
@@ -136,7 +137,7 @@ class MatchingFieldsFilter(Filter):
         super().__init__(*args, **kwargs)
         self._prepare_matching()
         if self.PARITY_NOTE:
-            LOG.warning("%s: %s", type(self).__name__, self.PARITY_NOTE)
+            say_once(LOG, (type(self), "parity"), "%s: %s", type(self).__name__, self.PARITY_NOTE)
 
     def _prepare_matching(self) -> None:
         """Apply an instance-level ``return_inputs`` to the class's spec and warn about returned inputs that are not
@@ -346,6 +347,10 @@ class SnowCover(StackMatchingFilter):
     """Snow cover fraction from snow depth and snow density (R: snow_cover.py:34-39)."""
 
     MATCHING = MatchingSpec(select="param", forward=("snow_depth", "snow_density"))
+    PARITY_NOTE = ("values agree with the reference's numpy statement to 1e-6 relative EXCEPT at the statement's own jump, `snow_cover[snow_cover > "
+                   "0.99] = 1.0` (snow_cover.py:38): where tanh lands within a few ulp of 0.99 the last bit of tanh decides between 0.99 and 1.0, "
+                   "and the device's tanh and numpy's may differ in that bit — either side is the statement's own value (about one point in "
+                   "30 000 in float32, none in practice in float64)")
 
     def __init__(self, *, snow_depth: str = "sd", snow_density: str = "rsn", snow_cover: str = "snowc") -> None:
         self.snow_depth = snow_depth

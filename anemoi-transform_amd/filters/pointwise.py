@@ -22,7 +22,7 @@ import numpy as np
 import torch
 
 from .. import native
-from ..core import Filter, SingleFieldFilter, filter_registry
+from ..core import Filter, SingleFieldFilter, filter_registry, say_once
 from ..fields import FieldList
 from .engine import LevelOp, PointMask, run_level_ops
 
@@ -169,9 +169,16 @@ class Convert(RescaleMixin, StackFieldFilter):
         if {self.unit_in, self.unit_out} != {"K", "degC"}:
             # the one pair the reference pins is K -> degC (R: tests/field_filters/test_rescale.py:58-72); everything else comes from
             # pint when it is installed, else from the private table above — say so, as `regrid`'s default route does
-            LOG.warning("convert(%s -> %s): scale %r and offset %r come from %s; only K <-> degC is pinned by the reference "
-                        "(tests/field_filters/test_rescale.py), other pairs are not held to a reference vector",
-                        self.unit_in, self.unit_out, scale, offset, "pint" if _have_pint() else "this package's private unit table (pint is not installed)")
+            # (pint IS the reference's own converter, R: rescale.py:94: with it installed this is information, not a warning; either way
+            # once per unit pair and process — core.say_once — not once per construction)
+            import logging
+
+            say_once(LOG, ("convert", self.unit_in, self.unit_out),
+                     "convert(%s -> %s): scale %r and offset %r come from %s; only K <-> degC is pinned by the reference "
+                     "(tests/field_filters/test_rescale.py), other pairs are not held to a reference vector",
+                     self.unit_in, self.unit_out, scale, offset,
+                     "pint, the reference's own converter" if _have_pint() else "this package's private unit table (pint is not installed)",
+                     level=logging.INFO if _have_pint() else logging.WARNING)
 
 
 filter_registry.register("rescale", Rescale)

@@ -43,8 +43,24 @@ import sys
 import threading
 import time
 
+T_IMPORT = time.monotonic()  # before the heavy imports: the first `import torch` on a fresh box takes one to two minutes
+try:  # how old the process already was when this file started to run (interpreter start, launcher hand-over)
+    import psutil
+
+    T_PROCESS_AGE = max(0.0, time.time() - psutil.Process().create_time())
+except Exception:  # noqa: BLE001 - a clock offset, never a reason to fail
+    try:
+        T_PROCESS_AGE = max(0.0, time.time() - os.stat(f"/proc/{os.getpid()}").st_ctime)
+    except OSError:
+        T_PROCESS_AGE = 0.0
+
 import numpy as np
 import torch
+
+
+def wall_seconds() -> float:
+    """Seconds since this PROCESS started — what a driver's time limit around the command counts."""
+    return T_PROCESS_AGE + (time.monotonic() - T_IMPORT)
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -82,6 +98,9 @@ def parse_args():
                     help="N > 1: backend of the group that carries the stacks (nccl = RCCL over xGMI); barriers always run on gloo")
     ap.add_argument("--secondary-seconds", type=float, default=360.0,
                     help="N > 1: wall-clock budget of the lines measured after `value`; when it runs out the JSON line is printed with what is there")
+    ap.add_argument("--total-seconds", type=float, default=300.0,
+                    help="N > 1: cap on the wall clock of the WHOLE command, process start to the printed line: a secondary section whose "
+                         "estimated cost (SECTION_ESTIMATE_S) no longer fits is `skipped`; `value` is measured before any of them")
     ap.add_argument("--rehearse-multi", action="store_true",
                     help="REHEARSAL ONLY, with --gpus 1: run the N > 1 secondary sections (RCCL exchange through torch.distributed and through "
                          "atx_comm_*, end to end, strong) at world size 1 — the whole multi-GPU code path on the real collective library")
@@ -224,7 +243,14 @@ def mirror_multi_gpu_into_config(result: dict) -> None:
         "config4": pick("config4", "value", "ms_per_step"),
         "config5": pick("config5", "value", "ms_per_step"),
         "secondary_timed_out_in": result.get("secondary_timed_out_in"),
-        "unit": "grid-points/s (values), ms (times)",
+        # the wall clock of the command (seconds, max over ranks): where the time of an N-rank run goes, and what was dropped to stay under the cap
+        "wall_s": result.get("wall_s"),
+        "setup_s": result.get("setup_s"),
+        "precompute_s": result.get("precompute_s"),
+        "sections_s": result.get("sections_s"),
+        "sections_skipped": result.get("sections_skipped"),
+        "total_seconds_cap": result.get("total_seconds_cap"),
+        "unit": "grid-points/s (values), ms (times), s (wall_s / setup_s / precompute_s / sections_s)",
     }
 
 
@@ -300,6 +326,14 @@ def main():
             dist.destroy_process_group()
         return
 
+    setup_s = {"process_start_to_main": wall_seconds()}  # interpreter start + `import torch` (one to two minutes on a fresh box)
+    marks = {"t": time.monotonic()}
+
+    def mark(name):  # seconds since the previous mark, under `name`
+        now = time.monotonic()
+        setup_s[name] = setup_s.get(name, 0.0) + (now - marks["t"])
+        marks["t"] = now
+
     graft.load_package()
     from anemoi_transform_amd import native
     from anemoi_transform_amd.gather import GatherPlan
@@ -343,6 +377,7 @@ def main():
     layout = COLUMNS if args.layout == "columns" else FIELDS
     if args.tile:
         native.set_tuning(args.tile)
+    mark("library_device_and_host_group")
 
     # ---- one-off precompute on the host (not timed): grids, cKDTree indices + weights
     t0 = time.perf_counter()
@@ -351,6 +386,7 @@ def main():
     idx64, w64 = knn_inverse_distance(src_grid, tgt_grid, k=args.k)
     precompute_s = time.perf_counter() - t0
     n_unique = int(np.unique(idx64).size)
+    mark("grids_and_knn_table")
 
     # target-point shard of this rank: contiguous, balanced by HBM traffic (GatherPlan.bounds) — equal-count
     # shards of a lat-lon target are 1.8x apart in cost (polar targets share their source columns)
@@ -365,6 +401,7 @@ def main():
 
     bounds = plan.bounds(world, target_cost=TARGET_COST_SHORT_LAUNCH)
     lo, hi = bounds[rank], bounds[rank + 1]
+    mark("plan_and_shard_bounds")
 
     # ---- sources resident in HBM before the timed region: the N stacks of the step, each a pure function of its id
     stacks = [synth_stack(src_grid, args.levels, tdtype, dev, r, layout) for r in range(world)]
@@ -373,6 +410,8 @@ def main():
     idx_d, w_d, rows_d = ordered_tables(idx64, w64, tgt_grid, lo, hi, np_dtype, dev, natural=layout != COLUMNS or args.natural_order)
     assert native.check_indices(idx_d, n_src) == 0
     outs = [Stack.empty(hi - lo, args.levels, tdtype, dev, layout)]
+    torch.cuda.synchronize()
+    mark("source_stacks_and_tables_resident")
 
     def launch(src, out, idx=None, w=w_d, k=args.k, n_t=hi - lo):
         rows = rows_d if idx is None else None  # callers that bring their own tables bring them in natural order
@@ -397,6 +436,10 @@ def main():
 
     units_per_step = n_tgt * args.levels  # all ranks together: ONE stack x the full target grid (the shards tile it), whatever N
     value = units_per_step * args.steps / elapsed
+    mark("timed_region")
+    if rank == 0:  # the headline's ingredients, on stderr the moment they exist: a run cut short later has still said them
+        print(f"bench.py: value {value:.6g} grid-points/s, {elapsed / args.steps * 1e3:.4f} ms/step over {args.steps} steps on {world} GPU(s), "
+              f"{wall_seconds():.1f} s after process start", file=sys.stderr, flush=True)
 
     # ---- roofline of the dominant kernel, HIP events around single launches (N > 1: this rank's shard of the stack)
     launch_ms = launch_times(step, min(max(args.steps, 10), 200), 2)
@@ -482,8 +525,17 @@ def main():
             "job": {"algorithmic_bytes_per_step_all_ranks": alg_all, "achieved": job_gbs, "peak": HBM_PEAK_GBS * world, "unit": "GB/s",
                     "frac": job_gbs / (HBM_PEAK_GBS * world), "ms_per_step": elapsed / args.steps * 1e3},
         },
-        "precompute_s": precompute_s,
+        "precompute_s": max_over_ranks(precompute_s),  # host-side k-NN table (cKDTree or its cache file), slowest rank
     }
+    mark("roofline_launches")
+    if multi:
+        # where the wall clock of an N-rank command goes before the secondary sections start (seconds, max over ranks per entry)
+        keys = sorted(setup_s)
+        t_setup = torch.tensor([setup_s[k] for k in keys], dtype=torch.float64)
+        dist.all_reduce(t_setup, op=dist.ReduceOp.MAX)
+        setup_s = {k: round(float(v), 3) for k, v in zip(keys, t_setup.tolist())}
+    result["setup_s"] = setup_s
+    result["total_seconds_cap"] = args.total_seconds if multi else None
 
     if multi:
         # the fixed-total-work line IS the headline: repeated under the name the rounds 1-4 records used for it (before the secondary
@@ -500,13 +552,14 @@ def main():
                             src_grid, tgt_grid, n_src, n_tgt, tdtype, np_dtype, idx64, w64, layout, quiet.saved)
         finally:
             quiet.__exit__()
-    if multi:
-        mirror_multi_gpu_into_config(result)
 
     if rank == 0 and world == 1 and not args.rehearse_multi:
         single_gpu_lines(args, result, dev, stacks, outs, launch, idx_d, w_d, rows_d, idx64, w64, n_src, n_tgt, n_unique, alg, src_grid, tgt_grid,
                          tdtype, np_dtype, itemsize, plan)
 
+    result["wall_s"] = max_over_ranks(wall_seconds())  # process start -> this line, slowest rank
+    if multi:
+        mirror_multi_gpu_into_config(result)
     if rank == 0:
         print(json.dumps(result), flush=True)
     if multi:
@@ -518,6 +571,34 @@ def main():
 # ------------------------------------------------------------------------------------------------------------------------
 # N > 1: what is measured AFTER `value` — the exchange over RCCL, end to end, strong scaling, field-axis sharding
 # ------------------------------------------------------------------------------------------------------------------------
+# What a secondary section is EXPECTED to cost on the slowest rank of an N-rank run at the default (full) sizes, in seconds: the budget
+# rule of `section` skips a section whose estimate no longer fits under --total-seconds.  Measured at world 1 on an MI355X box
+# (profiles/r06_bench_rehearse_multi_world1.json, `sections_s`), rounded up and doubled; the entries that grow with the number of ranks
+# (N stacks to move, N communicators to bring up) carry a per-rank part.  An unknown name costs 5 s.
+SECTION_ESTIMATE_S = {
+    "weak": (2.0, 0.5),
+    "exchange broadcast": (6.0, 1.5),   # first collective on the data group: RCCL brings up its rings here
+    "end_to_end": (3.0, 0.5),
+    "exchange bands": (4.0, 0.5),
+    "end_to_end_bands": (3.0, 0.5),
+    "config4": (40.0, 0.0),             # cKDTree for the N320-sized target + 88.7 GB of sources made resident + the launches
+    "config5": (35.0, 0.0),             # device k-NN over O2560 + a 29 GB stack + the launches
+    "exchange all_gather": (4.0, 1.5),
+    "end_to_end_all_gather": (3.0, 1.5),
+    "field_axis_sharding": (3.0, 0.0),
+    "c_abi init": (6.0, 1.0),
+    "c_abi broadcast": (3.0, 0.5),
+    "c_abi all_gather": (3.0, 1.5),
+    "c_abi bands": (3.0, 0.5),
+    "c_abi end_to_end": (3.0, 0.5),
+}
+
+
+def section_estimate(name: str, world: int) -> float:
+    base, per_rank = SECTION_ESTIMATE_S.get(name, (5.0, 0.0))
+    return base + per_rank * world
+
+
 def multi_gpu_lines(args, result, dist, rank, world, dev, plan, stacks, launch, units_per_step, barrier, max_over_ranks,
                     src_grid, tgt_grid, n_src, n_tgt, tdtype, np_dtype, idx64, w64, layout, real_stdout_fd):
     from anemoi_transform_amd import distributed as atxd
@@ -531,34 +612,53 @@ def multi_gpu_lines(args, result, dist, rank, world, dev, plan, stacks, launch, 
     def give_up():
         if rank == 0:
             result["secondary_timed_out_in"] = state["section"]
+            result["wall_s"] = wall_seconds()  # (this rank's clock: nobody waits for the others any more)
             mirror_multi_gpu_into_config(result)
             os.write(real_stdout_fd, (json.dumps(result) + "\n").encode())  # fd 1 points at stderr in here
         os._exit(3)  # the measured line is out, but a collective that never returned is a FAILURE of the run: the launcher must see it
 
-    watchdog = threading.Timer(args.secondary_seconds, give_up)
+    # the hard limit (a collective that never returns): the secondary budget, and never later than half a cap past the cap
+    watchdog = threading.Timer(max(0.0, min(args.secondary_seconds, 1.5 * args.total_seconds - wall_seconds())), give_up)
     watchdog.daemon = True
     watchdog.start()
 
     t_secondary = time.monotonic()
+    sections_s: dict[str, float] = {}
+    skipped: list[str] = []
+    result["sections_s"] = sections_s  # seconds per secondary section, slowest rank — filled as they complete
+    result["sections_skipped"] = skipped
 
     def section(name, fn):
         """Run one secondary measurement on all ranks; an exception on any rank is recorded and the ranks stay in step.
-        Past half of the secondary budget the remaining sections are skipped (all ranks decide together): the hard limit — which
-        ends the run with a non-zero status — is for a collective that never returns, not for a slow box."""
+        A section is SKIPPED (all ranks decide together, on the slowest rank's clock) when its estimated cost no longer fits under
+        `--total-seconds` counted from process start, or past half of the secondary budget: the hard limit — which ends the run with a
+        non-zero status — is for a collective that never returns, not for a slow box."""
         state["section"] = name
         barrier()
-        spent = torch.tensor([time.monotonic() - t_secondary], dtype=torch.float64)
-        dist.all_reduce(spent, op=dist.ReduceOp.MAX)
-        if spent.item() > 0.5 * args.secondary_seconds:
-            return {"skipped": f"{spent.item():.0f} s of the {args.secondary_seconds:.0f} s secondary budget already spent"}
+        clock = torch.tensor([time.monotonic() - t_secondary, wall_seconds()], dtype=torch.float64)
+        dist.all_reduce(clock, op=dist.ReduceOp.MAX)
+        spent, wall = clock.tolist()
+        estimate = section_estimate(name, world)
+        why = None
+        if wall + estimate > args.total_seconds:
+            why = (f"{wall:.0f} s after process start; this section is estimated at {estimate:.0f} s and the command is capped at "
+                   f"{args.total_seconds:.0f} s (--total-seconds)")
+        elif spent > 0.5 * args.secondary_seconds:
+            why = f"{spent:.0f} s of the {args.secondary_seconds:.0f} s secondary budget already spent"
+        if why is not None:
+            skipped.append(name)
+            return {"skipped": why}
+        t_section = time.monotonic()
         try:
             out = fn()
             ok = 1.0
         except Exception as e:  # a comparison line must never take the bench line down
             out, ok = {"error": f"{type(e).__name__}: {e}"}, 0.0
-        flag = torch.tensor([ok], dtype=torch.float64)
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-        if flag.item() < 1.0 and ok == 1.0:
+        torch.cuda.synchronize()
+        done = torch.tensor([-ok, time.monotonic() - t_section], dtype=torch.float64)
+        dist.all_reduce(done, op=dist.ReduceOp.MAX)  # (max of -ok = -min of ok)
+        sections_s[name] = round(float(done[1].item()), 3)
+        if -done[0].item() < 1.0 and ok == 1.0:
             out = {"error": "failed on another rank"}
         return out
 
@@ -617,7 +717,10 @@ def multi_gpu_lines(args, result, dist, rank, world, dev, plan, stacks, launch, 
         return {"value": units_per_step * args.steps / t, "unit": "grid-points/s", "ms_per_step": t / args.steps * 1e3,
                 "note": "each rank regrids its own stack to the full target grid; no source exchange"}
 
-    result["field_axis_sharding"] = section("field_axis_sharding", field_axis)
+    if layout != COLUMNS:  # field-major stacks: the exchange helpers of distributed.py are written for column stacks
+        result["field_axis_sharding"] = section("field_axis_sharding", field_axis)
+        watchdog.cancel()
+        return
 
     # ---- BASELINE configs[3] as specified: O1280 -> N320-sized, 6 variables x 137 levels x 4 timesteps = 24 stacks, the target points
     #      sharded over the N ranks (no exchange in the step: every rank holds the 24 source stacks, 88.7 GB f32)
@@ -681,18 +784,14 @@ def multi_gpu_lines(args, result, dist, rank, world, dev, plan, stacks, launch, 
         return {"value": all_units * reps / t, "unit": "grid-points/s", "ms_per_step": t / reps * 1e3, "scaling": "strong",
                 "workload": f"O2560 -> 0.25 deg, k=4, 137 levels, regrid | orog_to_z | convert fused in one launch; one stack, target points over {world} ranks"}
 
-    if layout == COLUMNS:
-        result["config4"] = section("config4", config4)
-        torch.cuda.empty_cache()
-        result["config5"] = section("config5", config5)
-        torch.cuda.empty_cache()
-    if layout != COLUMNS:
-        watchdog.cancel()
-        return
-
     # ---- the source exchange itself, on the data group (RCCL): first use creates the communicators
     state["section"] = "data group"
+    t_group = time.monotonic()
     atxd.set_data_group(dist.new_group(backend=args.backend))
+    sections_s["data group"] = round(max_over_ranks(time.monotonic() - t_group), 3)
+    if "error" in result["weak"] or "skipped" in result["weak"]:  # the exchange sections verify against `outs`: fill them whatever became of the timing
+        weak_step()
+        torch.cuda.synchronize()
     mine = stacks[rank]
     exchange_ms, verified, detail = {}, {}, {}
     result["source_exchange_ms"] = exchange_ms  # filled as the sections complete: a budget cut keeps what is there
@@ -731,10 +830,11 @@ def multi_gpu_lines(args, result, dist, rank, world, dev, plan, stacks, launch, 
                 "verified_bit_equal": all(torch.equal(g.data, s.data) for g, s in zip(got, stacks)),
                 "note": "the whole-stack exchange as ONE all-gather instead of N broadcasts"}
 
+    # ---- ORDER = PRIORITY.  The sections run in the order below and the cap drops them from the END: first what north_star words ("the
+    #      source field broadcast once via RCCL", then the step that includes it), then the xGMI-native band exchange, then BASELINE
+    #      configs[3] and [4] on the N GPUs, then the all-gather and field-axis comparison points, last the same exchanges once more
+    #      through the C-ABI communicator.
     detail["broadcast"] = section("exchange broadcast", broadcast)
-    detail["all_gather"] = section("exchange all_gather", all_gather)
-    torch.cuda.empty_cache()
-    detail["bands"] = section("exchange bands", bands)
 
     def repetitions(exchange):  # as many repetitions as fit ~3 s of exchange; none if one exchange alone takes more than 30 s (gloo rehearsals)
         ms = exchange_ms.get(exchange)
@@ -752,6 +852,7 @@ def multi_gpu_lines(args, result, dist, rank, world, dev, plan, stacks, launch, 
                 "note": "one step INCLUDING the exchange of the N source stacks: broadcast r+1 (RCCL) overlapped with launch r, two source buffers alive"}
 
     result["end_to_end"] = section("end_to_end", end_to_end)
+    detail["bands"] = section("exchange bands", bands)
 
     def end_to_end_bands():
         # the xGMI-native form of the same step: ONE all-to-all of band slabs (every rank sends each peer only the source columns that
@@ -787,8 +888,15 @@ def multi_gpu_lines(args, result, dist, rank, world, dev, plan, stacks, launch, 
                 "note": "one step INCLUDING the exchange: one all-gather of the N source stacks, then one batched launch"}
 
     torch.cuda.empty_cache()
+    result["config4"] = section("config4", config4)
+    torch.cuda.empty_cache()
+    result["config5"] = section("config5", config5)
+    torch.cuda.empty_cache()
+    detail["all_gather"] = section("exchange all_gather", all_gather)
+    torch.cuda.empty_cache()
     result["end_to_end_all_gather"] = section("end_to_end_all_gather", end_to_end_all_gather)
     torch.cuda.empty_cache()
+    result["field_axis_sharding"] = section("field_axis_sharding", field_axis)
 
     # ---- the same exchanges through the library's own C-ABI communicator (atx_comm_*: RCCL bound directly)
     if args.backend == "nccl":

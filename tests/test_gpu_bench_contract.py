@@ -99,6 +99,29 @@ def assert_mirrored(d: dict) -> None:
     assert m["secondary_timed_out_in"] is None
     text = d["config"]["sharding"]
     assert "end_to_end" in text and "weak" in text and "north_star" in text and "STRONG" in text and "FIXED TOTAL WORK" in text
+    assert_wall_clock_accounted(d)
+
+
+SECTIONS = ["weak", "data group", "exchange broadcast", "end_to_end", "exchange bands", "end_to_end_bands", "config4", "config5",
+            "exchange all_gather", "end_to_end_all_gather", "field_axis_sharding"]
+
+
+def assert_wall_clock_accounted(d: dict, skipped: bool = False) -> None:
+    """The N > 1 line says where its own wall clock went — process start to the printed line, the set-up stages before `value`, every
+    secondary section — and stays under the stated cap; the same figures are mirrored into `config` (which the driver's record keeps)."""
+    m = d["config"]["multi_gpu"]
+    for key in ("wall_s", "setup_s", "precompute_s", "sections_s", "sections_skipped", "total_seconds_cap"):
+        assert m[key] == d[key], key
+    assert m["total_seconds_cap"] == 300.0 and 0 < d["wall_s"] < m["total_seconds_cap"]  # the whole command, process start -> print
+    setup = d["setup_s"]
+    assert {"process_start_to_main", "library_device_and_host_group", "grids_and_knn_table", "plan_and_shard_bounds",
+            "source_stacks_and_tables_resident", "timed_region", "roofline_launches"} <= set(setup)
+    assert all(v >= 0 for v in setup.values()) and d["precompute_s"] <= setup["grids_and_knn_table"] + 1e-3
+    if not skipped:
+        assert d["sections_skipped"] == [] and list(d["sections_s"])[:len(SECTIONS)] == SECTIONS  # run in priority order, none dropped
+    assert all(v >= 0 for v in d["sections_s"].values())
+    # the parts add up to the whole (barriers and the JSON itself are the slack)
+    assert sum(setup.values()) + sum(d["sections_s"].values()) <= d["wall_s"] + 1.0
 
 
 def test_two_ranks_rehearsal_over_gloo():
@@ -169,6 +192,27 @@ def test_secondary_lines_cannot_cost_the_value():
     assert d["config"]["multi_gpu"]["secondary_timed_out_in"] == d["secondary_timed_out_in"]  # the cut is visible in `config` too
 
 
+def test_total_seconds_cap_skips_sections_and_keeps_the_line():
+    """`--total-seconds` below what the process has already spent: every secondary section is skipped (all ranks agree, nobody hangs),
+    the line is printed with `value`, the run ends with status 0 and says what it dropped."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", *SMALL, "--backend", "gloo", "--share-device",
+           "--total-seconds", "1"]
+    run = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert run.returncode == 0, run.stderr[-2000:]
+    d = last_json(run.stdout)
+    assert d["value"] > 0 and d["n_gpus"] == 2 and "secondary_timed_out_in" not in d and d["total_seconds_cap"] == 1.0
+    assert d["sections_skipped"][:4] == ["weak", "exchange broadcast", "end_to_end", "exchange bands"] and "config4" in d["sections_skipped"]
+    assert "skipped" in d["weak"] and "--total-seconds" in d["weak"]["skipped"] and "skipped" in d["config5"]
+    assert set(d["sections_s"]) == {"data group"}  # (bringing the group up is not a measurement: it is not skippable)
+    m = d["config"]["multi_gpu"]
+    assert m["strong"]["value"] == d["value"] and m["weak"] == {"skipped": d["weak"]["skipped"]} and m["sections_skipped"] == d["sections_skipped"]
+    assert "value" in run.stderr and "after process start" in run.stderr  # the headline's ingredients went to stderr the moment they existed
+
+
 def test_multi_gpu_sections_on_real_rccl_at_world_1():
     """Everything `bench.py --gpus N` does after `value` — the nccl data group, both exchanges, end to end, and the same through
     the C-ABI communicator — on the real collective library, at the world size one GPU allows."""
@@ -192,6 +236,7 @@ def test_multi_gpu_sections_on_real_rccl_at_world_1():
     assert c["init"]["rccl_version"] >= 20000
     for name in ("broadcast", "all_gather", "bands", "end_to_end"):
         assert c[name]["verified_bit_equal"] is True, c
+    assert {"c_abi init", "c_abi broadcast", "c_abi all_gather", "c_abi bands", "c_abi end_to_end"} <= set(d["sections_s"])
 
 
 def test_integration_md_ctypes_stub_runs(tmp_path):

@@ -560,7 +560,13 @@ def test_float64_exp_within_one_ulp_of_numpy(dev):
                 v = np.nextafter(v, np.inf if step > 0 else -np.inf)
             near.append(v)
     cases["reduction boundaries"] = np.resize(np.concatenate(near), n)
-    special = np.array([0.0, -0.0, np.inf, -np.inf, np.nan, 710.0, -746.0, 1.0, -1.0, 709.782712893384, -745.1332191019411, 1e-300, 0.5])
+    # (beyond +-1100 the routine clamps its argument before reducing it — k = rint(x log2 e) must fit an int: every magnitude between
+    # there and the largest double, and the points either side of the clamp, must still give +inf / 0; the humidity operators can produce
+    # such arguments next to the poles of their Magnus quotients, t close to 32.19 or -0.7)
+    special = np.array([0.0, -0.0, np.inf, -np.inf, np.nan, 710.0, -746.0, 1.0, -1.0, 709.782712893384, -745.1332191019411, 1e-300, 0.5,
+                        1099.0, -1099.0, 1100.0, -1100.0, np.nextafter(1100.0, np.inf), np.nextafter(-1100.0, -np.inf), 1e5, -1e5, 2.0e9, -2.0e9,
+                        3.1e9, -3.1e9, 1e12, -1e12, 2.0 ** 50, -(2.0 ** 50), 2.0 ** 51, -(2.0 ** 51), 1e300, -1e300, np.finfo(np.float64).max,
+                        -np.finfo(np.float64).max])
 
     def run(x, per_level=False, stages=(native.OP_EXP,)):
         st = Stack.from_fields(np.stack([x, x[::-1].copy()]), dev=dev)
@@ -584,7 +590,10 @@ def test_float64_exp_within_one_ulp_of_numpy(dev):
     for per_level in (False, True):
         got = run(special, per_level)
         assert np.array_equal(got[:7], want[:7], equal_nan=True), (got[:7], want[:7])  # 1, 1, inf, 0, NaN, inf, 0
-        assert np.all(np.abs(got[7:] - want[7:]) <= np.spacing(np.abs(want[7:])))
+        decided = ~np.isfinite(want) | (want == 0.0)  # overflow / total underflow: exactly numpy's +inf / 0 (NaN: the NaN)
+        assert np.array_equal(got[decided], want[decided], equal_nan=True), (special[decided], got[decided])
+        live = ~decided
+        assert np.all(np.abs(got[live] - want[live]) <= np.spacing(np.abs(want[live])))
     # sp_to_lnsp | lnsp_to_sp and back as ONE two-stage launch (what tools/kernel_bench.py times): each stage within 1 ulp of numpy's
     # function of the previous stage's OWN result is what the chain can promise, i.e. 1 ulp + the conditioning of the second function
     p = rng.uniform(3.0e4, 1.1e5, n)

@@ -18,18 +18,25 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 UNPINNED = ["uv_to_ddff", "ddff_to_uv", "r_to_d", "d_to_r", "q_to_r", "r_to_q", "q_to_r_height_with_p", "r_to_q_height_with_p"]
 
 
-def parity_warnings(caplog, name, **config):
+def parity_warnings(caplog, name, fresh=True, words=("pinned",), **config):
+    """The WARNING-level parity notes of one construction; `fresh`: as the first construction of the process (core.say_once)."""
+    from anemoi_transform_amd.core import reset_notes
+
+    if fresh:
+        reset_notes()
     caplog.clear()
-    with caplog.at_level(logging.WARNING, logger="anemoi_transform_amd"):
+    with caplog.at_level(logging.DEBUG, logger="anemoi_transform_amd"):
         create_filter_by_name(name, **config)
-    return [r.getMessage() for r in caplog.records if "pinned" in r.getMessage()]
+    return [r.getMessage() for r in caplog.records if r.levelno >= logging.WARNING and any(w in r.getMessage() for w in words)]
 
 
 @pytest.mark.parametrize("name", UNPINNED)
 def test_filters_on_restated_earthkit_meteo_arithmetic_say_so(caplog, name):
     notes = parity_warnings(caplog, name)
-    assert len(notes) == 1, notes  # once per filter instance
+    assert len(notes) == 1, notes  # said by the first instance of the class in a process ...
     assert "earthkit-meteo" in notes[0] and "reference's test points" in notes[0] and "np.allclose" in notes[0]
+    assert parity_warnings(caplog, name, fresh=False) == []  # ... and not again by the next (a pipeline that builds its filters per date)
+    assert any("earthkit-meteo" in r.getMessage() and r.levelno == logging.DEBUG for r in caplog.records)  # still there for who asks
 
 
 def test_convert_says_which_pairs_are_not_pinned(caplog):
@@ -38,10 +45,44 @@ def test_convert_says_which_pairs_are_not_pinned(caplog):
     notes = parity_warnings(caplog, "convert", unit_in="Pa", unit_out="hPa", param="sp")
     assert len(notes) == 1 and "Pa -> hPa" in notes[0] and "K <-> degC" in notes[0]
     assert ("private unit table" in notes[0]) or ("pint" in notes[0])
+    assert parity_warnings(caplog, "convert", fresh=False, unit_in="Pa", unit_out="hPa", param="sp") == []  # once per unit pair and process
+    assert len(parity_warnings(caplog, "convert", fresh=False, unit_in="hPa", unit_out="Pa", param="sp")) == 1  # another pair: its own note
+
+
+def test_convert_with_pint_installed_informs_instead_of_warning(caplog, monkeypatch):
+    """pint is the reference's own converter (R: rescale.py:94): when it supplies the factor the note is INFO, not WARNING."""
+    import sys
+    import types
+
+    class Quantity:
+        def __init__(self, x, unit):
+            self.x, self.unit = x, unit
+
+        def to(self, unit):
+            assert (self.unit, unit) == ("Pa", "hPa")
+            return types.SimpleNamespace(magnitude=self.x / 100.0)
+
+    fake = types.ModuleType("pint")
+    fake.UnitRegistry = lambda: types.SimpleNamespace(Quantity=Quantity)
+    monkeypatch.setitem(sys.modules, "pint", fake)
+    assert parity_warnings(caplog, "convert", unit_in="Pa", unit_out="hPa", param="sp") == []
+    said = [r for r in caplog.records if "K <-> degC" in r.getMessage()]
+    assert len(said) == 1 and said[0].levelno == logging.INFO and "the reference's own converter" in said[0].getMessage()
+
+
+def test_snow_cover_says_where_it_can_differ(caplog):
+    """`snow_cover` is pinned — and has a jump in its statement (R: snow_cover.py:38, `> 0.99 -> 1`) that makes the last bit of tanh
+    visible: the filter says so (once per process), README's parity table says so, tests/test_gpu_random_shapes.py holds it to that."""
+    notes = parity_warnings(caplog, "snow_cover", words=("0.99",))
+    assert len(notes) == 1 and "snow_cover.py:38" in notes[0] and "either side is the statement's own value" in notes[0]
+    assert parity_warnings(caplog, "snow_cover", fresh=False, words=("0.99",)) == []
+    readme = open(os.path.join(ROOT, "README.md")).read()
+    row = next(ln for ln in readme.splitlines() if ln.startswith("|") and "snow_cover" in ln)
+    assert "except at the jump" in row and "either side is the statement's own value" in row
 
 
 @pytest.mark.parametrize("name,config", [
-    ("rescale", dict(scale=1.0, offset=-273.15, param="2t")), ("orog_to_z", {}), ("lnsp_to_sp", {}), ("snow_cover", {}), ("cos_sin_from_rad", dict(param="mwd")),
+    ("rescale", dict(scale=1.0, offset=-273.15, param="2t")), ("orog_to_z", {}), ("lnsp_to_sp", {}), ("snow_depth_m", {}), ("cos_sin_from_rad", dict(param="mwd")),
     ("rodeo_opera_clipping", {}), ("sum", dict(params=["a", "b"], output="c")), ("regrid", dict(in_grid="O32", out_grid=[5.0, 5.0], method="nearest")),
 ])
 def test_pinned_filters_are_silent(caplog, name, config):
