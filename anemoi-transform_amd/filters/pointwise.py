@@ -171,8 +171,6 @@ class Convert(RescaleMixin, StackFieldFilter):
             # pint when it is installed, else from the private table above — say so, as `regrid`'s default route does
             # (pint IS the reference's own converter, R: rescale.py:94: with it installed this is information, not a warning; either way
             # once per unit pair and process — core.say_once — not once per construction)
-            import logging
-
             say_once(LOG, ("convert", self.unit_in, self.unit_out),
                      "convert(%s -> %s): scale %r and offset %r come from %s; only K <-> degC is pinned by the reference "
                      "(tests/field_filters/test_rescale.py), other pairs are not held to a reference vector",
