@@ -239,11 +239,12 @@ def test_config4_3288_fields_through_a_sharded_regrid_filter(o1280_n320, dev, la
     torch.cuda.empty_cache()
 
 
-def test_config4_host_list_is_regrouped_by_variable_and_cut_into_stacks(o1280_n320, dev, launches, monkeypatch):
+def test_config4_host_list_is_regrouped_by_variable_and_cut_into_stacks(o1280_n320, dev, launches, monkeypatch, tmp_path):
     """The same filter chain on fields that arrive from the HOST, level by level with four variables interleaved — 548 float32 O1280
     fields, more than one stack holds (`fields.MAX_STACK_LEVELS` = 512): the list is uploaded as "all levels of t, then q, ..."
     (`fields._variables_together`), cut into two stacks that share one batched launch... and, with `convert` on `t` and `clip` on `q`
-    behind a sharded regrid, into one fused launch per stack.  Every field against the filter-by-filter run, samples against the oracle."""
+    and `apply_mask` with a FULL-grid mask file on `u` and `t` behind a sharded regrid, into one fused launch per stack (four stages, a point mask windowed to the rank's
+    slice).  Every field against the filter-by-filter run, samples against the oracle."""
     from anemoi_transform_amd import fields as fields_mod
 
     case = o1280_n320
@@ -260,10 +261,16 @@ def test_config4_host_list_is_regrouped_by_variable_and_cut_into_stacks(o1280_n3
     fields = fieldlist_from_dicts(specs)
     assert len(fields) == 548 > fields_mod.MAX_STACK_LEVELS
 
+    # a FULL-grid point mask behind a sharded regrid: the fields know their window of the target grid and the mask is cut to it
+    mask_full = np.random.default_rng(549).random(case["n_tgt"]) < 0.25
+    mask_path = str(tmp_path / "target-mask.npy")
+    np.save(mask_path, mask_full.astype(np.float64))
+
     def pipeline():
         return (create_filter_by_name("regrid", matrix=case["path"], shard=(3, 8)) | create_filter_by_name("orog_to_z")
                 | create_filter_by_name("convert", unit_in="K", unit_out="degC", param="t")
-                | create_filter_by_name("clip", param="q", minimum=280.0, maximum=300.0))
+                | create_filter_by_name("clip", param="q", minimum=280.0, maximum=300.0)
+                | create_filter_by_name("apply_mask", path=mask_path, mask_value=1, param=["u", "t"]))
 
     before = dict(launches)
     fused = pipeline().forward(fields)
@@ -292,5 +299,8 @@ def test_config4_host_list_is_regrouped_by_variable_and_cut_into_stacks(o1280_n3
             want = oracle.clip(full, np.float32(280.0), np.float32(300.0))
         else:
             want = full
+        if name in ("u", "t"):  # R: apply_mask.py:185 `values[self.mask] = np.nan`, on this rank's window of the mask
+            want = oracle.apply_mask_values(want.copy(), mask_full[lo:hi])
+            assert np.isnan(want).sum() == mask_full[lo:hi].sum() > 0
         got = fused[pos].to_numpy()
-        assert got.dtype == np.float32 and np.array_equal(got, want), (pos, name)
+        assert got.dtype == np.float32 and np.array_equal(got, want, equal_nan=True), (pos, name)
