@@ -620,8 +620,9 @@ def multi_gpu_lines(args, result, dist, rank, world, dev, plan, stacks, launch, 
             os.write(real_stdout_fd, (json.dumps(result) + "\n").encode())  # fd 1 points at stderr in here
         os._exit(3)  # the measured line is out, but a collective that never returned is a FAILURE of the run: the launcher must see it
 
-    # the hard limit (a collective that never returns): the secondary budget, and never later than half a cap past the cap
-    watchdog = threading.Timer(max(0.0, min(args.secondary_seconds, 1.5 * args.total_seconds - wall_seconds())), give_up)
+    # the hard limit (a collective that never returns): the secondary budget, and no later than half a cap past the cap — but never less
+    # than a minute from here: a run that is ALREADY past its cap skips every section, which still takes a few barrier round trips
+    watchdog = threading.Timer(max(0.0, min(args.secondary_seconds, max(60.0, 1.5 * args.total_seconds - wall_seconds()))), give_up)
     watchdog.daemon = True
     watchdog.start()
 
