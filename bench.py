@@ -246,6 +246,7 @@ def mirror_multi_gpu_into_config(result: dict) -> None:
         # the wall clock of the command (seconds, max over ranks): where the time of an N-rank run goes, and what was dropped to stay under the cap
         "wall_s": result.get("wall_s"),
         "setup_s": result.get("setup_s"),
+        "setup_s_rank": result.get("setup_s_rank"),
         "precompute_s": result.get("precompute_s"),
         "sections_s": result.get("sections_s"),
         "sections_skipped": result.get("sections_skipped"),
@@ -529,11 +530,16 @@ def main():
     }
     mark("roofline_launches")
     if multi:
-        # where the wall clock of an N-rank command goes before the secondary sections start (seconds, max over ranks per entry)
+        # where the wall clock of an N-rank command goes before the secondary sections start: the stage times of the rank that took
+        # LONGEST to get here, as that rank saw them (an entry-by-entry maximum would count a slow rank's stage and the others' wait
+        # for it at the next barrier twice)
         keys = sorted(setup_s)
-        t_setup = torch.tensor([setup_s[k] for k in keys], dtype=torch.float64)
-        dist.all_reduce(t_setup, op=dist.ReduceOp.MAX)
-        setup_s = {k: round(float(v), 3) for k, v in zip(keys, t_setup.tolist())}
+        mine = torch.tensor([setup_s[k] for k in keys], dtype=torch.float64)
+        every = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(every, mine)
+        slowest = max(range(world), key=lambda r: float(every[r].sum()))
+        setup_s = {k: round(float(v), 3) for k, v in zip(keys, every[slowest].tolist())}
+        result["setup_s_rank"] = slowest
     result["setup_s"] = setup_s
     result["total_seconds_cap"] = args.total_seconds if multi else None
 
@@ -613,12 +619,22 @@ def multi_gpu_lines(args, result, dist, rank, world, dev, plan, stacks, launch, 
     state = {"section": "start"}
 
     def give_up():
-        if rank == 0:
-            result["secondary_timed_out_in"] = state["section"]
-            result["wall_s"] = wall_seconds()  # (this rank's clock: nobody waits for the others any more)
-            mirror_multi_gpu_into_config(result)
-            os.write(real_stdout_fd, (json.dumps(result) + "\n").encode())  # fd 1 points at stderr in here
-        os._exit(3)  # the measured line is out, but a collective that never returned is a FAILURE of the run: the launcher must see it
+        try:
+            if rank == 0:
+                payload = None
+                for _ in range(50):  # the main thread may be adding a key to `result` this very moment: serialise a consistent view
+                    try:
+                        result["secondary_timed_out_in"] = state["section"]
+                        result["wall_s"] = wall_seconds()  # (this rank's clock: nobody waits for the others any more)
+                        mirror_multi_gpu_into_config(result)
+                        payload = json.dumps(result)
+                        break
+                    except RuntimeError:  # "dictionary changed size during iteration"
+                        time.sleep(0.01)
+                if payload is not None:
+                    os.write(real_stdout_fd, (payload + "\n").encode())  # fd 1 points at stderr in here
+        finally:
+            os._exit(3)  # the measured line is out, but a collective that never returned is a FAILURE of the run: the launcher must see it
 
     # the hard limit (a collective that never returns): the secondary budget, and no later than half a cap past the cap — but never less
     # than a minute from here: a run that is ALREADY past its cap skips every section, which still takes a few barrier round trips

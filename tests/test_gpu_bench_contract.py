@@ -110,7 +110,8 @@ def assert_wall_clock_accounted(d: dict, skipped: bool = False) -> None:
     """The N > 1 line says where its own wall clock went — process start to the printed line, the set-up stages before `value`, every
     secondary section — and stays under the stated cap; the same figures are mirrored into `config` (which the driver's record keeps)."""
     m = d["config"]["multi_gpu"]
-    for key in ("wall_s", "setup_s", "precompute_s", "sections_s", "sections_skipped", "total_seconds_cap"):
+    assert 0 <= d["setup_s_rank"] < d["n_gpus"]  # (the set-up stages are the slowest rank's own)
+    for key in ("wall_s", "setup_s", "setup_s_rank", "precompute_s", "sections_s", "sections_skipped", "total_seconds_cap"):
         assert m[key] == d[key], key
     assert m["total_seconds_cap"] == 300.0 and 0 < d["wall_s"] < m["total_seconds_cap"]  # the whole command, process start -> print
     setup = d["setup_s"]
