@@ -161,7 +161,9 @@ class GatherPlan:
             if n_src is None:
                 raise ValueError("an integer mask needs the number of source points")
             index = mask.reshape(-1)
-            if index.size and index.dtype.kind in "iu" and (int(index.min()) < -n_src or int(index.max()) >= n_src):
+            if index.dtype.kind not in "iu":  # numpy's own refusal of `data[..., np.array([1.0, 2.0])]`
+                raise IndexError("arrays used as indices must be of integer (or boolean) type")
+            if index.size and (int(index.min()) < -n_src or int(index.max()) >= n_src):
                 # R: regrid.py:420 `data[..., self.mask]` — numpy's own error for an index list made for another grid
                 bad = int(index.max()) if int(index.max()) >= n_src else int(index.min())
                 raise IndexError(f"index {bad} is out of bounds for axis 0 with size {n_src}")

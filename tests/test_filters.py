@@ -513,6 +513,10 @@ def test_regrid_wrong_field_size_raises_what_the_reference_raises(engine):
         list(source | create_filter_by_name("regrid", mask=np.zeros(n_other, dtype=bool)))
     with pytest.raises(IndexError):
         list(source | create_filter_by_name("regrid", mask=np.array([0, n_other - 1])))
+    with pytest.raises(IndexError, match="integer"):  # numpy: "arrays used as indices must be of integer (or boolean) type"
+        np.zeros(n_src)[..., np.array([0.0, 1.0])]
+    with pytest.raises(IndexError, match="integer"):
+        list(source | create_filter_by_name("regrid", mask=np.array([0.0, 1.0])))
     # and the right sizes go through
     assert len(list(test_source(synthetic_fields(other, 2)) | create_filter_by_name("regrid", matrix=matrix))) == 2
 
