@@ -221,10 +221,6 @@ static unsigned blocks_for(int64_t n) {
     return (unsigned)(b < 1 ? 1 : b);
 }
 
-}  // namespace atx
-
-using namespace atx;
-
 // ---- cutout mask: ray / triangle tests for every global point -------------------------------
 // np.cross / np.dot of 3-vectors as the reference's per-point loop evaluates them (R: spatial.py:211-231).  np.cross is numpy
 // ufuncs: products and differences, each rounded (no contraction).  np.dot of two 1-D arrays is cblas_ddot, and the x86-64
@@ -276,6 +272,10 @@ cutout_inside_kernel(const double* __restrict__ g, int64_t n, const double* __re
     }
     inside[i] = hit ? 1 : 0;
 }
+
+}  // namespace atx
+
+using namespace atx;
 
 extern "C" int atx_cutout_inside(const double* global_xyz, int64_t n, const double* lam_xyz, int64_t n_lam,
                                  const int32_t* neighbours, int32_t k, uint8_t* inside, void* stream) {
