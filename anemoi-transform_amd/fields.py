@@ -627,12 +627,18 @@ def group_into_stacks(fields: Iterable[Any], positions: list[int] | None = None,
     fields = list(fields)
     wanted = range(len(fields)) if positions is None else positions
     buckets: dict[Any, list[int]] = {}
+    host_arrays: dict[int, np.ndarray] = {}
     for i in wanted:
         ref = fields[i].stack_ref() if isinstance(fields[i], Field) else None
         if ref is not None:
             key = ("hbm", id(ref[0]))
         else:
-            key = ("host", int(np.prod(fields[i].shape)))
+            # the width of a field is its OWN (float32 stays float32, everything else is float64 — the dtype rule of DESIGN.md §4):
+            # float32 and float64 fields of one grid go into two stacks, so that what a field comes out as never depends on which
+            # other fields a filter happened to select with it (fused or filter by filter)
+            host_arrays[i] = host_values(fields[i])
+            narrow = _upload_dtype is None and host_arrays[i].dtype == np.float32
+            key = ("host", int(host_arrays[i].size), narrow)
         buckets.setdefault(key, []).append(i)
 
     groups = []
@@ -647,7 +653,7 @@ def group_into_stacks(fields: Iterable[Any], positions: list[int] | None = None,
                 groups.append(StackGroup(select_levels(stack, levels), members, group_fields))
         else:
             members, group_fields = _variables_together(members, group_fields)
-            arrays = [host_values(f) for f in group_fields]
+            arrays = [host_arrays[i] for i in members]
             dtype = _host_dtype(arrays)
             # long lists (config 4: thousands of fields on one grid) become several stacks of at most MAX_STACK_LEVELS:
             # the operator tables of an 8-stage program then always fit the kernels' shared memory, the staging chunks

@@ -175,6 +175,10 @@ class RemoveNaNs(Filter):
             self._prepare(fields)
         out: list[Any] = [None] * len(fields)
         for group in group_into_stacks(fields):
+            if group.stack.n_pts != self._plan.n_src:
+                # R: remove_nans.py:113 `data[self._mask]` — numpy's own refusal of a field on another grid than the first one
+                raise IndexError(f"boolean index did not match indexed array along axis 0; size of axis is {group.stack.n_pts} "
+                                 f"but size of corresponding boolean axis is {self._plan.n_src}")
             compressed = self._plan.apply(group.stack)
             for level, (pos, f) in enumerate(zip(group.positions, group.fields)):
                 out[pos] = new_field_from_stack(

@@ -236,6 +236,18 @@ def test_remove_nans(engine, rn_source):
         assert fo.metadata("step") == i  # everything else is inherited from the input field
 
 
+def test_remove_nans_field_on_another_grid_raises_numpys_error(engine):
+    """R: remove_nans.py:113 `data[self._mask]`: the mask comes from the FIRST field; a later field on another grid fails numpy's
+    boolean indexing with IndexError — here before any launch."""
+    from anemoi_transform_amd.grids import lookup
+
+    with pytest.raises(IndexError, match="boolean index did not match"):
+        np.zeros(7)[np.ones(5, dtype=bool)]
+    specs = synthetic_fields(lookup("o16"), 2, nan_frac=0.1) + synthetic_fields(lookup("o8"), 1)
+    with pytest.raises(IndexError, match="boolean index did not match"):
+        list(test_source(specs) | create_filter_by_name("remove_nans"))
+
+
 def test_remove_nans_invalid_method():
     with pytest.raises(AssertionError, match="Method invalid_method not implemented"):
         create_filter_by_name("remove_nans", method="invalid_method")
