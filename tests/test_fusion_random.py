@@ -9,7 +9,8 @@ by variable, shuffled), one or two source grids in one list, NaNs, host or devic
 the levels of one stack), the head of the pipeline (none / nearest / k = 4 matrix / index mask, whole or one shard of 2-3), and a
 tail of 1-6 filters drawn from the per-point family (fusable), a stream-mask `apply_mask` and `remove_nans` (which cut a fused
 segment).  Held: same length, same order, same `param` / `levelist` / `units`, same values bit for bit (NaNs in the same places),
-same grid points, same target window.  `ATX_FUSION_SEEDS=first:count` widens the sweep for a soak.
+same grid points, same target window — and, for host float64 lists behind an unsharded head, the same fields as the ORACLE's
+filter-level restatements of the reference (`oracle.filter_*`) chained the same way.  `ATX_FUSION_SEEDS=first:count` widens the sweep for a soak.
 """
 
 from __future__ import annotations
@@ -24,6 +25,7 @@ from anemoi_transform_amd import interp
 from anemoi_transform_amd.fields import FieldList
 from anemoi_transform_amd.filters import create_filter_by_name
 from anemoi_transform_amd.grids import lookup
+from oracle import oracle
 
 import native_double
 from test_filters import test_source
@@ -143,6 +145,46 @@ def describe(f):
             f.target_range() if hasattr(f, "target_range") else None)
 
 
+def oracle_chain(specs, head, tail, src, tgt, tables):
+    """The same pipeline on the oracle's filter-level restatements of the reference (oracle/oracle.py `filter_*`), or None when a
+    stage has none (rename) or the head is sharded."""
+    fields = [dict(s) for s in specs]
+    if head is not None:
+        if "shard" in head:
+            return None
+        if "method" in head:
+            fields = oracle.filter_regrid_nearest(fields, in_grid=src, out_grid=tgt)
+        elif "matrix" in head:
+            fields = oracle.filter_regrid_matrix(fields, matrix=tables["matrix"])
+        else:
+            fields = oracle.filter_regrid_mask(fields, mask=head["mask"])
+    for name, cfg in tail:
+        if name == "rescale":
+            fields = oracle.filter_rescale(fields, **cfg)
+        elif name == "convert":
+            fields = [dict(f, units="degC") if f.get("param") == "t" else f for f in oracle.filter_rescale(fields, scale=1.0, offset=-273.15, param="t")]
+        elif name in ("orog_to_z", "orog_to_z_fields"):
+            fields = oracle.filter_orog_to_z(fields)
+        elif name == "z_to_orog":
+            fields = oracle.filter_orog_to_z(fields, backward=True)
+        elif name == "clip":
+            fields = oracle.filter_clip(fields, **cfg)
+        elif name == "impute_nans":
+            fields = oracle.filter_impute_nans(fields, **cfg)
+        elif name == "lnsp_to_sp":
+            fields = oracle.filter_lnsp_to_sp(fields)
+        elif name == "apply_mask":
+            fields = oracle.filter_apply_mask(fields, mask_values=np.load(cfg["path"]), mask_value=cfg["mask_value"], param=cfg["param"],
+                                              rename=cfg.get("rename"))
+        elif name == "remove_nans":
+            fields = oracle.filter_remove_nans(fields)
+        elif name == "noop":
+            pass
+        else:
+            return None
+    return fields
+
+
 @pytest.mark.parametrize("seed", SEEDS)
 def test_fused_pipeline_equals_filter_by_filter(engine, seed, tmp_path, monkeypatch):
     rng = np.random.default_rng(90_000 + seed)
@@ -169,7 +211,8 @@ def test_fused_pipeline_equals_filter_by_filter(engine, seed, tmp_path, monkeypa
         monkeypatch.setattr(fields_mod, "MAX_STACK_LEVELS", 4)  # long lists in several stacks
 
     data = test_source(specs).ds
-    if head is not None and rng.random() < 0.35:
+    device_input = head is not None and rng.random() < 0.35
+    if device_input:
         # device-resident input: the fields become levels of ONE stack (a first nearest-neighbour regrid onto their own grid), then a
         # re-ordered subset of them is handed on
         on_device = list(create_filter_by_name("regrid", in_grid=src, out_grid=src, method="nearest").forward(data))
@@ -204,3 +247,25 @@ def test_fused_pipeline_equals_filter_by_filter(engine, seed, tmp_path, monkeypa
         assert va.dtype == vb.dtype and np.array_equal(va, vb, equal_nan=True), (what, i, a.metadata("param"))
         assert np.array_equal(np.signbit(va), np.signbit(vb)), (what, i)
         assert np.array_equal(a.grid_points()[0], b.grid_points()[0]) and np.array_equal(a.grid_points()[1], b.grid_points()[1]), (what, i)
+
+    # third leg: the oracle's restatement of the reference's filters, chained the same way (host float64 lists, unsharded heads)
+    if device_input or any(s["values"].dtype != np.float64 for s in specs):
+        return
+    try:
+        want = oracle_chain(specs, head, tail, src, tgt, tables)
+    except Exception as e:  # noqa: BLE001
+        raise AssertionError(f"the oracle refuses what the engine accepted: {type(e).__name__}: {e}; {what}") from e
+    if want is None:
+        return
+    assert len(want) == len(fused), what
+    for i, (a, w_) in enumerate(zip(fused, want)):
+        assert a.metadata("param") == w_["param"], (what, i)
+        got, ref = a.to_numpy(flatten=True), np.asarray(w_["values"]).ravel()
+        assert got.shape == ref.shape, (what, i)
+        if any(n == "lnsp_to_sp" for n, _ in tail) and w_["param"] == "sp":
+            with np.errstate(all="ignore"):  # exp: <= 1 ulp from numpy's (tests/test_gpu_kernels.py), and whatever follows it in the chain
+                close = np.isclose(got, ref, rtol=1e-14, atol=0.0, equal_nan=True) | (np.isinf(got) & np.isinf(ref))
+            assert close.all(), (what, i)
+        else:
+            assert np.array_equal(got, ref, equal_nan=True), (what, i, w_["param"])
+        assert np.array_equal(a.grid_points()[0], np.asarray(w_["latitudes"])) and np.array_equal(a.grid_points()[1], np.asarray(w_["longitudes"])), (what, i)
