@@ -135,7 +135,7 @@ __global__ void __launch_bounds__(kBlock) stream_copy_kernel(const Bytes16* __re
 
 extern "C" int atx_stream_copy(const void* src, void* dst, int64_t n_bytes, void* stream) {
     using namespace atx;
-    ATX_REQUIRE(src && dst, ATX_EINVAL, "atx_stream_copy: null pointer");
+    ATX_REQUIRE((src && dst) || n_bytes == 0, ATX_EINVAL, "atx_stream_copy: null pointer");
     ATX_REQUIRE(n_bytes >= 0 && n_bytes % 16 == 0, ATX_EINVAL, "atx_stream_copy: n_bytes=%lld is not a multiple of 16", (long long)n_bytes);
     ATX_REQUIRE(aligned16(src) && aligned16(dst), ATX_EALIGN, "atx_stream_copy: pointers must be 16-byte aligned");
     const int64_t n = n_bytes / 16;

@@ -592,11 +592,11 @@ extern "C" int atx_combine_stack(int op, const void* const* inputs, int32_t n_in
     ATX_REQUIRE(level_param || !reads_param, ATX_EINVAL, "atx_combine_stack: operator %d needs level_param", op);
     CombArgs a{};
     for (int k = 0; k < n_in; ++k) {
-        ATX_REQUIRE(inputs[k], ATX_EINVAL, "atx_combine_stack: null input %d", k);
+        ATX_REQUIRE(inputs[k] || n_pts == 0, ATX_EINVAL, "atx_combine_stack: null input %d", k);  // (an empty stack may have no storage)
         a.in[k] = inputs[k];
     }
     for (int k = 0; k < n_out; ++k) {
-        ATX_REQUIRE(outputs[k], ATX_EINVAL, "atx_combine_stack: null output %d", k);
+        ATX_REQUIRE(outputs[k] || n_pts == 0, ATX_EINVAL, "atx_combine_stack: null output %d", k);
         a.out[k] = outputs[k];
     }
     if (n_pts == 0) return ATX_OK;

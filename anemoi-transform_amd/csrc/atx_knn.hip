@@ -279,7 +279,7 @@ using namespace atx;
 
 extern "C" int atx_cutout_inside(const double* global_xyz, int64_t n, const double* lam_xyz, int64_t n_lam,
                                  const int32_t* neighbours, int32_t k, uint8_t* inside, void* stream) {
-    ATX_REQUIRE(global_xyz && lam_xyz && neighbours && inside, ATX_EINVAL, "atx_cutout_inside: null pointer");
+    ATX_REQUIRE(lam_xyz && ((global_xyz && neighbours && inside) || n == 0), ATX_EINVAL, "atx_cutout_inside: null pointer");
     ATX_REQUIRE(n >= 0 && n_lam > 0 && k >= 1 && k <= kMaxK, ATX_EINVAL, "atx_cutout_inside: bad sizes (n=%lld, n_lam=%lld, k=%d)",
                 (long long)n, (long long)n_lam, k);
     if (n == 0) return ATX_OK;

@@ -1313,7 +1313,7 @@ extern "C" int atx_pointwise_stack(const void* x, void* y, int64_t n_pts, int64_
                                    int64_t y_pitch, int dtype, int layout, const atx_level_op* prog,
                                    const atx_level_op* vec_prog, const atx_level_op* host_prog, int32_t n_stage,
                                    const uint8_t* point_mask, void* stream) {
-    ATX_REQUIRE(x && y && prog, ATX_EINVAL, "atx_pointwise_stack: null pointer");
+    ATX_REQUIRE(prog && ((x && y) || n_pts == 0), ATX_EINVAL, "atx_pointwise_stack: null pointer");  // (an empty stack may have no storage)
     ATX_REQUIRE(dtype == ATX_F32 || dtype == ATX_F64, ATX_EINVAL, "atx_pointwise_stack: bad dtype %d", dtype);
     ATX_REQUIRE(layout == ATX_COLUMNS || layout == ATX_FIELDS, ATX_EINVAL, "atx_pointwise_stack: bad layout %d", layout);
     ATX_REQUIRE(n_pts >= 0 && n_lev > 0 && n_lev <= 65535, ATX_EINVAL, "atx_pointwise_stack: bad sizes n_pts=%lld n_lev=%lld",
@@ -1340,7 +1340,7 @@ extern "C" int atx_pointwise_stack(const void* x, void* y, int64_t n_pts, int64_
 
 extern "C" int atx_mask_build(const void* m, int64_t m_stride, uint8_t* mask, int64_t n, int cmp, double threshold,
                               int dtype, void* stream) {
-    ATX_REQUIRE(m && mask, ATX_EINVAL, "atx_mask_build: null pointer");
+    ATX_REQUIRE((m && mask) || n == 0, ATX_EINVAL, "atx_mask_build: null pointer");
     ATX_REQUIRE(n >= 0 && m_stride >= 1, ATX_EINVAL, "atx_mask_build: bad n=%lld / stride=%lld", (long long)n, (long long)m_stride);
     ATX_REQUIRE(cmp >= ATX_CMP_GT && cmp <= ATX_CMP_ISNAN, ATX_EINVAL, "atx_mask_build: bad comparison %d", cmp);
     ATX_REQUIRE(dtype == ATX_F32 || dtype == ATX_F64, ATX_EINVAL, "atx_mask_build: bad dtype %d", dtype);
@@ -1357,7 +1357,7 @@ extern "C" int atx_mask_build(const void* m, int64_t m_stride, uint8_t* mask, in
 }
 
 extern "C" int atx_mask_count(const uint8_t* mask, int64_t n, int64_t* count, void* stream) {
-    ATX_REQUIRE(mask && count, ATX_EINVAL, "atx_mask_count: null pointer");
+    ATX_REQUIRE(count && (mask || n == 0), ATX_EINVAL, "atx_mask_count: null pointer");
     ATX_REQUIRE(n >= 0, ATX_EINVAL, "atx_mask_count: negative n");
     hipStream_t s = static_cast<hipStream_t>(stream);
     int st = hip_status(hipMemsetAsync(count, 0, sizeof(int64_t), s), "atx_mask_count memset");
@@ -1377,7 +1377,7 @@ extern "C" size_t atx_mask_to_index_workspace(int64_t n) {
 
 extern "C" int atx_mask_to_index(const uint8_t* mask, int64_t n, int32_t* index, int64_t* count, void* workspace,
                                  size_t workspace_bytes, void* stream) {
-    ATX_REQUIRE(mask && index && count && workspace, ATX_EINVAL, "atx_mask_to_index: null pointer");
+    ATX_REQUIRE(count && workspace && ((mask && index) || n == 0), ATX_EINVAL, "atx_mask_to_index: null pointer");
     ATX_REQUIRE(n >= 0 && n <= INT32_MAX, ATX_EINVAL, "atx_mask_to_index: n=%lld outside int32", (long long)n);
     ATX_REQUIRE(workspace_bytes >= atx_mask_to_index_workspace(n), ATX_EWORKSPACE, "atx_mask_to_index: workspace %zu < %zu",
                 workspace_bytes, atx_mask_to_index_workspace(n));

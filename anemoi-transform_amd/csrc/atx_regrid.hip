@@ -93,7 +93,7 @@ static int validate_table(const char* fn, const char* what, const int32_t* idx, 
 
 static int check_stack_args(const char* fn, const void* src, const void* out, int64_t n_src, int64_t n_tgt,
                             int64_t n_lev, int64_t sp, int64_t op, int dtype, int layout) {
-    ATX_REQUIRE(src && out, ATX_EINVAL, "%s: null src/out pointer", fn);
+    ATX_REQUIRE(src && (out || n_tgt == 0), ATX_EINVAL, "%s: null src/out pointer", fn);  // (an output of zero targets may have no storage)
     ATX_REQUIRE(dtype == ATX_F32 || dtype == ATX_F64, ATX_EINVAL, "%s: bad dtype %d", fn, dtype);
     ATX_REQUIRE(layout == ATX_COLUMNS || layout == ATX_FIELDS, ATX_EINVAL, "%s: bad layout %d", fn, layout);
     ATX_REQUIRE(n_src > 0 && n_tgt >= 0 && n_lev > 0, ATX_EINVAL, "%s: bad sizes n_src=%lld n_tgt=%lld n_lev=%lld", fn,
@@ -131,7 +131,7 @@ static int regrid_ell_common(const char* fn, const void* const* srcs, void* cons
         int st = check_stack_args(fn, srcs[i], outs[i], n_src, n_tgt, n_lev, src_pitch, out_pitch, dtype, layout);
         if (st != ATX_OK) return st;
     }
-    ATX_REQUIRE(idx, ATX_EINVAL, "%s: null idx", fn);
+    ATX_REQUIRE(idx || n_tgt == 0, ATX_EINVAL, "%s: null idx", fn);
     ATX_REQUIRE(k >= 1 && k <= 64, ATX_EINVAL, "%s: k=%d outside [1, 64]", fn, k);
     ATX_REQUIRE(w || k == 1, ATX_EINVAL, "%s: a pure gather (w == NULL) needs k == 1, got %d", fn, k);
     ATX_REQUIRE((flags & ~ATX_ELL_PADDED) == 0, ATX_EINVAL, "%s: unknown flags 0x%x", fn, flags);
@@ -212,7 +212,7 @@ static int regrid_csr_common(const char* fn, const void* src, void* out, const i
                              int32_t n_stage, const uint8_t* tgt_mask, const int32_t* tgt_rows, void* stream) {
     int st = check_stack_args(fn, src, out, n_src, n_tgt, n_lev, src_pitch, out_pitch, dtype, layout);
     if (st != ATX_OK) return st;
-    ATX_REQUIRE(indptr, ATX_EINVAL, "%s: null indptr", fn);
+    ATX_REQUIRE(indptr || n_tgt == 0, ATX_EINVAL, "%s: null indptr", fn);
     ATX_REQUIRE(nnz >= 0 && nnz <= INT32_MAX, ATX_ENOTIMPL, "%s: nnz=%lld outside int32", fn, (long long)nnz);
     ATX_REQUIRE(nnz == 0 || (indices && data), ATX_EINVAL, "%s: null indices/data", fn);
     ATX_REQUIRE((prog == nullptr) == (n_stage == 0) && n_stage >= 0 && n_stage <= 8, ATX_EINVAL,
@@ -257,7 +257,7 @@ extern "C" int atx_regrid_csr_ordered(const void* src, void* out, const int32_t*
 }
 
 extern "C" int atx_check_indices(const int32_t* idx, int64_t n, int64_t n_src, int64_t* n_bad, void* stream) {
-    ATX_REQUIRE(idx && n_bad, ATX_EINVAL, "atx_check_indices: null pointer");
+    ATX_REQUIRE(n_bad && (idx || n == 0), ATX_EINVAL, "atx_check_indices: null pointer");
     ATX_REQUIRE(n >= 0 && n_src >= 0, ATX_EINVAL, "atx_check_indices: negative size");
     hipStream_t s = static_cast<hipStream_t>(stream);
     int st = hip_status(hipMemsetAsync(n_bad, 0, sizeof(int64_t), s), "atx_check_indices memset");

@@ -434,7 +434,7 @@ using namespace atx;
 
 extern "C" int atx_select_levels(const void* src, void* dst, const int32_t* level_map, int32_t n_map, int64_t n_pts,
                                  int64_t n_src_lev, int64_t src_pitch, int64_t dst_pitch, int dtype, int layout, void* stream) {
-    ATX_REQUIRE(src && dst && (level_map || n_map == 0), ATX_EINVAL, "atx_select_levels: null pointer");
+    ATX_REQUIRE(((src && dst) || n_pts == 0 || n_map == 0) && (level_map || n_map == 0), ATX_EINVAL, "atx_select_levels: null pointer");  // (an empty stack may have no storage)
     ATX_REQUIRE(dtype == ATX_F32 || dtype == ATX_F64, ATX_EINVAL, "atx_select_levels: bad dtype %d", dtype);
     ATX_REQUIRE(layout == ATX_COLUMNS || layout == ATX_FIELDS, ATX_EINVAL, "atx_select_levels: bad layout %d", layout);
     ATX_REQUIRE(n_pts >= 0 && n_map >= 0 && n_src_lev > 0, ATX_EINVAL, "atx_select_levels: bad sizes");
@@ -451,8 +451,8 @@ extern "C" int atx_select_levels(const void* src, void* dst, const int32_t* leve
 
 extern "C" int atx_relayout(const void* src, void* dst, int64_t n_pts, int64_t n_lev, int64_t src_pitch,
                             int64_t dst_pitch, int src_layout, int dst_layout, int dtype, void* stream) {
-    ATX_REQUIRE(src && dst, ATX_EINVAL, "atx_relayout: null pointer");
-    ATX_REQUIRE(src != dst, ATX_EINVAL, "atx_relayout: in-place relayout is not supported");
+    ATX_REQUIRE((src && dst) || n_pts == 0, ATX_EINVAL, "atx_relayout: null pointer");  // (an empty stack may have no storage)
+    ATX_REQUIRE(src != dst || n_pts == 0, ATX_EINVAL, "atx_relayout: in-place relayout is not supported");
     ATX_REQUIRE(dtype == ATX_F32 || dtype == ATX_F64, ATX_EINVAL, "atx_relayout: bad dtype %d", dtype);
     ATX_REQUIRE((src_layout == ATX_COLUMNS || src_layout == ATX_FIELDS) && (dst_layout == ATX_COLUMNS || dst_layout == ATX_FIELDS),
                 ATX_EINVAL, "atx_relayout: bad layout (%d, %d)", src_layout, dst_layout);

@@ -13,7 +13,10 @@
  *  - Plain C types only.  Every pointer named in a signature is a DEVICE
  *    pointer (HBM) unless the comment says "host".  The caller owns every
  *    buffer; the library allocates nothing and keeps no state besides a
- *    thread-local error string.
+ *    thread-local error string.  A buffer of ZERO elements — a stack of no
+ *    points, the output of a regrid to no targets — may have no storage: its
+ *    pointer may be NULL, the call validates the rest, does nothing and
+ *    returns ATX_OK (allocators hand out NULL for empty tensors).
  *  - `stream` is a hipStream_t passed as void* (NULL = the null stream).
  *    Calls enqueue work and return without synchronising.
  *  - Return value: ATX_OK (0) or a negative ATX_E* code; atx_last_error()
@@ -65,7 +68,9 @@
 extern "C" {
 #endif
 
-#define ATX_VERSION 420 /* 0.4.2 — round 5: no signature, enum or layout changed.  The float64 library functions are the library's own routines now
+#define ATX_VERSION 420 /* 0.4.2 — round 6: nothing changed but two relaxations — the declarations carry ATX_API (the library exports nothing else),
+                           * and zero-element buffers may be NULL (see Conventions).
+                           * round 5: no signature, enum or layout changed.  The float64 library functions are the library's own routines now
                            * (ATX_OP_EXP, ATX_OP_LOG, the tanh of ATX_COMB_SNOW_COVER, the polynomials of ATX_COMB_COS_SIN): results may differ from 0.4.1 in the
                            * last bit and stay within 1 ulp (exp, log), 2 ulp (cos, sin) and 4 ulp (tanh) of numpy's, as before.
                            * 0.4.1 — eight more multi-input operators (ATX_COMB_OPERA_CLIP .. ATX_COMB_R_TO_Q); nothing else changed.

@@ -483,6 +483,16 @@ def test_abi_argument_validation_without_a_gpu():
     assert lib.atx_mask_build(one, 1, one, 8, 99, 0.0, 0, None) == native.EINVAL
     assert lib.atx_relayout(one, one, 8, 4, 4, 8, 0, 1, 0, None) == native.EINVAL  # in place
     assert lib.atx_mask_to_index_workspace(4096 * 3) >= 16
+    # a buffer of ZERO elements may have no storage (allocators hand out NULL for empty tensors): validated, nothing done, ATX_OK
+    assert lib.atx_relayout(None, None, 0, 4, 4, 0, 0, 1, 0, None) == native.OK
+    assert lib.atx_relayout(None, None, 1, 4, 4, 1, 0, 1, 0, None) == native.EINVAL  # ... but one point needs its storage
+    assert lib.atx_select_levels(None, None, None, 0, 0, 4, 4, 0, 0, 0, None) == native.OK
+    assert lib.atx_pointwise_stack(None, None, 0, 4, 4, 4, 0, 0, one, None, None, 1, None, None) == native.OK
+    assert lib.atx_pointwise_stack(None, None, 0, 4, 4, 4, 0, 0, None, None, None, 1, None, None) == native.EINVAL  # the program is never optional
+    assert lib.atx_mask_build(None, 1, None, 0, 0, 0.0, 0, None) == native.OK
+    assert lib.atx_stream_copy(None, None, 0, None) == native.OK and lib.atx_stream_copy(None, None, 16, None) == native.EINVAL
+    assert lib.atx_regrid_ell(one, None, None, None, 8, 0, 1, 4, 4, 4, 0, 0, 0, None, None, None, 0, None, None) == native.OK  # no targets
+    assert lib.atx_regrid_ell(one, None, one, None, 8, 1, 1, 4, 4, 4, 0, 0, 0, None, None, None, 0, None, None) == native.EINVAL
     # collective entry points: argument checks come before RCCL or HIP are touched
     assert lib.atx_bcast(None, one, 16, 0, None) == native.EINVAL and b"communicator" in lib.atx_last_error()
     assert lib.atx_comm_init(None, 1, 0, one) == native.EINVAL
