@@ -1,0 +1,144 @@
+"""Randomised test of the multi-input filter family (`MatchingFieldsFilter` / `GroupByParam`, R: filters/fields/matching.py:155-246,
+grouping/__init__.py:55-137) — snow depth / cover, cos-sin of radians (and back) and of wave directions, w <-> wz —
+on random FieldLists: several dates and levels, members in any order, bystander fields mixed in, with and without a MARS namespace.
+
+The engine evaluates ALL groups of a list in one `atx_combine_stack` launch per grid (`filters/multi.py: combine_groups`); the
+reference handles one group at a time.  The test restates the reference's loop independently, in a dozen lines (identity of a field =
+its metadata minus `param`; bystanders first, in input order; then the groups in the order their identity first appeared, each as
+"returned inputs, then outputs"; the arithmetic by the oracle's array-level statements), and requires the same list: order, `param`,
+the group's own metadata on every output, values bit for bit (library functions to their tested ulp bounds).  Incomplete or duplicated
+groups must fail with ValueError both ways.  `ATX_MATCHING_SEEDS=first:count` widens the sweep.
+"""
+
+from __future__ import annotations
+
+import os
+
+import numpy as np
+import pytest
+
+from anemoi_transform_amd.fields import fieldlist_from_dicts
+from anemoi_transform_amd.filters import create_filter_by_name
+from oracle import oracle
+
+import native_double
+
+_FIRST, _COUNT = (int(v) for v in os.environ.get("ATX_MATCHING_SEEDS", "0:0").split(":"))
+SEEDS = range(_FIRST, _FIRST + _COUNT) if _COUNT else range(60)
+GRID = {"latitudes": np.linspace(80.0, -80.0, 37), "longitudes": np.linspace(0.0, 350.0, 37)}  # one latitude / longitude per point
+
+
+@pytest.fixture(params=["double", pytest.param("hip", marks=pytest.mark.gpu)])
+def engine(request, monkeypatch):
+    if request.param == "double":
+        native_double.install(monkeypatch)
+    return request.param
+
+
+# name -> (filter config, operand params in order, which inputs come back, outputs as (param, function of the operand arrays and level))
+def cases(rng):
+    return {
+        "snow_depth_m": (dict(), ["sd", "rsn"], [], [("sde", lambda a, lev: oracle.snow_depth_m(a[0], a[1]))]),
+        "snow_cover": (dict(), ["sd", "rsn"], [], [("snowc", lambda a, lev: oracle.snow_cover(a[0].copy(), a[1].copy()))]),
+        "cos_sin_from_rad": (dict(param="mdir"), ["mdir"], [], [("cos_mdir", lambda a, lev: oracle.cos_sin(a[0])[0]),
+                                                                ("sin_mdir", lambda a, lev: oracle.cos_sin(a[0])[1])]),
+        "cos_sin_mean_wave_direction": (dict(), ["mwd"], [], [("cos_mwd", lambda a, lev: oracle.cos_sin(a[0], True)[0]),
+                                                              ("sin_mwd", lambda a, lev: oracle.cos_sin(a[0], True)[1])]),
+        "w_to_wz": (dict(), ["w", "t", "q"], ["w", "t", "q"], [("wz", lambda a, lev: oracle.w_to_wz(a[0], a[1], a[2], lev))]),
+        "wz_to_w": (dict(), ["wz", "t", "q"], ["wz", "t", "q"], [("w", lambda a, lev: oracle.wz_to_w(a[0], a[1], a[2], lev))]),
+        # the backward transform of a reversible filter, through `.reverse()` (R: transform.py:175-244)
+        "cos_sin_from_rad reversed": (dict(param="mdir"), ["cos_mdir", "sin_mdir"], [],
+                                      [("mdir", lambda a, lev: oracle.direction_from_cos_sin(a[0], a[1]))]),
+    }
+
+
+def values_for(rng, param, n):
+    if param == "sd":
+        v = rng.uniform(0.0, 0.3, n)
+        v[rng.random(n) < 0.3] = 0.0
+        return v
+    if param == "rsn":
+        return rng.uniform(50.0, 600.0, n)
+    if param == "mdir":
+        return rng.uniform(-6.2, 6.2, n)
+    if param in ("cos_mdir", "sin_mdir"):
+        return rng.uniform(-1.0, 1.0, n)
+    if param == "mwd":
+        return rng.uniform(0.0, 360.0, n)
+    if param == "t":
+        return rng.uniform(200.0, 310.0, n)
+    if param == "q":
+        return rng.uniform(0.0, 0.02, n)
+    return rng.normal(0.0, 0.5, n)  # w, wz, bystanders
+
+
+def identity(spec):
+    return tuple(sorted((k, str(v)) for k, v in spec.items() if k not in ("param", "values", "latitudes", "longitudes")))
+
+
+def close(got, want, exact):
+    if exact:
+        return np.array_equal(got, want, equal_nan=True)
+    return np.allclose(got, want, rtol=1e-12, atol=1e-15, equal_nan=True)
+
+
+@pytest.mark.parametrize("seed", SEEDS)
+def test_all_groups_at_once_equal_the_reference_loop(engine, seed):
+    rng = np.random.default_rng(50_000 + seed)
+    table = cases(rng)
+    name = str(rng.choice(list(table)))
+    config, operands, returned, outputs = table[name]
+    n = len(GRID["latitudes"])
+    # (`date` / `time` are what a MARS namespace identifies a date by — R: tests/conftest.py:27-38; `valid_datetime` what plain metadata does)
+    dates = [(20200101 + d, f"2020-01-0{d + 1}T00:00:00Z") for d in range(int(rng.integers(1, 4)))]
+    levels = [int(v) for v in rng.choice([1000, 850, 700, 500, 300], size=int(rng.integers(1, 4)), replace=False)]
+    bystanders = [str(p) for p in rng.choice(["lsm", "z", "2t", "tp"], size=int(rng.integers(0, 3)), replace=False)]
+    specs = []
+    for date, valid in dates:
+        for level in levels:
+            for param in operands + bystanders:
+                specs.append({"param": param, "levelist": level, "date": date, "time": 0, "valid_datetime": valid,
+                              "values": values_for(rng, param, n), **GRID})
+    fault = rng.choice(["none", "none", "none", "none", "missing", "duplicate"])
+    if fault == "missing" and len(operands) > 1:
+        victim = next(i for i, s in enumerate(specs) if s["param"] == operands[-1])
+        del specs[victim]
+    elif fault == "duplicate":
+        specs.append(dict(next(s for s in specs if s["param"] == operands[0])))
+    else:
+        fault = "none"
+    specs = [specs[i] for i in rng.permutation(len(specs))]
+    mars = bool(rng.random() < 0.5)
+    fields = fieldlist_from_dicts(specs, mars=mars)
+
+    f = create_filter_by_name(name.split()[0], **config)
+    if name.endswith("reversed"):
+        f = f.reverse()
+    if fault != "none":
+        with pytest.raises(ValueError, match="Missing component|Duplicate component"):
+            f.forward(fields)
+        return
+    got = list(f.forward(fields))
+
+    # ---- the reference's loop, restated: bystanders first; groups in first-seen order; per group the returned inputs, then the outputs
+    want = [(s["param"], identity(s), np.asarray(s["values"]), True) for s in specs if s["param"] not in operands]
+    groups: dict[tuple, dict[str, dict]] = {}
+    for s in specs:
+        if s["param"] in operands:
+            groups.setdefault(identity(s), {})[s["param"]] = s
+    for ident, members in groups.items():
+        arrays = [np.asarray(members[p]["values"]) for p in operands]
+        for p in returned:
+            want.append((p, ident, np.asarray(members[p]["values"]), True))
+        level = np.float64(members[operands[0]]["levelist"])
+        for out_param, fn in outputs:
+            exact = name in ("snow_depth_m", "w_to_wz", "wz_to_w")  # plain arithmetic: numpy's bits; cos / sin / tanh: their tested ulp bounds
+            want.append((out_param, ident, fn(arrays, level), exact))
+
+    what = (seed, name, fault, mars, len(specs))
+    assert len(got) == len(want), what
+    for i, (field, (param, ident, values, exact)) in enumerate(zip(got, want)):
+        assert field.metadata("param") == param, (what, i, field.metadata("param"), param)
+        assert (("levelist", str(field.metadata("levelist"))) in ident) and (("valid_datetime", str(field.metadata("valid_datetime"))) in ident), (what, i)
+        assert close(field.to_numpy(flatten=True), values, exact), (what, i, param)
+        assert np.array_equal(field.grid_points()[0], GRID["latitudes"]), (what, i)
