@@ -123,3 +123,65 @@ def test_target_sharded_regrid(tmp_path, kind, world):
     seven peers per rank in the band exchange, eight broadcasts in the double-buffered step."""
     mp.spawn(_worker, args=(world, _free_port(), kind, str(tmp_path)), nprocs=world, join=True)
     assert all((tmp_path / f"ok{r}").exists() for r in range(world))
+
+
+
+def _random_worker(rank: int, world: int, port: int, first_seed: int, n_cases: int, tmpdir: str) -> None:
+    """Random matrices (tests/test_gather_random.py: uniform, ragged, long, empty rows, FEWER TARGETS THAN RANKS, no targets at all)
+    through the sharded step in its three forms; every rank draws the same matrix from the shared seed and owns its own source stack."""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import __graft_entry__ as graft
+
+    graft.load_package()
+    import torch.distributed as dist
+    from scipy.sparse import csr_array
+
+    import native_double
+    from anemoi_transform_amd import distributed as atxd
+    from anemoi_transform_amd.gather import GatherPlan
+    from anemoi_transform_amd.stack import Stack
+    from test_gather_random import random_matrix
+
+    native_double.install(_Patch())
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    assert atxd.init_process_group("gloo") == (rank, world)
+    cpu = torch.device("cpu")
+    for seed in range(first_seed, first_seed + n_cases):
+        matrix, style = random_matrix(np.random.default_rng(70_000 + seed))
+        n_tgt, n_src = (int(v) for v in matrix["matrix_shape"])
+        n_lev = 1 + seed % 3
+        m = csr_array((matrix["matrix_data"], matrix["matrix_indices"], matrix["matrix_indptr"]), shape=(n_tgt, n_src))
+        plan = GatherPlan.from_matrix(matrix)
+        sources = [280.0 + np.random.default_rng(1000 * seed + r).standard_normal((n_lev, n_src)) for r in range(world)]
+        mine = Stack.from_fields(sources[rank], dev=cpu)
+        lo, hi = plan.shard_range(rank, world)
+        what = (seed, style, n_tgt, n_src, world, rank)
+
+        def want(r):
+            full = np.stack([m @ level for level in sources[r]])
+            return full[:, lo:hi], full
+
+        stacks = atxd.exchange_stacks(mine)
+        for r, st in enumerate(stacks):
+            local = atxd.sharded_regrid(plan, st)
+            assert np.array_equal(local.numpy(), want(r)[0]), what
+            assert np.array_equal(atxd.gather_target_shards(local, plan).numpy(), want(r)[1]), what
+        bands, local_plan = atxd.exchange_source_bands(mine, plan)
+        for r, band in enumerate(bands):
+            assert np.array_equal(local_plan.apply(band).numpy(), want(r)[0]), what
+        for r, got in enumerate(atxd.pipelined_sharded_regrid(plan, mine)):
+            assert np.array_equal(got.numpy(), want(r)[0]), what
+    dist.barrier()
+    with open(os.path.join(tmpdir, f"ok{rank}"), "w") as f:
+        f.write("ok")
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,first_seed", [(3, 0), (5, 40)])
+def test_random_matrices_through_the_sharded_step(tmp_path, world, first_seed):
+    """40 random matrices per world size — among them target grids smaller than the number of ranks (empty shards: zero-row tables,
+    zero-byte bands) and none at all — through whole-stack exchange + sharded regrid + shard gather, the band-limited exchange, and the
+    double-buffered step, each against scipy's `csr_array @ x` on the rank's window."""
+    mp.spawn(_random_worker, args=(world, _free_port(), first_seed, 40, str(tmp_path)), nprocs=world, join=True)
+    assert all((tmp_path / f"ok{r}").exists() for r in range(world))
