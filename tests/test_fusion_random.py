@@ -248,6 +248,28 @@ def test_fused_pipeline_equals_filter_by_filter(engine, seed, tmp_path, monkeypa
         assert np.array_equal(np.signbit(va), np.signbit(vb)), (what, i)
         assert np.array_equal(a.grid_points()[0], b.grid_points()[0]) and np.array_equal(a.grid_points()[1], b.grid_points()[1]), (what, i)
 
+    # Pipeline.backward (R: workflows/pipeline.py:50-64: the filters' backward transforms in reverse order), fused the same way
+    reversible = {"rescale", "convert", "orog_to_z", "orog_to_z_fields", "z_to_orog", "lnsp_to_sp", "noop"}
+    if head is None and all(n in reversible for n, _ in tail):
+        def back(no_fusion):
+            if no_fusion:
+                monkeypatch.setenv("ATX_NO_FUSION", "1")
+            else:
+                monkeypatch.delenv("ATX_NO_FUSION", raising=False)
+            try:
+                return list(build(None, tail).backward(data)), None
+            except Exception as e:  # noqa: BLE001
+                return None, e
+
+        (fused_b, err_f), (plain_b, err_p) = back(False), back(True)
+        assert type(err_f) is type(err_p), (what, err_f, err_p)
+        if err_f is None:
+            assert len(fused_b) == len(plain_b), what
+            for i, (a, b) in enumerate(zip(fused_b, plain_b)):
+                assert describe(a) == describe(b), (what, "backward", i)
+                assert np.array_equal(a.to_numpy(flatten=True), b.to_numpy(flatten=True), equal_nan=True), (what, "backward", i)
+        monkeypatch.delenv("ATX_NO_FUSION", raising=False)
+
     # third leg: the oracle's restatement of the reference's filters, chained the same way (host float64 lists, unsharded heads)
     if device_input or any(s["values"].dtype != np.float64 for s in specs):
         return
