@@ -99,3 +99,35 @@ def test_prefetch_on_the_device_uploads_on_its_own_stream(dev):
         got.append([f.to_numpy(flatten=True) for f in regrid.forward(dev_fl)])
     assert len(streams) == 1  # the consumer stayed on its own stream throughout
     assert len(got) == 4 and all(np.array_equal(a, b) for x, y in zip(got, want) for a, b in zip(x, y))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("np_dtype", [np.float32, np.float64])
+def test_chunked_pinned_upload_and_download_keep_every_row(dev, monkeypatch, np_dtype):
+    """The host -> HBM path of `Stack.from_fields` above its pinned-staging threshold: rows copied by threads into two pinned chunks
+    that alternate under asynchronous DMAs, then one relayout — with the thresholds lowered so that a small stack takes many chunks
+    (at their real values only multi-GB uploads do: tests/test_gpu_plugin_fullsize.py samples seven fields of such a list).  Every row,
+    both layouts, odd sizes, source arrays of another width (cast on the way) and non-contiguous views; then `Stack.numpy()` back through
+    its pinned download."""
+    import torch
+
+    from anemoi_transform_amd import stack as stack_mod
+    from anemoi_transform_amd.stack import COLUMNS, FIELDS, Stack
+
+    monkeypatch.setattr(stack_mod, "_PINNED_MIN_BYTES", 1 << 10)
+    rng = np.random.default_rng(12)
+    for n_lev, n_pts, stage_bytes in ((37, 1001, 8 << 10), (5, 4099, 16 << 10), (64, 257, 4 << 10), (3, 70001, 1 << 20)):
+        monkeypatch.setattr(stack_mod, "_STAGE_BYTES", stage_bytes)
+        rows = [(250.0 + 30.0 * rng.standard_normal(n_pts)).astype(np_dtype) for _ in range(n_lev)]
+        rows[1 % n_lev] = rows[1 % n_lev].astype(np.float64 if np_dtype == np.float32 else np.float32)  # another width: cast while staging
+        wide = rng.standard_normal(2 * n_pts).astype(np_dtype)
+        rows[2 % n_lev] = wide[::2]  # a strided view
+        want = np.stack([np.asarray(r).astype(np_dtype) for r in rows])
+        tdtype = torch.float32 if np_dtype == np.float32 else torch.float64
+        for layout in (COLUMNS, FIELDS):
+            st = Stack.from_fields(rows, dtype=tdtype, dev=dev, layout=layout)
+            assert (st.n_lev, st.n_pts, st.layout, st.dtype) == (n_lev, n_pts, layout, tdtype)
+            got = st.numpy()
+            assert got.dtype == np_dtype and np.array_equal(got, want), (n_lev, n_pts, layout)
+            for level in (0, n_lev // 2, n_lev - 1):
+                assert np.array_equal(st.level_numpy(level), want[level])
