@@ -556,6 +556,19 @@ def main():
         try:
             multi_gpu_lines(args, result, dist, rank, world, dev, plan, stacks, launch, units_per_step * world, barrier, max_over_ranks,
                             src_grid, tgt_grid, n_src, n_tgt, tdtype, np_dtype, idx64, w64, layout, quiet.saved)
+        except Exception as e:  # noqa: BLE001
+            # An error OUTSIDE a section (sections catch their own): the other ranks are, or will be, inside a collective this rank will
+            # never join — no further collective from here.  The measured line goes out (rank 0) and the process ends with a failure
+            # status; the others leave through their watchdog the same way.
+            import traceback
+
+            traceback.print_exc(file=sys.stderr)
+            if rank == 0:
+                result["secondary_error"] = f"{type(e).__name__}: {e}"
+                result["wall_s"] = wall_seconds()
+                mirror_multi_gpu_into_config(result)
+                os.write(quiet.saved, (json.dumps(result) + "\n").encode())
+            os._exit(3)
         finally:
             quiet.__exit__()
 
@@ -807,8 +820,24 @@ def multi_gpu_lines(args, result, dist, rank, world, dev, plan, stacks, launch, 
     # ---- the source exchange itself, on the data group (RCCL): first use creates the communicators
     state["section"] = "data group"
     t_group = time.monotonic()
-    atxd.set_data_group(dist.new_group(backend=args.backend))
+    group_error = None
+    try:
+        atxd.set_data_group(dist.new_group(backend=args.backend))
+    except Exception as e:  # noqa: BLE001 - the collective library failing to come up must not cost the measured line
+        group_error = f"{type(e).__name__}: {e}"
+    ok = torch.tensor([0.0 if group_error else 1.0], dtype=torch.float64)
+    dist.all_reduce(ok, op=dist.ReduceOp.MIN)  # (on the host-side gloo group: all ranks take the same way from here)
     sections_s["data group"] = round(max_over_ranks(time.monotonic() - t_group), 3)
+    if ok.item() < 1.0:
+        result["source_exchange"] = {"error": group_error or "the data group failed on another rank"}
+        # what needs no exchange still runs
+        result["config4"] = section("config4", config4)
+        torch.cuda.empty_cache()
+        result["config5"] = section("config5", config5)
+        torch.cuda.empty_cache()
+        result["field_axis_sharding"] = section("field_axis_sharding", field_axis)
+        watchdog.cancel()
+        return
     if "error" in result["weak"] or "skipped" in result["weak"]:  # the exchange sections verify against `outs`: fill them whatever became of the timing
         weak_step()
         torch.cuda.synchronize()
