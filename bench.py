@@ -243,6 +243,7 @@ def mirror_multi_gpu_into_config(result: dict) -> None:
         "config4": pick("config4", "value", "ms_per_step"),
         "config5": pick("config5", "value", "ms_per_step"),
         "secondary_timed_out_in": result.get("secondary_timed_out_in"),
+        "secondary_error": result.get("secondary_error"),
         # the wall clock of the command (seconds, max over ranks): where the time of an N-rank run goes, and what was dropped to stay under the cap
         "wall_s": result.get("wall_s"),
         "setup_s": result.get("setup_s"),
@@ -630,6 +631,8 @@ def multi_gpu_lines(args, result, dist, rank, world, dev, plan, stacks, launch, 
     # A hung collective must not cost the line that is already measured: when the budget runs out every rank leaves, and
     # rank 0 prints what it has.  (Exceptions are caught per section; this is for waits that never return.)
     state = {"section": "start"}
+    if os.environ.get("ATX_BENCH_TEST_FAULT") == "outside_sections":  # test hook (tests/test_gpu_bench_contract.py)
+        raise RuntimeError("injected: a failure outside every section")
 
     def give_up():
         try:
@@ -822,6 +825,8 @@ def multi_gpu_lines(args, result, dist, rank, world, dev, plan, stacks, launch, 
     t_group = time.monotonic()
     group_error = None
     try:
+        if os.environ.get("ATX_BENCH_TEST_FAULT") == "data_group":  # test hook (tests/test_gpu_bench_contract.py)
+            raise RuntimeError("injected: the collective library did not come up")
         atxd.set_data_group(dist.new_group(backend=args.backend))
     except Exception as e:  # noqa: BLE001 - the collective library failing to come up must not cost the measured line
         group_error = f"{type(e).__name__}: {e}"

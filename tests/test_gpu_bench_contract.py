@@ -214,6 +214,35 @@ def test_total_seconds_cap_skips_sections_and_keeps_the_line():
     assert "value" in run.stderr and "after process start" in run.stderr  # the headline's ingredients went to stderr the moment they existed
 
 
+def _two_ranks(extra_env: dict, *flags: str):
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", *SMALL, "--backend", "gloo", "--share-device", *flags]
+    return subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT, env=dict(os.environ, **extra_env))
+
+
+def test_a_collective_library_that_does_not_come_up_costs_only_the_exchange_sections():
+    """The data group failing to come up (injected) is recorded, the sections that need no exchange still run, the line is printed, status 0."""
+    run = _two_ranks({"ATX_BENCH_TEST_FAULT": "data_group"})
+    assert run.returncode == 0, run.stderr[-2000:]
+    d = last_json(run.stdout)
+    assert d["value"] > 0 and d["weak"]["value"] > 0 and "injected" in d["source_exchange"]["error"]
+    assert d["config4"]["value"] > 0 and d["config5"]["value"] > 0 and d["field_axis_sharding"]["value"] > 0
+    assert "end_to_end" not in d and d["config"]["multi_gpu"]["end_to_end"] is None and d["wall_s"] > 0
+
+
+def test_a_failure_outside_every_section_still_prints_the_measured_line():
+    """An exception outside the per-section guards (injected): rank 0 prints `value` with `secondary_error`, every rank ends with a
+    failure status — no rank goes on into collectives the failed one will never join."""
+    run = _two_ranks({"ATX_BENCH_TEST_FAULT": "outside_sections"})
+    assert run.returncode != 0
+    d = last_json(run.stdout)
+    assert d["value"] > 0 and d["n_gpus"] == 2 and "injected" in d["secondary_error"]
+    assert d["config"]["multi_gpu"]["secondary_error"] == d["secondary_error"] and d["config"]["multi_gpu"]["strong"]["value"] == d["value"]
+
+
 def test_multi_gpu_sections_on_real_rccl_at_world_1():
     """Everything `bench.py --gpus N` does after `value` — the nccl data group, both exchanges, end to end, and the same through
     the C-ABI communicator — on the real collective library, at the world size one GPU allows."""
