@@ -94,7 +94,7 @@ def random_head(rng, src, tgt, tables):
     return cfg
 
 
-def random_tail(rng, n_points_for_mask, tmp_path, seed):
+def random_tail(rng, n_points_for_mask, tmp_path, seed, present):
     """1-6 filter configs; most fusable, some that cut the fused segment."""
     pool = [
         lambda: ("rescale", dict(scale=float(rng.choice([1.0, 2.0, 0.5, 1.8])), offset=float(rng.choice([0.0, -273.15, 32.0])), param=str(rng.choice(PARAMS)))),
@@ -107,10 +107,16 @@ def random_tail(rng, n_points_for_mask, tmp_path, seed):
         lambda: ("lnsp_to_sp", {}),
         lambda: ("rename", dict(param={"q": "qq"}) if rng.random() < 0.5 else dict(param={"t": "temp"})),
         lambda: ("apply_mask_file", None),
-        lambda: ("remove_nans", {}),
+        lambda: ("remove_nans", {} if rng.random() < 0.6 else dict(param=str(rng.choice(PARAMS)))),
         lambda: ("noop", {}),
+        # the mask taken from a field of the stream (R: apply_mask.py:194-218): first field of that name, consumed unless `return_mask`
+        lambda: ("apply_mask", dict(mask_param=str(rng.choice(present if rng.random() < 0.85 else PARAMS)),
+                                    **(dict(mask_value=float(rng.choice([0.0, 1.0, 250.0]))) if rng.random() < 0.3 else
+                                       dict(threshold=float(rng.uniform(240.0, 320.0)), threshold_operator=str(rng.choice([">", "<", ">=", "<=", "gt", "le", "ne"])))),
+                                    **({"param": [str(p) for p in rng.choice(PARAMS, size=2, replace=False)]} if rng.random() < 0.6 else {}),
+                                    **({"rename": "m"} if rng.random() < 0.3 else {}), return_mask=bool(rng.random() < 0.4))),
     ]
-    weights = np.array([3, 2, 2, 1, 1, 2, 2, 1, 1, 2, 0.5, 0.5])
+    weights = np.array([3, 2, 2, 1, 1, 2, 2, 1, 1, 2, 0.5, 0.5, 1.5])
     tail = []
     for _ in range(int(rng.integers(1, 7))):
         name, cfg = pool[int(rng.choice(len(pool), p=weights / weights.sum()))]()
@@ -173,11 +179,13 @@ def oracle_chain(specs, head, tail, src, tgt, tables):
             fields = oracle.filter_impute_nans(fields, **cfg)
         elif name == "lnsp_to_sp":
             fields = oracle.filter_lnsp_to_sp(fields)
-        elif name == "apply_mask":
+        elif name == "apply_mask" and "path" in cfg:
             fields = oracle.filter_apply_mask(fields, mask_values=np.load(cfg["path"]), mask_value=cfg["mask_value"], param=cfg["param"],
                                               rename=cfg.get("rename"))
+        elif name == "apply_mask":
+            fields = oracle.filter_apply_mask(fields, **cfg)
         elif name == "remove_nans":
-            fields = oracle.filter_remove_nans(fields)
+            fields = oracle.filter_remove_nans(fields, **cfg)
         elif name == "noop":
             pass
         else:
@@ -206,7 +214,7 @@ def test_fused_pipeline_equals_filter_by_filter(engine, seed, tmp_path, monkeypa
         n_mask = None if head.get("shard") else len(keep)
     else:
         n_mask = n_tgt
-    tail = random_tail(rng, n_mask, tmp_path, seed)
+    tail = random_tail(rng, n_mask, tmp_path, seed, sorted({s["param"] for s in specs}))
     if rng.random() < 0.15:
         monkeypatch.setattr(fields_mod, "MAX_STACK_LEVELS", 4)  # long lists in several stacks
 
