@@ -142,3 +142,57 @@ def test_all_groups_at_once_equal_the_reference_loop(engine, seed):
         assert (("levelist", str(field.metadata("levelist"))) in ident) and (("valid_datetime", str(field.metadata("valid_datetime"))) in ident), (what, i)
         assert close(field.to_numpy(flatten=True), values, exact), (what, i, param)
         assert np.array_equal(field.grid_points()[0], GRID["latitudes"]), (what, i)
+
+
+@pytest.mark.parametrize("seed", range(60) if not _COUNT else SEEDS)
+def test_sum_and_accum_to_interval_on_random_lists(engine, seed):
+    """`sum` (R: filters/fields/sum.py:72-121: MARS identity minus `param` — minus `levelist` with `ignore_level` —, bystanders first,
+    the terms added in the order the fields come, the first term as template) and `accum_to_interval`
+    (R: accum_to_interval.py:73-101, restated by `oracle.filter_accum_to_interval`) on random lists."""
+    rng = np.random.default_rng(60_000 + seed)
+    n = len(GRID["latitudes"])
+    if rng.random() < 0.5:
+        terms = [str(p) for p in rng.choice(["cp", "lsp", "sf", "tp2", "e"], size=int(rng.integers(1, 5)), replace=False)]
+        ignore_level = bool(rng.random() < 0.3)
+        levels = [850] if ignore_level else [int(v) for v in rng.choice([1000, 850, 500], size=int(rng.integers(1, 3)), replace=False)]
+        specs = []
+        for date in range(int(rng.integers(1, 4))):
+            for level in levels:
+                for j, param in enumerate(terms + [str(p) for p in rng.choice(["z", "lsm"], size=int(rng.integers(0, 3)), replace=False)]):
+                    # with ignore_level the terms of one date may sit on different levels: the level leaves the identity
+                    lev = level + (j if ignore_level else 0)
+                    specs.append({"param": param, "levelist": lev, "date": 20200101 + date, "time": 0, "values": rng.normal(0.0, 3.0, n), **GRID})
+        specs = [specs[i] for i in rng.permutation(len(specs))]
+        fields = fieldlist_from_dicts(specs, mars=True)
+        got = list(create_filter_by_name("sum", params=terms, output="total", ignore_level=ignore_level).forward(fields))
+        want = [(s["param"], np.asarray(s["values"])) for s in specs if s["param"] not in terms]
+        groups: dict[tuple, list[dict]] = {}
+        for s in specs:
+            if s["param"] in terms:
+                key = (s["date"], s["time"]) + (() if ignore_level else (s["levelist"],))
+                groups.setdefault(key, []).append(s)
+        for members in groups.values():
+            assert len(members) == len(terms)
+            want.append(("total", oracle.sum_fields([np.asarray(m["values"]) for m in members])))
+        assert len(got) == len(want), (seed, terms, ignore_level)
+        for f, (param, values) in zip(got, want):
+            assert f.metadata("param") == param and np.array_equal(f.to_numpy(flatten=True), values), (seed, param)
+        return
+    variables = [str(p) for p in rng.choice(["tp", "cp", "sf"], size=int(rng.integers(1, 3)), replace=False)]
+    zero_left = bool(rng.random() < 0.6)
+    specs = []
+    for param in variables + [str(p) for p in rng.choice(["2t", "z"], size=int(rng.integers(0, 3)), replace=False)]:
+        for level in ([None] if rng.random() < 0.5 else [850, 500]):
+            running = np.zeros(n)
+            for hour in range(int(rng.integers(1, 6))):
+                running = running + np.abs(rng.normal(0.0, 1.0, n))
+                specs.append({"param": param, "level": level, "levelType": "sfc" if level is None else "pl",
+                              "valid_datetime": f"2020-01-01T{6 * hour:02d}:00:00", "values": running.copy(), **GRID})
+    specs = [specs[i] for i in rng.permutation(len(specs))]
+    fields = fieldlist_from_dicts(specs)
+    got = list(create_filter_by_name("accum_to_interval", variables=variables, zero_left=zero_left).forward(fields))
+    want = oracle.filter_accum_to_interval([dict(s) for s in specs], variables=variables, zero_left=zero_left)
+    assert len(got) == len(want), (seed, variables, zero_left)
+    for f, w_ in zip(got, want):
+        assert (f.metadata("param"), f.metadata("valid_datetime")) == (w_["param"], w_["valid_datetime"]), seed
+        assert np.array_equal(f.to_numpy(flatten=True), np.asarray(w_["values"]).ravel()), (seed, w_["param"])
