@@ -248,6 +248,26 @@ def test_remove_nans_field_on_another_grid_raises_numpys_error(engine):
         list(test_source(specs) | create_filter_by_name("remove_nans"))
 
 
+def test_filters_on_fields_of_zero_points(engine):
+    """A first field that is NaN everywhere leaves `remove_nans` with fields of ZERO points (R: remove_nans.py:101-116: `data[mask]` of an
+    all-False mask); the filters behind it must take such fields — numpy does — instead of tripping over empty device buffers."""
+    from anemoi_transform_amd.grids import lookup
+
+    g = lookup("o8")
+    n = len(g["latitudes"])
+    specs = [{"param": p, "levelist": 1, "values": np.full(n, np.nan) if i == 0 else 250.0 + np.arange(n, dtype=np.float64),
+              "latitudes": g["latitudes"], "longitudes": g["longitudes"]} for i, p in enumerate(["t", "q", "orog"])]
+    pipeline = (test_source(specs) | create_filter_by_name("remove_nans") | create_filter_by_name("rescale", scale=2.0, offset=1.0, param="q")
+                | create_filter_by_name("orog_to_z") | create_filter_by_name("clip", param="t", minimum=0.0))
+    out = list(pipeline)
+    assert [f.metadata("param") for f in out] == ["t", "q", "z"]
+    for f in out:
+        assert f.to_numpy(flatten=True).shape == (0,) and f.grid_points()[0].shape == (0,)
+    # and a regrid of such fields through an (empty) index list
+    again = list(test_source(specs) | create_filter_by_name("remove_nans") | create_filter_by_name("regrid", mask=np.zeros(0, dtype=np.int64)))
+    assert len(again) == 3 and all(f.to_numpy().shape == (0,) for f in again)
+
+
 def test_remove_nans_invalid_method():
     with pytest.raises(AssertionError, match="Method invalid_method not implemented"):
         create_filter_by_name("remove_nans", method="invalid_method")
